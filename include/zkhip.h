@@ -1,0 +1,78 @@
+/* zkhip - C ABI of the MI355X (gfx950) wrapping-prover kernels.
+ *
+ * This is the drop-in boundary for the hot path of clearmatics/zecale:
+ *   libzecale::aggregator_circuit::prove -> wsnarkT::generate_proof(pk, pb)
+ *   (reference libzecale/circuits/aggregator_circuit.tcc:168; policy class wsnarkT =
+ *    libzeth::groth16_snark<libff::bw6_761_pp>, aggregator_server/aggregator_server.cpp:61).
+ * The reference has no FFI of its own (its seams are C++ template parameters); the
+ * entry points below are what a `groth16_snark_hip<wppT>` policy class binds.
+ *
+ * Conventions
+ *   - Field elements are little-endian arrays of 64-bit limbs in Montgomery form, radix 2^768
+ *     (Fq, 12 limbs) / 2^384 (Fr, 6 limbs), fully reduced - libff's in-memory Fp_model layout.
+ *   - Affine points: x then y (24 limbs).  The point at infinity is the all-zero pattern.
+ *   - Jacobian points: X, Y, Z (36 limbs), infinity <=> Z = 0.  Both G1 and G2 of BW6-761 are
+ *     over Fq, so every point entry point serves both groups.
+ *   - All functions return ZKHIP_OK (0) or a negative error code; no exceptions cross the ABI.
+ *   - One context per process; calls are serialised by the caller (not re-entrant).
+ *   - `_dev` variants take DEVICE pointers (e.g. torch tensor data_ptr()); the others take host
+ *     pointers and stage through HBM themselves.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKHIP_OK 0
+#define ZKHIP_ERR_ARG (-1)        /* bad argument */
+#define ZKHIP_ERR_NO_DEVICE (-2)  /* no gfx950 device / HIP runtime unavailable */
+#define ZKHIP_ERR_HIP (-3)        /* a HIP call failed; see zkhip_last_error() */
+#define ZKHIP_ERR_STATE (-4)      /* library not initialised / handle invalid */
+
+typedef struct zkhip_bases zkhip_bases; /* opaque: a base-point set resident in HBM */
+
+/* replaces: libff::bw6_761_pp::init_public_params() + device selection
+ * (aggregator_server/aggregator_server.cpp:476-477) */
+int zkhip_init(int device);
+void zkhip_shutdown(void);
+const char* zkhip_strerror(int code);
+const char* zkhip_last_error(void);
+
+/* Window size (bits) of the bucket method; 0 = automatic from len. */
+int zkhip_set_msm_window(int c);
+
+/* replaces: holding r1cs_gg_ppzksnark_proving_key query vectors in host memory
+ * (aggregator_server/aggregator_server.cpp:483-514 loads the keypair once).
+ * Copies `len` affine points (len x 24 limbs) into HBM in the kernels' packed layout. */
+int zkhip_bases_upload(const uint64_t* bases_affine, size_t len, zkhip_bases** out);
+int zkhip_bases_upload_dev(const void* d_bases_affine, size_t len, zkhip_bases** out);
+size_t zkhip_bases_len(const zkhip_bases* b);
+void zkhip_bases_free(zkhip_bases* b);
+
+/* replaces: libff::multi_exp<G, Fr, multi_exp_method_BDLO12>(bases, scalars, chunks)
+ * as called five times by r1cs_gg_ppzksnark_prover (reached from aggregator_circuit.tcc:168).
+ * result = sum_{i<len} scalars[i] * bases[offset + i].
+ * scalars: len x 6 limbs, Montgomery form (scalars_montgomery = 1) or canonical integers (0). */
+int zkhip_msm(const zkhip_bases* bases, size_t offset, const uint64_t* scalars, size_t len, int scalars_montgomery,
+              uint64_t out_jac[36]);
+int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery,
+                  uint64_t out_jac[36]);
+/* one-shot form (BASELINE config 2): host bases + host scalars */
+int zkhip_msm_raw(const uint64_t* bases_affine, const uint64_t* scalars, size_t len, int scalars_montgomery,
+                  uint64_t out_jac[36]);
+
+/* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
+float zkhip_last_accumulate_ms(void);
+
+/* host helpers on results (tiny, serial): Jacobian -> affine (infinity -> all zero), a + b */
+int zkhip_jac_to_affine(const uint64_t jac[36], uint64_t aff[24]);
+int zkhip_jac_add(const uint64_t a[36], const uint64_t b[36], uint64_t out[36]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKHIP_H */

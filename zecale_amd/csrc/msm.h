@@ -1,0 +1,32 @@
+// Internal interface of the MSM engine (msm.hip).  The public C ABI is include/zkhip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/zkhip.h"
+
+namespace zkhip {
+
+struct AffPacked;
+
+struct MsmCtx {
+  int c, W, L, logL;
+  size_t B, max_n;
+  hipStream_t stream, stream2;
+  hipEvent_t ev, ev_acc0, ev_acc1;
+  int32_t* digits;
+  uint32_t *counts, *offsets, *cursor, *block_tot, *entries;
+  uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels;
+  uint64_t *win_abi, *win_host;
+  float last_accumulate_ms;
+  char errbuf[256];
+};
+
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c);
+void msm_plan_free(MsmCtx* ctx);
+int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPacked* d_out);
+int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, size_t n, int scalars_montgomery,
+            uint64_t out_jac[36]);
+
+}  // namespace zkhip

@@ -1,0 +1,388 @@
+// Multi-scalar multiplication in G1 / G2 of BW6-761 on gfx950 (Pippenger / bucket method with
+// signed digits).  Replaces the five libff::multi_exp calls the reference reaches through
+// wsnarkT::generate_proof (libzecale/circuits/aggregator_circuit.tcc:168).
+//
+// Pipeline (all kernels hand-written for wave64; one lane owns one field element, see fp29.cuh):
+//   k_bases_to_dev      ABI affine points -> packed device-form points (once per base set)
+//   k_scalar_digits     Montgomery scalars -> canonical -> signed c-bit digits + bucket histogram
+//   k_scan_*            exclusive prefix sum of the histogram (bucket offsets)
+//   k_scatter           counting-sort scatter: bucket-ordered list of (point index, sign)
+//   k_accumulate        one lane per bucket: XYZZ mixed additions of its points   <-- dominant
+//   k_seg / k_sum       bucket reduction  sum_j (j+1) B_j  by recursive L-ary running sums
+//   k_window_combine    per window: R0 + L (R1 + L (R2 + ...))
+// The last step, sum_w 2^(c w) W_w (about 380 serial doublings of ONE point), runs on the host:
+// a serial chain has no parallelism for a GPU lane (one lane needs ~5 us per Fq multiplication).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "ec.cuh"
+#include "host_field.hpp"
+#include "msm.h"
+
+namespace zkhip {
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+
+// one thread per point: 24 u64 (x, y in ABI Montgomery form; all-zero = infinity) -> AffPacked
+__global__ void __launch_bounds__(256) k_bases_to_dev(const uint64_t* __restrict__ in, AffPacked* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t x[12], y[12];
+  uint64_t nz = 0;
+#pragma unroll
+  for (int k = 0; k < 12; k++) { x[k] = in[i * 24 + k]; y[k] = in[i * 24 + 12 + k]; nz |= x[k] | y[k]; }
+  AffPacked p;
+  if (nz == 0) {
+#pragma unroll
+    for (int k = 0; k < 24; k++) { p.x[k] = 0; p.y[k] = 0; }
+  } else {
+    Fq fx = fp_cond_sub_p(fp_from_abi<FqParams>(x));
+    Fq fy = fp_cond_sub_p(fp_from_abi<FqParams>(y));
+    fp_pack32<FqParams>(fx, p.x);
+    fp_pack32<FqParams>(fy, p.y);
+  }
+  out[i] = p;
+}
+
+// one thread per scalar.  digits[w*n + i] = signed digit of window w (|d| <= 2^(c-1));
+// counts[w*B + |d|-1] += 1 for d != 0.
+__global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restrict__ scalars, size_t n, int c, int W,
+                                                        int montgomery, int32_t* __restrict__ digits,
+                                                        uint32_t* __restrict__ counts) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t s[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) s[k] = scalars[i * 6 + k];
+  uint32_t w32[13];
+  if (montgomery) {
+    fp_abi_to_canonical_words<FrParams>(s, w32);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) { w32[2 * k] = (uint32_t)s[k]; w32[2 * k + 1] = (uint32_t)(s[k] >> 32); }
+  }
+  w32[12] = 0;
+  const uint32_t B = 1u << (c - 1);
+  const uint32_t mask = (1u << c) - 1;
+  uint32_t carry = 0;
+  for (int w = 0; w < W; w++) {
+    int bit = w * c;
+    uint32_t d = 0;
+    if (bit < 384) {
+      int j = bit >> 5, sh = bit & 31;
+      uint64_t v = (uint64_t)w32[j] >> sh;
+      if (j + 1 < 13) v |= (uint64_t)w32[j + 1] << (32 - sh);
+      d = (uint32_t)v & mask;
+    }
+    d += carry;
+    int32_t sd;
+    if (d > B) { sd = (int32_t)d - (int32_t)(1u << c); carry = 1; }
+    else { sd = (int32_t)d; carry = 0; }
+    digits[(size_t)w * n + i] = sd;
+    if (sd != 0) {
+      uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
+      atomicAdd(&counts[(size_t)w * B + (mag - 1)], 1u);
+    }
+  }
+}
+
+// ---- exclusive scan over `m` u32 counters, 1024 per block ----
+__global__ void __launch_bounds__(256) k_scan_local(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                     uint32_t* __restrict__ block_tot, size_t m) {
+  __shared__ uint32_t sh[256];
+  size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
+  uint32_t v[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { v[k] = (base + k < m) ? in[base + k] : 0; sum += v[k]; }
+  sh[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    uint32_t t = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t excl = sh[threadIdx.x] - sum;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { if (base + k < m) out[base + k] = excl; excl += v[k]; }
+  if (threadIdx.x == 255) block_tot[blockIdx.x] = sh[255];
+}
+
+__global__ void __launch_bounds__(1024) k_scan_tot(uint32_t* __restrict__ block_tot, size_t nb) {
+  // single block, sequential over chunks of 1024
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (size_t base = 0; base < nb; base += 1024) {
+    size_t i = base + threadIdx.x;
+    uint32_t v = (i < nb) ? block_tot[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint32_t t = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) block_tot[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_tot, size_t m) {
+  size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
+  uint32_t add = block_tot[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (base + k < m) out[base + k] += add;
+}
+
+__global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, size_t n, int c, int W,
+                                                  const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                  uint32_t* __restrict__ entries) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t B = 1u << (c - 1);
+  for (int w = 0; w < W; w++) {
+    int32_t sd = digits[(size_t)w * n + i];
+    if (sd == 0) continue;
+    uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
+    size_t b = (size_t)w * B + (mag - 1);
+    uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
+    entries[pos] = (uint32_t)i | (sd < 0 ? 0x80000000u : 0u);
+  }
+}
+
+// One lane per bucket.  `order` (optional) maps thread -> bucket so that lanes of a wave get
+// buckets of similar population.
+__global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ entries,
+                                                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                        size_t nbuckets, uint32_t* __restrict__ out /* XYZZ limb-major, stride nbuckets */) {
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  uint32_t start = offsets[b], cnt = counts[b];
+  XYZZ acc = xyzz_infinity();
+  for (uint32_t k = 0; k < cnt; k++) {
+    uint32_t e = entries[start + k];
+    AffineDev p = aff_load(&bases[e & 0x7fffffffu]);
+    if (p.inf) continue;
+    if (e & 0x80000000u) p.y = fp_sub<FqParams, 2>(fp_zero<FqParams>(), p.y);   // [2]... value p - y, < 2p
+    xyzz_madd(acc, p.x, p.y);
+  }
+  xyzz_store(out, nbuckets, b, acc);
+}
+
+// Segment pass of the bucket reduction.  in: n_in items (XYZZ limb-major, stride n_in), grouped in
+// runs of L.  For segment t: S_t = sum_u item[tL+u],  R_t = sum_u (u + o) item[tL+u]   (o in {0,1}).
+__global__ void __launch_bounds__(256, 2) k_seg(const uint32_t* __restrict__ in, size_t n_in, int L, int o,
+                                                 uint32_t* __restrict__ outS, uint32_t* __restrict__ outR) {
+  size_t n_out = n_in / L;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out) return;
+  XYZZ run = xyzz_infinity(), acc = xyzz_infinity();
+  for (int u = L - 1; u >= 0; u--) {
+    XYZZ it = xyzz_load(in, n_in, t * L + u);
+    xyzz_add(run, it);
+    if (u + o > 0) xyzz_add(acc, run);
+  }
+  xyzz_store(outS, n_out, t, run);
+  xyzz_store(outR, n_out, t, acc);
+}
+
+// out[t] = sum_u in[tL + u]
+__global__ void __launch_bounds__(256, 2) k_sum(const uint32_t* __restrict__ in, size_t n_in, int L, uint32_t* __restrict__ out) {
+  size_t n_out = n_in / L;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out) return;
+  XYZZ run = xyzz_load(in, n_in, t * L);
+  for (int u = 1; u < L; u++) {
+    XYZZ it = xyzz_load(in, n_in, t * L + u);
+    xyzz_add(run, it);
+  }
+  xyzz_store(out, n_out, t, run);
+}
+
+// per window w: out[w] = R[0][w] + L (R[1][w] + L (R[2][w] + ...)), levels-1 .. 0.
+// R_all: `levels` arrays of W XYZZ points each, limb-major with stride W, consecutive (108*W words apart).
+struct LevelShifts { uint8_t log_l[32]; };
+__global__ void __launch_bounds__(64, 2) k_window_combine(const uint32_t* __restrict__ R_all, int levels, int W, LevelShifts ls,
+                                                           uint64_t* __restrict__ out_abi /* W x 4 x 12 u64 */) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  XYZZ acc = xyzz_load(R_all + (size_t)(levels - 1) * 108 * W, W, w);
+  for (int k = levels - 2; k >= 0; k--) {
+    for (int d = 0; d < ls.log_l[k]; d++) acc = xyzz_dbl(acc);
+    XYZZ r = xyzz_load(R_all + (size_t)k * 108 * W, W, w);
+    xyzz_add(acc, r);
+  }
+  uint64_t* o = out_abi + (size_t)w * 48;
+  fp_to_abi<FqParams>(acc.X, o);
+  fp_to_abi<FqParams>(acc.Y, o + 12);
+  fp_to_abi<FqParams>(acc.ZZ, o + 24);
+  fp_to_abi<FqParams>(acc.ZZZ, o + 36);
+}
+
+// ------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------
+#define HIP_TRY(x)                                                                  \
+  do {                                                                              \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) {                                                         \
+      snprintf(ctx->errbuf, sizeof ctx->errbuf, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return ZKHIP_ERR_HIP;                                                         \
+    }                                                                               \
+  } while (0)
+
+static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c) {
+  memset(ctx, 0, sizeof *ctx);
+  if (c < 4 || c > 20) return ZKHIP_ERR_ARG;
+  ctx->c = c;
+  ctx->W = (378 + c - 1) / c;   // scalars < 2^377, +1 bit for the signed-digit carry
+  ctx->B = (size_t)1 << (c - 1);
+  ctx->max_n = max_n;
+  ctx->L = 4; ctx->logL = 2;
+  size_t nb = ctx->B * ctx->W;
+  HIP_TRY(hipStreamCreate(&ctx->stream));
+  HIP_TRY(hipStreamCreate(&ctx->stream2));
+  HIP_TRY(hipEventCreateWithFlags(&ctx->ev, hipEventDisableTiming));
+  HIP_TRY(hipEventCreate(&ctx->ev_acc0));
+  HIP_TRY(hipEventCreate(&ctx->ev_acc1));
+  HIP_TRY(hipMalloc(&ctx->digits, (size_t)ctx->W * max_n * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&ctx->counts, nb * 4));
+  HIP_TRY(hipMalloc(&ctx->offsets, nb * 4));
+  HIP_TRY(hipMalloc(&ctx->cursor, nb * 4));
+  HIP_TRY(hipMalloc(&ctx->block_tot, (nb / 1024 + 2) * 4));
+  HIP_TRY(hipMalloc(&ctx->entries, (size_t)ctx->W * max_n * 4));
+  HIP_TRY(hipMalloc(&ctx->buckets, nb * 108 * 4));
+  // reduction scratch: S ping-pong (<= nb/L each) and R arrays (sum over levels <= nb/L * L/(L-1)), R sums
+  HIP_TRY(hipMalloc(&ctx->segS[0], (nb / ctx->L + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->segS[1], (nb / ctx->L + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->segR, (nb / ctx->L + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->sumR[0], (nb / ctx->L / ctx->L + ctx->W + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->sumR[1], (nb / ctx->L / ctx->L + ctx->W + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->Rlevels, (size_t)32 * ctx->W * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->win_abi, (size_t)ctx->W * 48 * 8));
+  HIP_TRY(hipHostMalloc(&ctx->win_host, (size_t)ctx->W * 48 * 8));
+  return ZKHIP_OK;
+}
+
+void msm_plan_free(MsmCtx* ctx) {
+  void* ptrs[] = {ctx->digits, ctx->counts, ctx->offsets, ctx->cursor, ctx->block_tot, ctx->entries, ctx->buckets,
+                  ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (ctx->win_host) (void)hipHostFree(ctx->win_host);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->ev) (void)hipEventDestroy(ctx->ev);
+  if (ctx->ev_acc0) (void)hipEventDestroy(ctx->ev_acc0);
+  if (ctx->ev_acc1) (void)hipEventDestroy(ctx->ev_acc1);
+  memset(ctx, 0, sizeof *ctx);
+}
+
+int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPacked* d_out) {
+  hipLaunchKernelGGL(k_bases_to_dev, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_bases_abi, d_out, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ZKHIP_OK;
+}
+
+// d_bases: packed device-form points; d_scalars: n x 6 u64 (device memory).  Result: Jacobian, ABI form (host).
+int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, size_t n, int scalars_montgomery,
+            uint64_t out_jac[36]) {
+  using namespace host;
+  if (n > ctx->max_n) return ZKHIP_ERR_ARG;
+  const int c = ctx->c, W = ctx->W;
+  const size_t B = ctx->B, nb = B * W;
+  hipStream_t st = ctx->stream;
+  if (n == 0) {
+    HJac inf = HJac::infinity();
+    inf.X.to_limbs(out_jac); inf.Y.to_limbs(out_jac + 12); inf.Z.to_limbs(out_jac + 24);
+    return ZKHIP_OK;
+  }
+  HIP_TRY(hipMemsetAsync(ctx->counts, 0, nb * 4, st));
+  HIP_TRY(hipMemsetAsync(ctx->cursor, 0, nb * 4, st));
+  hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(n, 256)), dim3(256), 0, st, d_scalars, n, c, W, scalars_montgomery,
+                     ctx->digits, ctx->counts);
+  unsigned sb = nblk(nb, 1024);
+  hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->counts, ctx->offsets, ctx->block_tot, nb);
+  hipLaunchKernelGGL(k_scan_tot, dim3(1), dim3(1024), 0, st, ctx->block_tot, (size_t)sb);
+  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, ctx->offsets, ctx->block_tot, nb);
+  hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->digits, n, c, W, ctx->offsets, ctx->cursor,
+                     ctx->entries);
+  HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
+  hipLaunchKernelGGL(k_accumulate, dim3(nblk(nb, 256)), dim3(256), 0, st, d_bases, ctx->entries, ctx->offsets, ctx->counts,
+                     nb, ctx->buckets);
+  HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
+  HIP_TRY(hipGetLastError());
+
+  // bucket reduction: F(items) = sum_t R_t + L * F0(S), recursively; levels until one item per window
+  const uint32_t* cur = ctx->buckets;
+  size_t n_cur = nb;   // W groups of n_cur / W
+  int level = 0;
+  LevelShifts ls;
+  memset(&ls, 0, sizeof ls);
+  while (n_cur > (size_t)W) {
+    int L = ctx->L;
+    while ((size_t)L > n_cur / W) L >>= 1;      // last level: fewer items per window than L
+    int lg = 0; while ((1 << lg) < L) lg++;
+    ls.log_l[level] = (uint8_t)lg;
+    size_t n_out = n_cur / L;
+    uint32_t* S = ctx->segS[level & 1];
+    hipLaunchKernelGGL(k_seg, dim3(nblk(n_out, 256)), dim3(256), 0, st, cur, n_cur, L, level == 0 ? 1 : 0, S, ctx->segR);
+    // reduce R (n_out items, W groups) to W items: Rlevels[level]
+    const uint32_t* rc = ctx->segR;
+    size_t rn = n_out;
+    int pp = 0;
+    while (rn > (size_t)W) {
+      int Ls = ctx->L;
+      while ((size_t)Ls > rn / W) Ls >>= 1;
+      size_t ro = rn / Ls;
+      uint32_t* dst = (ro == (size_t)W) ? ctx->Rlevels + (size_t)level * 108 * W : ctx->sumR[pp];
+      hipLaunchKernelGGL(k_sum, dim3(nblk(ro, 256)), dim3(256), 0, st, rc, rn, Ls, dst);
+      rc = dst; rn = ro; pp ^= 1;
+    }
+    if (n_out == (size_t)W) {   // R already one per window
+      HIP_TRY(hipMemcpyAsync(ctx->Rlevels + (size_t)level * 108 * W, ctx->segR, (size_t)108 * W * 4, hipMemcpyDeviceToDevice, st));
+    }
+    cur = S; n_cur = n_out; level++;
+  }
+  // the last S (one item per window) has weight 0 at its level (o = 0 for level >= 1) and is dropped.
+  hipLaunchKernelGGL(k_window_combine, dim3(nblk(W, 64)), dim3(64), 0, st, ctx->Rlevels, level, W, ls, ctx->win_abi);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(ctx->win_host, ctx->win_abi, (size_t)W * 48 * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
+  ctx->last_accumulate_ms = ms;
+
+  // host: sum_w 2^(c w) W_w  (Horner from the top window)
+  HJac acc = HJac::infinity();
+  for (int w = W - 1; w >= 0; w--) {
+    for (int d = 0; d < c; d++) acc = acc.dbl();
+    const uint64_t* p = ctx->win_host + (size_t)w * 48;
+    HFq X = HFq::from_limbs(p), Y = HFq::from_limbs(p + 12), ZZ = HFq::from_limbs(p + 24), ZZZ = HFq::from_limbs(p + 36);
+    if (ZZ.is_zero()) continue;
+    // XYZZ -> Jacobian with Z = ZZ*ZZZ:  X' = X ZZ ZZZ^2,  Y' = Y ZZ^3 ZZZ^2
+    HFq z3s = ZZZ.sqr(), zz2 = ZZ.sqr();
+    HJac q;
+    q.X = X * ZZ * z3s;
+    q.Y = Y * zz2 * ZZ * z3s;
+    q.Z = ZZ * ZZZ;
+    acc = acc.add(q);
+  }
+  acc.X.to_limbs(out_jac); acc.Y.to_limbs(out_jac + 12); acc.Z.to_limbs(out_jac + 24);
+  return ZKHIP_OK;
+}
+
+}  // namespace zkhip
