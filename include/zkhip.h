@@ -65,6 +65,15 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
 int zkhip_msm_raw(const uint64_t* bases_affine, const uint64_t* scalars, size_t len, int scalars_montgomery,
                   uint64_t out_jac[36]);
 
+/* replaces: the fixed-base batch exponentiations of r1cs_gg_ppzksnark_generator, reached from
+ * aggregator_circuit::generate_trusted_setup (libzecale/circuits/aggregator_circuit.tcc:100-109).
+ * out[i] = scalars[i] * base, affine (len x 24 limbs).  base: one affine point (host memory).
+ * The _dev form reads scalars from and writes points to DEVICE memory. */
+int zkhip_fixed_base_mul(const uint64_t base_affine[24], const uint64_t* scalars, size_t len, int scalars_montgomery,
+                         uint64_t* out_affine);
+int zkhip_fixed_base_mul_dev(const uint64_t base_affine[24], const void* d_scalars, size_t len, int scalars_montgomery,
+                             void* d_out_affine);
+
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
 

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import oracle as O
+    O.load()
+    return O
+
+
+@pytest.fixture(scope="session")
+def zk():
+    """The product library through its C ABI; initialised on device 0.  Fails loudly without a GPU."""
+    from zecale_amd import zkhip
+    zkhip.init(0)
+    return zkhip

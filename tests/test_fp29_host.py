@@ -1,0 +1,56 @@
+"""The product's device field arithmetic (zecale_amd/csrc/fp29.cuh) compiled for the HOST by g++
+and checked against big integers / golden vectors.  CPU only (no compute through libzkhip)."""
+import ctypes
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyref as R
+from tests.helpers import golden, h2i
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(HERE, "libfp29_host_shim.so")
+    src = os.path.join(HERE, "fp29_host_shim.cpp")
+    hdr = os.path.join(HERE, "..", "zecale_amd", "csrc", "fp29.cuh")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    return ctypes.CDLL(so)
+
+
+def _arr(x, n):
+    return (ctypes.c_uint64 * n)(*R.int_to_limbs(x, n))
+
+
+@pytest.mark.parametrize("name,p,n", [("fq", R.Q_MOD, 12), ("fr", R.R_MOD, 6)])
+def test_fp29_against_golden_and_random(shim, name, p, n):
+    Rm = 1 << (64 * n)
+    tm = lambda x: x * Rm % p
+    fm = lambda X: X * pow(Rm, -1, p) % p
+    out = (ctypes.c_uint64 * n)()
+    rng = random.Random(11)
+    vecs = [(h2i(v["a"]), h2i(v["b"])) for v in golden("field_vectors.json")[name]]
+    vecs += [(rng.randrange(p), rng.randrange(p)) for _ in range(200)]
+    for a, b in vecs:
+        getattr(shim, name + "_mul")(_arr(tm(a), n), _arr(tm(b), n), out)
+        assert fm(R.limbs_to_int(out)) == a * b % p
+        getattr(shim, name + "_sqr")(_arr(tm(a), n), out)
+        assert fm(R.limbs_to_int(out)) == a * a % p
+        getattr(shim, name + "_add")(_arr(tm(a), n), _arr(tm(b), n), out)
+        assert fm(R.limbs_to_int(out)) == (a + b) % p
+        getattr(shim, name + "_sub")(_arr(tm(a), n), _arr(tm(b), n), out)
+        assert fm(R.limbs_to_int(out)) == (a - b) % p
+        getattr(shim, name + "_roundtrip")(_arr(tm(a), n), out)
+        assert R.limbs_to_int(out) == tm(a)
+        getattr(shim, name + "_lazy_chain")(_arr(tm(a), n), _arr(tm(b), n), out)
+        s = 2 * (a + b); d = s - 4 * b; m = s * d; t = m - d
+        assert fm(R.limbs_to_int(out)) == t * t % p
+        w = (ctypes.c_uint32 * (2 * n))()
+        getattr(shim, name + "_canon_words")(_arr(tm(a), n), w)
+        assert sum(int(w[i]) << (32 * i) for i in range(2 * n)) == a

@@ -1,0 +1,121 @@
+"""Parity of the HIP MSM (through the C ABI, include/zkhip.h) with the CPU oracle.  Bit-exact:
+results are compared as affine-normalised Montgomery limbs.  Cases follow what the reference's
+path sees: random, all-zero, all-one, single term, duplicate points, P + (-P),
+maximal scalar r - 1, infinity bases, boolean-heavy witness-like scalars; G1 and G2."""
+import numpy as np
+import pytest
+
+from oracle import pyref as R
+from tests.helpers import aff_limbs, aff_point, fr_array, golden, h2i, pt_from_json, random_fr_canonical
+
+pytestmark = pytest.mark.gpu
+
+
+def _msm_aff(zk, bases, scal, montgomery=True, window=0):
+    zk.set_msm_window(window)
+    return zk.jac_to_affine(zk.msm_raw(bases, scal, montgomery=montgomery))
+
+
+@pytest.mark.parametrize("window", [0, 5, 9])
+def test_golden_vectors(zk, window):
+    for case in golden("msm_vectors.json"):
+        bases = np.array([aff_limbs(pt_from_json(p)) for p in case["bases"]])
+        scal = fr_array([h2i(s) for s in case["scalars"]])
+        got = aff_point(_msm_aff(zk, bases, scal, window=window))
+        assert got == pt_from_json(case["result"]), case["name"]
+
+
+def test_empty(zk):
+    b = zk.Bases.upload(np.zeros((4, 24), dtype=np.uint64))
+    out = b.msm(np.zeros((0, 6), dtype=np.uint64))
+    assert (zk.jac_to_affine(out) == 0).all()
+    b.free()
+
+
+def test_fixed_base_mul_matches_oracle(zk, oracle_lib):
+    O = oracle_lib
+    for G in (R.G1_GEN, R.G2_GEN):
+        g = aff_limbs(G)
+        ks = random_fr_canonical(7, 64)
+        ks[0] = 0
+        ks[1, :] = 0; ks[1, 0] = 1
+        pts = zk.fixed_base_mul(g, ks, montgomery=True)
+        for i in range(64):
+            assert (pts[i] == O.jac_to_affine(O.scalar_mul(g, ks[i]))).all(), i
+
+
+@pytest.mark.parametrize("n,window", [(1 << 10, 0), (5000, 11), (1 << 14, 0), (1 << 14, 13)])
+def test_random_vs_oracle_g1(zk, oracle_lib, n, window):
+    O = oracle_lib
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(100 + n, n), montgomery=False)
+    scal = random_fr_canonical(200 + n, n)
+    assert (_msm_aff(zk, bases, scal, window=window) == O.jac_to_affine(O.msm(bases, scal))).all()
+
+
+def test_random_vs_oracle_g2(zk, oracle_lib):
+    O = oracle_lib
+    n = 3000
+    bases = zk.fixed_base_mul(aff_limbs(R.G2_GEN), random_fr_canonical(31, n), montgomery=False)
+    assert O.on_curve(bases[5], g2=True)
+    scal = random_fr_canonical(32, n)
+    assert (_msm_aff(zk, bases, scal) == O.jac_to_affine(O.msm(bases, scal))).all()
+
+
+def test_witness_like_scalars(zk, oracle_lib):
+    """70 % of the scalars in {0, 1} (boolean-heavy R1CS witness), Montgomery form."""
+    O = oracle_lib
+    n = 1 << 13
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(41, n), montgomery=False)
+    rng = np.random.default_rng(5)
+    sel = rng.random(n)
+    vals = [0 if s < 0.35 else 1 if s < 0.7 else int(x) for s, x in zip(sel, rng.integers(2, 1 << 62, n))]
+    scal = fr_array(vals)
+    big = random_fr_canonical(42, n)
+    scal[sel > 0.85] = big[sel > 0.85]       # some full-size ones (treated as Montgomery residues)
+    assert (_msm_aff(zk, bases, scal) == O.jac_to_affine(O.msm(bases, scal))).all()
+
+
+def test_resident_bases_offset_and_reuse(zk, oracle_lib):
+    O = oracle_lib
+    n = 2048
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(51, n), montgomery=False)
+    b = zk.Bases.upload(bases)
+    assert len(b) == n
+    for off, ln in ((0, n), (100, 1000), (2047, 1)):
+        scal = random_fr_canonical(52 + off, ln)
+        got = zk.jac_to_affine(b.msm(scal, offset=off))
+        assert (got == O.jac_to_affine(O.msm(bases[off:off + ln], scal))).all()
+    with pytest.raises(zk.ZkhipError):
+        b.msm(random_fr_canonical(1, 10), offset=n - 5)
+    b.free()
+
+
+def test_full_size_2_20_closed_form(zk, oracle_lib):
+    """BASELINE config 2 size.  Bases k_i*G (k_i known) => sum s_i (k_i G) = (sum s_i k_i mod r) G:
+    a size-independent check of the 2^20 MSM against ONE oracle scalar multiplication; plus
+    linearity MSM(s) + MSM(t) = MSM(s + t) on the same bases."""
+    O = oracle_lib
+    n = 1 << 20
+    g = aff_limbs(R.G1_GEN)
+    ks = random_fr_canonical(61, n)
+    bases = zk.fixed_base_mul(g, ks, montgomery=False)
+    # spot-check the generator itself against the oracle
+    for i in (0, 12345, n - 1):
+        k_m = np.array(R.int_to_limbs(R.to_mont(R.limbs_to_int(ks[i]), R.R_MOD, 6), 6), dtype=np.uint64)
+        assert (bases[i] == O.jac_to_affine(O.scalar_mul(g, k_m))).all()
+    b = zk.Bases.upload(bases)
+    s = random_fr_canonical(62, n)
+    t = random_fr_canonical(63, n)
+    to_int = lambda a: [int(x[0]) | int(x[1]) << 64 | int(x[2]) << 128 | int(x[3]) << 192 | int(x[4]) << 256 | int(x[5]) << 320
+                        for x in a.tolist()]
+    ki, si, ti = to_int(ks), to_int(s), to_int(t)
+    zk.set_msm_window(0)
+    ms = b.msm(s, montgomery=False)
+    mt = b.msm(t, montgomery=False)
+    dot = sum(a * k for a, k in zip(si, ki)) % R.R_MOD
+    exp = O.jac_to_affine(O.scalar_mul(g, np.array(R.int_to_limbs(R.to_mont(dot, R.R_MOD, 6), 6), dtype=np.uint64)))
+    assert (zk.jac_to_affine(ms) == exp).all()
+    st = np.array([R.int_to_limbs((a + c) % R.R_MOD, 6) for a, c in zip(si, ti)], dtype=np.uint64)
+    mst = b.msm(st, montgomery=False)
+    assert (zk.jac_to_affine(zk.jac_add(ms, mt)) == zk.jac_to_affine(mst)).all()
+    b.free()

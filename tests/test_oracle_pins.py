@@ -1,0 +1,167 @@
+"""Pins the test oracle.
+ 1. oracle/pyref.py (big-int) against the reference's own known-answer fixtures
+    (tests/golden/dummy_app/* = reference testdata/dummy_app/*; expectations:
+    client/test_commands/test_bw6_761_groth16_contract.py:66-79, dummy_application_test.cpp:32-44).
+ 2. oracle/bw6_oracle.c against the golden vectors generated from pyref (tests/golden/gen_golden.py).
+CPU only."""
+import numpy as np
+import pytest
+
+from oracle import pyref as R
+from tests.helpers import (aff_limbs, aff_point, fq_int, fq_limbs, fr_array, fr_int, fr_ints, fr_limbs, golden, h2i,
+                           pt_from_json)
+
+
+# ---------------------------------------------------------------- 1. pyref vs reference fixtures
+def _load_bw6_vk():
+    j = golden("dummy_app/aggregator_vk.json")
+    return dict(alpha=pt_from_json(j["alpha"]), beta=pt_from_json(j["beta"]), delta=pt_from_json(j["delta"]),
+                ABC=[pt_from_json(p) for p in j["ABC"]])
+
+
+def _load_bw6_proof(name):
+    j = golden("dummy_app/" + name)["ext_proof"]
+    return {k: pt_from_json(v) for k, v in j["proof"].items()}, [h2i(x) for x in j["inputs"]]
+
+
+def test_reference_constants():
+    # generators on their curves, of order r; -G2 equals the contract constant's relation (q - y)
+    assert R.on_curve(R.G1_GEN, R.G1_B) and R.on_curve(R.G2_GEN, R.G2_B)
+    assert R.ec_mul(R.R_MOD, R.G1_GEN) is None and R.ec_mul(R.R_MOD, R.G2_GEN) is None
+    assert pow(R.FR_GENERATOR, (R.R_MOD - 1) // 2, R.R_MOD) == R.R_MOD - 1   # non-residue
+    w = R.fr_root_of_unity(R.FR_TWO_ADICITY)
+    assert pow(w, 1 << (R.FR_TWO_ADICITY - 1), R.R_MOD) == R.R_MOD - 1      # primitive 2^46-th root
+    assert (R.R_MOD - 1) % (1 << 46) == 0 and ((R.R_MOD - 1) >> 46) % 2 == 1
+
+
+def test_reference_fixture_points_on_curve():
+    vk = _load_bw6_vk()
+    assert R.on_curve(vk["alpha"], R.G1_B) and R.on_curve(vk["beta"], R.G2_B) and R.on_curve(vk["delta"], R.G2_B)
+    assert all(R.on_curve(p, R.G1_B) for p in vk["ABC"])
+    assert len(vk["ABC"]) == 6   # older 5-input layout
+    pr, _ = _load_bw6_proof("batch1.json")
+    assert R.on_curve(pr["a"], R.G1_B) and R.on_curve(pr["b"], R.G2_B) and R.on_curve(pr["c"], R.G1_B)
+    assert R.ec_mul(R.R_MOD, pr["a"]) is None and R.ec_mul(R.R_MOD, pr["b"]) is None
+
+
+def test_reference_bw6_groth16_kat_valid():
+    pr, inputs = _load_bw6_proof("batch1.json")
+    assert R.bw6_groth16_verify(_load_bw6_vk(), pr, inputs)
+
+
+def test_reference_bw6_groth16_kat_invalid():
+    pr, inputs = _load_bw6_proof("batch1-invalid.json")
+    assert not R.bw6_groth16_verify(_load_bw6_vk(), pr, inputs)
+
+
+def test_reference_nested_bls12_377_fixtures():
+    """extproof1..6 under vk.json (BLS12-377, coordinates in Fr(BW6)): curve membership, subgroup
+    order, and the gamma-free consequence of the Groth16 equation: with
+    T_i = e(A_i,B_i) e(alpha,-beta) e(C_i,-delta) = e(ABC0 + x_i ABC1, gamma) and inputs 7, 8, 9:
+    T_7 * T_9 = T_8^2."""
+    vk = golden("dummy_app/vk.json")
+    alpha = pt_from_json(vk["alpha"])
+    g2 = lambda p: ((h2i(p[0][1]), h2i(p[0][0])), (h2i(p[1][1]), h2i(p[1][0])))   # JSON order is [c1, c0]
+    beta, delta = g2(vk["beta"]), g2(vk["delta"])
+    assert R.on_curve(alpha, 1, R.BLS_Q) and R.bls_g2_on_curve(beta) and R.bls_g2_on_curve(delta)
+    assert all(R.on_curve(pt_from_json(p), 1, R.BLS_Q) for p in vk["ABC"])
+    proofs = []
+    for i in range(1, 7):
+        j = golden(f"dummy_app/extproof{i}.json")["extended_proof"]
+        a, b, c = pt_from_json(j["proof"]["a"]), g2(j["proof"]["b"]), pt_from_json(j["proof"]["c"])
+        assert R.on_curve(a, 1, R.BLS_Q) and R.on_curve(c, 1, R.BLS_Q) and R.bls_g2_on_curve(b)
+        assert R.ec_mul(R.BLS_R, a, R.BLS_Q) is None
+        assert [h2i(x) for x in j["inputs"]] == [6 + i]
+        proofs.append((a, b, c))
+    nb, nd = R.bls_g2_neg(beta), R.bls_g2_neg(delta)
+    (a7, b7, c7), (a8, b8, c8), (a9, b9, c9) = proofs[0], proofs[1], proofs[2]
+    neg = lambda P: R.ec_neg(P, R.BLS_Q)
+    # T7 * T9 / T8^2 == 1 ; e(alpha,-beta) cancels (1 + 1 - 2)
+    pairs = [(a7, b7), (c7, nd), (a9, b9), (c9, nd), (neg(a8), b8), (neg(a8), b8), (c8, delta), (c8, delta)]
+    assert R.bls12_377_pairing_product_is_one(pairs)
+    # and a corrupted variant fails
+    pairs[0] = (a9, b7)
+    assert not R.bls12_377_pairing_product_is_one(pairs)
+
+
+# ---------------------------------------------------------------- 2. C oracle vs golden vectors
+def test_c_oracle_fields(oracle_lib):
+    O = oracle_lib
+    for which, name, lim, back in ((0, "fq", fq_limbs, fq_int), (1, "fr", fr_limbs, fr_int)):
+        for v in golden("field_vectors.json")[name]:
+            a, b = h2i(v["a"]), h2i(v["b"])
+            assert back(O.f_op("mul", which, lim(a), lim(b))) == h2i(v["mul"])
+            assert back(O.f_op("add", which, lim(a), lim(b))) == h2i(v["add"])
+            assert back(O.f_op("sub", which, lim(a), lim(b))) == h2i(v["sub"])
+            if v["inv_a"]:
+                assert back(O.f_op("inv", which, lim(a))) == h2i(v["inv_a"])
+
+
+def test_c_oracle_curve(oracle_lib):
+    O = oracle_lib
+    cv = golden("curve_vectors.json")
+    for name, g2 in (("g1", False), ("g2", True)):
+        G = aff_limbs(pt_from_json(cv[name]["gen"]))
+        assert O.on_curve(G, g2)
+        for m in cv[name]["muls"]:
+            got = aff_point(O.jac_to_affine(O.scalar_mul(G, fr_limbs(h2i(m["k"])))))
+            assert got == pt_from_json(m["P"])
+        ad = cv[name]["add"]
+        P, Q = aff_limbs(pt_from_json(ad["P"])), aff_limbs(pt_from_json(ad["Q"]))
+        assert aff_point(O.jac_to_affine(O.jac_add(O.aff_to_jac(P), O.aff_to_jac(Q)))) == pt_from_json(ad["sum"])
+        assert aff_point(O.jac_to_affine(O.jac_add(O.aff_to_jac(P), O.aff_to_jac(P)))) == pt_from_json(ad["dblP"])
+        assert aff_point(O.jac_to_affine(O.jac_dbl(O.aff_to_jac(P)))) == pt_from_json(ad["dblP"])
+
+
+@pytest.mark.parametrize("chunks,mixed", [(1, True), (3, True), (4, False)])
+def test_c_oracle_msm(oracle_lib, chunks, mixed):
+    O = oracle_lib
+    for case in golden("msm_vectors.json"):
+        bases = np.array([aff_limbs(pt_from_json(p)) for p in case["bases"]])
+        scal = fr_array([h2i(s) for s in case["scalars"]])
+        got = aff_point(O.jac_to_affine(O.msm(bases, scal, chunks, mixed)))
+        assert got == pt_from_json(case["result"]), case["name"]
+
+
+def test_c_oracle_ntt(oracle_lib):
+    O = oracle_lib
+    for v in golden("ntt_vectors.json"):
+        a = fr_array([h2i(x) for x in v["input"]])
+        ld = v["log_d"]
+        assert fr_ints(O.ntt(a, ld)) == [h2i(x) for x in v["fft"]]
+        assert fr_ints(O.ntt(a, ld, inverse=True)) == [h2i(x) for x in v["ifft"]]
+        assert fr_ints(O.ntt(a, ld, coset=True)) == [h2i(x) for x in v["coset_fft"]]
+        assert fr_ints(O.ntt(a, ld, inverse=True, coset=True)) == [h2i(x) for x in v["icoset_fft"]]
+
+
+def csr_from_rows(rows):
+    rp, col, val = [0], [], []
+    for row in rows:
+        for i, c in row:
+            col.append(i)
+            val.append(h2i(c) if isinstance(c, str) else c)
+        rp.append(len(col))
+    return (np.array(rp, dtype=np.uint32), np.array(col, dtype=np.uint32), fr_array(val))
+
+
+def load_groth16_small():
+    g = golden("groth16_small.json")
+    pts = lambda L: np.array([aff_limbs(pt_from_json(p)) for p in L]).reshape(-1, 24)
+    pk = {k: (aff_limbs(pt_from_json(v)) if k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2") else pts(v))
+          for k, v in g["pk"].items()}
+    return g, pk
+
+
+def test_c_oracle_qap_and_groth16(oracle_lib):
+    O = oracle_lib
+    g, pk = load_groth16_small()
+    A, B, C = (csr_from_rows(g[k]) for k in "ABC")
+    z = fr_array([h2i(x) for x in g["z"]])
+    n = len(g["A"])
+    assert O.qap_log_d(n, g["n_primary"]) == g["log_d"]
+    h = O.qap_h(A, B, C, z, n, g["n_primary"])
+    assert fr_ints(h) == [h2i(x) for x in g["h"]]
+    proof = O.groth16_prove(pk, z, g["n_primary"], h, fr_limbs(h2i(g["r"])), fr_limbs(h2i(g["s"])), chunks=2)
+    assert aff_point(proof[:24]) == pt_from_json(g["proof"]["a"])
+    assert aff_point(proof[24:48]) == pt_from_json(g["proof"]["b"])
+    assert aff_point(proof[48:]) == pt_from_json(g["proof"]["c"])

@@ -29,4 +29,7 @@ int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPac
 int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, size_t n, int scalars_montgomery,
             uint64_t out_jac[36]);
 
+int fixed_base_mul(const uint64_t base_aff[24], const uint64_t* d_scalars, size_t n, int montgomery, uint64_t* d_out,
+                   char* errbuf, size_t errlen);
+
 }  // namespace zkhip

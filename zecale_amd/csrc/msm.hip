@@ -230,6 +230,61 @@ __global__ void __launch_bounds__(64, 2) k_window_combine(const uint32_t* __rest
   fp_to_abi<FqParams>(acc.ZZZ, o + 36);
 }
 
+// ---- batch fixed-base scalar multiplication: out[i] = k_i * G (the inner loop of Groth16 setup:
+// reference libzecale/circuits/aggregator_circuit.tcc:100-109 -> wsnarkT::generate_setup) ----
+// table[w*15 + (d-1)] = d * 2^(4w) * G, w < 95, d = 1..15 (packed device form).
+__device__ const uint32_t FQ_P_LIMBS_DEV[27] = {
+    FqParams::P[0], FqParams::P[1], FqParams::P[2], FqParams::P[3], FqParams::P[4], FqParams::P[5], FqParams::P[6],
+    FqParams::P[7], FqParams::P[8], FqParams::P[9], FqParams::P[10], FqParams::P[11], FqParams::P[12], FqParams::P[13],
+    FqParams::P[14], FqParams::P[15], FqParams::P[16], FqParams::P[17], FqParams::P[18], FqParams::P[19], FqParams::P[20],
+    FqParams::P[21], FqParams::P[22], FqParams::P[23], FqParams::P[24], FqParams::P[25], FqParams::P[26]};
+
+__device__ __forceinline__ Fq fq_inv_fermat(const Fq& a) {
+  // a^(p-2); exponent bits taken from the modulus limbs
+  Fq acc = fp_one<FqParams>();
+  for (int i = FqParams::NBITS - 1; i >= 0; i--) {
+    acc = fp_sqr(acc);
+    // bit i of p - 2 (p odd, p0 = ...8b so p - 2 only changes limb 0: 0x8b - 2 = 0x89)
+    uint32_t limb = FQ_P_LIMBS_DEV[i / 29];
+    if (i / 29 == 0) limb -= 2;
+    if ((limb >> (i % 29)) & 1) acc = fp_mul(acc, a);
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(256, 2) k_fixed_base_mul(const AffPacked* __restrict__ table, const uint64_t* __restrict__ scalars,
+                                                            size_t n, int montgomery, uint64_t* __restrict__ out_abi /* n x 24 */) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t s[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) s[k] = scalars[i * 6 + k];
+  uint32_t w32[12];
+  if (montgomery) {
+    fp_abi_to_canonical_words<FrParams>(s, w32);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) { w32[2 * k] = (uint32_t)s[k]; w32[2 * k + 1] = (uint32_t)(s[k] >> 32); }
+  }
+  XYZZ acc = xyzz_infinity();
+  for (int w = 0; w < 95; w++) {
+    uint32_t d = (w32[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (d == 0) continue;
+    AffineDev p = aff_load(&table[w * 15 + (d - 1)]);
+    xyzz_madd(acc, p.x, p.y);
+  }
+  uint64_t* o = out_abi + i * 24;
+  if (xyzz_is_inf(acc)) {
+#pragma unroll
+    for (int k = 0; k < 24; k++) o[k] = 0;
+    return;
+  }
+  Fq zi = fq_inv_fermat(fp_mul(acc.ZZ, acc.ZZZ));     // 1 / (ZZ * ZZZ)
+  Fq izz = fp_mul(zi, acc.ZZZ), izzz = fp_mul(zi, acc.ZZ);
+  fp_to_abi<FqParams>(fp_mul(acc.X, izz), o);
+  fp_to_abi<FqParams>(fp_mul(acc.Y, izzz), o + 12);
+}
+
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
@@ -383,6 +438,45 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, si
   }
   acc.X.to_limbs(out_jac); acc.Y.to_limbs(out_jac + 12); acc.Z.to_limbs(out_jac + 24);
   return ZKHIP_OK;
+}
+
+// out[i] = k_i * base for i < n.  base: ABI affine (host); d_scalars, d_out: device memory.
+int fixed_base_mul(const uint64_t base_aff[24], const uint64_t* d_scalars, size_t n, int montgomery, uint64_t* d_out,
+                   char* errbuf, size_t errlen) {
+  using namespace host;
+  struct { char errbuf[256]; } c_, *ctx = &c_;
+  ctx->errbuf[0] = 0;
+  // table on the host: 95 windows x 15 multiples, affine, ABI form -> device packed form
+  std::vector<uint64_t> tab((size_t)95 * 15 * 24);
+  HJac wbase = HJac::from_affine(HFq::from_limbs(base_aff), HFq::from_limbs(base_aff + 12));
+  for (int w = 0; w < 95; w++) {
+    HJac m = wbase;
+    for (int d = 1; d <= 15; d++) {
+      HFq x, y;
+      m.to_affine(x, y);
+      x.to_limbs(&tab[((size_t)w * 15 + d - 1) * 24]);
+      y.to_limbs(&tab[((size_t)w * 15 + d - 1) * 24 + 12]);
+      m = m.add(wbase);
+    }
+    for (int k = 0; k < 4; k++) wbase = wbase.dbl();
+  }
+  uint64_t* d_tab_abi = nullptr;
+  AffPacked* d_tab = nullptr;
+  int rc = ZKHIP_OK;
+  do {
+    hipError_t e;
+    if ((e = hipMalloc(&d_tab_abi, tab.size() * 8)) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
+    if ((e = hipMalloc(&d_tab, (size_t)95 * 15 * sizeof(AffPacked))) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
+    if ((e = hipMemcpy(d_tab_abi, tab.data(), tab.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
+    hipLaunchKernelGGL(k_bases_to_dev, dim3(nblk(95 * 15, 256)), dim3(256), 0, 0, d_tab_abi, d_tab, (size_t)95 * 15);
+    hipLaunchKernelGGL(k_fixed_base_mul, dim3(nblk(n, 256)), dim3(256), 0, 0, d_tab, d_scalars, n, montgomery, d_out);
+    if ((e = hipGetLastError()) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
+    if ((e = hipDeviceSynchronize()) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
+  } while (0);
+  if (rc != ZKHIP_OK && errbuf) snprintf(errbuf, errlen, "fixed_base_mul: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
+  if (d_tab_abi) (void)hipFree(d_tab_abi);
+  if (d_tab) (void)hipFree(d_tab);
+  return rc;
 }
 
 }  // namespace zkhip

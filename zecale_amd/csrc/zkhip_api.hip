@@ -177,6 +177,30 @@ int zkhip_msm_raw(const uint64_t* bases_affine, const uint64_t* scalars, size_t 
   return rc;
 }
 
+int zkhip_fixed_base_mul_dev(const uint64_t base_affine[24], const void* d_scalars, size_t len, int scalars_montgomery,
+                             void* d_out_affine) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!base_affine || (len && (!d_scalars || !d_out_affine))) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (len == 0) return ZKHIP_OK;
+  return fixed_base_mul(base_affine, (const uint64_t*)d_scalars, len, scalars_montgomery, (uint64_t*)d_out_affine, g.err, sizeof g.err);
+}
+
+int zkhip_fixed_base_mul(const uint64_t base_affine[24], const uint64_t* scalars, size_t len, int scalars_montgomery,
+                         uint64_t* out_affine) {
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (len && (!scalars || !out_affine)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (len == 0) return ZKHIP_OK;
+  void *ds = nullptr, *dp = nullptr;
+  API_HIP(hipMalloc(&ds, len * 48));
+  API_HIP(hipMalloc(&dp, len * 192));
+  API_HIP(hipMemcpy(ds, scalars, len * 48, hipMemcpyHostToDevice));
+  int rc = zkhip_fixed_base_mul_dev(base_affine, ds, len, scalars_montgomery, dp);
+  if (rc == ZKHIP_OK) API_HIP(hipMemcpy(out_affine, dp, len * 192, hipMemcpyDeviceToHost));
+  (void)hipFree(ds); (void)hipFree(dp);
+  return rc;
+}
+
 float zkhip_last_accumulate_ms(void) { return g.msm_ready ? g.msm.last_accumulate_ms : 0.f; }
 
 int zkhip_jac_to_affine(const uint64_t jac[36], uint64_t aff[24]) {

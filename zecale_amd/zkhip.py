@@ -14,6 +14,7 @@ EXPORTS = [
     "zkhip_init", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window",
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_last_accumulate_ms",
+    "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev",
     "zkhip_jac_to_affine", "zkhip_jac_add",
 ]
 
@@ -47,6 +48,8 @@ def load():
     lib.zkhip_msm.argtypes = [ctypes.c_void_p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
     lib.zkhip_msm_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, c_u64p]
     lib.zkhip_msm_raw.argtypes = [c_u64p, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
+    lib.zkhip_fixed_base_mul.argtypes = [c_u64p, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
+    lib.zkhip_fixed_base_mul_dev.argtypes = [c_u64p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     lib.zkhip_last_accumulate_ms.restype = ctypes.c_float
     lib.zkhip_jac_to_affine.argtypes = [c_u64p, c_u64p]
     lib.zkhip_jac_add.argtypes = [c_u64p, c_u64p, c_u64p]
@@ -118,6 +121,20 @@ def msm_raw(bases_affine, scalars, montgomery=True):
     out = np.zeros(36, dtype=np.uint64)
     _check(load().zkhip_msm_raw(_p(a), _p(s), a.shape[0], int(montgomery), _p(out)))
     return out
+
+
+def fixed_base_mul(base_affine, scalars, montgomery=True):
+    """out[i] = scalars[i] * base (affine, n x 24 limbs) - the batch exponentiation of Groth16 setup."""
+    b = np.ascontiguousarray(base_affine, dtype=np.uint64).reshape(24)
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 6)
+    out = np.zeros((s.shape[0], 24), dtype=np.uint64)
+    _check(load().zkhip_fixed_base_mul(_p(b), _p(s), s.shape[0], int(montgomery), _p(out)))
+    return out
+
+
+def fixed_base_mul_dev(base_affine, d_scalars_ptr, n, d_out_ptr, montgomery=True):
+    b = np.ascontiguousarray(base_affine, dtype=np.uint64).reshape(24)
+    _check(load().zkhip_fixed_base_mul_dev(_p(b), ctypes.c_void_p(d_scalars_ptr), n, int(montgomery), ctypes.c_void_p(d_out_ptr)))
 
 
 def jac_to_affine(jac):
