@@ -1,0 +1,226 @@
+// Point additions on MEMORY-resident XYZZ accumulators, written as small "micro-programs":
+// one rolled loop over the 10 (mixed add) / 14 (full add) field multiplications of the formula,
+// with a switch that selects the operands and files the result.  Why:
+//   * A fully unrolled 761-bit Montgomery multiplication is ~12 KB of straight-line code.  Ten of
+//     them inlined into one loop body (120 KB) overflow the CU's instruction cache and the kernel
+//     becomes instruction-fetch bound (measured: 10x slower than the arithmetic allows).  Calling
+//     an out-of-line multiply passes its 2 x 27 limbs through scratch memory (2x slower).  The
+//     rolled micro-program keeps exactly ONE copy of the multiplier in the loop: ~20 KB per kernel.
+//   * Only four temporaries (4 x 27 VGPRs) plus the multiplier's own operands are live, so the
+//     kernel fits 256 VGPRs and runs two waves per SIMD; the accumulator itself stays in memory in
+//     limb-major layout (word (k, idx) at base[k*stride + idx]): lane t <-> accumulator t, every
+//     access is a coalesced 256-byte row per wave, served from L2.
+// Formulas: madd-2008-s / add-2008-s (see ec.cuh for the register-resident versions and bounds).
+#pragma once
+#include "ec.cuh"
+
+namespace zkhip {
+
+// Addressing: buffer instructions with a wave-uniform descriptor (SGPRs), the row offset
+// (k * stride) in the scalar offset and only the 32-bit lane offset in a VGPR - with flat 64-bit
+// addresses hipcc hoists 108 address pairs per accumulator out of the loop and spills them.
+typedef __amdgpu_buffer_rsrc_t zk_rsrc_t;
+struct XyzzRef {
+  zk_rsrc_t rs;        // wave-uniform: base pointer, 108 * stride words
+  uint32_t stride_b;   // wave-uniform: row stride in bytes
+  uint32_t voff;       // per lane: 4 * index
+};
+// base / stride must be wave-uniform (kernel arguments); 108 * stride * 4 must stay below 4 GiB.
+__device__ __forceinline__ XyzzRef make_ref(uint32_t* base, uint32_t stride, uint32_t idx) {
+  XyzzRef r;
+  r.rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(108u * stride * 4u), 0x00020000);
+  r.stride_b = stride * 4u;
+  r.voff = idx * 4u;
+  return r;
+}
+enum { CX = 0, CY = 1, CZZ = 2, CZZZ = 3 };
+
+__device__ __forceinline__ Fq mem_ld(const XyzzRef& r, int c) {
+  Fq v;
+#pragma unroll
+  for (int i = 0; i < 27; i++)
+    v.l[i] = __builtin_amdgcn_raw_buffer_load_b32(r.rs, r.voff, (uint32_t)(c * 27 + i) * r.stride_b, 0);
+  return v;
+}
+__device__ __forceinline__ void mem_st(const XyzzRef& r, int c, const Fq& v) {
+#pragma unroll
+  for (int i = 0; i < 27; i++)
+    __builtin_amdgcn_raw_buffer_store_b32(v.l[i], r.rs, r.voff, (uint32_t)(c * 27 + i) * r.stride_b, 0);
+}
+__device__ __forceinline__ void mem_set_inf(const XyzzRef& r) {
+  Fq z = fp_zero<FqParams>();
+  mem_st(r, CX, z); mem_st(r, CY, z); mem_st(r, CZZ, z); mem_st(r, CZZZ, z);
+}
+__device__ __forceinline__ bool mem_is_inf(const XyzzRef& r) { return fp_is_zero_2p(mem_ld(r, CZZ)); }
+__device__ __forceinline__ void mem_copy(const XyzzRef& dst, const XyzzRef& src) {
+#pragma unroll
+  for (int c = 0; c < 4; c++) mem_st(dst, c, mem_ld(src, c));
+}
+
+// packed affine point (device form) coordinate loads; neg: return p - y (as a [2] value)
+__device__ __forceinline__ Fq aff_ld_x(const AffPacked* p) {
+  uint32_t w[24];
+#pragma unroll
+  for (int i = 0; i < 24; i++) w[i] = p->x[i];
+  return fp_unpack32<FqParams>(w);
+}
+__device__ __forceinline__ Fq aff_ld_y(const AffPacked* p, bool neg) {
+  uint32_t w[24];
+#pragma unroll
+  for (int i = 0; i < 24; i++) w[i] = p->y[i];
+  Fq y = fp_unpack32<FqParams>(w);
+  if (neg) y = fp_sub<FqParams, 2>(fp_zero<FqParams>(), y);
+  return y;
+}
+__device__ __forceinline__ bool aff_is_inf(const AffPacked* p) {
+  uint32_t nz = 0;
+#pragma unroll
+  for (int i = 0; i < 24; i++) nz |= p->x[i] | p->y[i];
+  return nz == 0;
+}
+
+// rare paths (same x coordinate), out of line: their cost does not matter, their code size does
+__device__ __noinline__ void madd_same_x(XyzzRef acc, const AffPacked* p, bool neg) {
+  Fq x2 = aff_ld_x(p), y2 = aff_ld_y(p, neg);
+  Fq S2 = fp_mul(y2, mem_ld(acc, CZZZ));
+  Fq R = fp_sub<FqParams, 4>(S2, mem_ld(acc, CY));
+  if (fp_is_zero_2p(fp_sqr(R))) {
+    XYZZ d = xyzz_dbl_affine(x2, y2);
+    mem_st(acc, CX, d.X); mem_st(acc, CY, d.Y); mem_st(acc, CZZ, d.ZZ); mem_st(acc, CZZZ, d.ZZZ);
+  } else {
+    mem_set_inf(acc);
+  }
+}
+__device__ __noinline__ void add_same_x(XyzzRef a, XyzzRef b) {
+  Fq S1 = fp_mul(mem_ld(a, CY), mem_ld(b, CZZZ));
+  Fq S2 = fp_mul(mem_ld(b, CY), mem_ld(a, CZZZ));
+  Fq R = fp_sub<FqParams, 2>(S2, S1);
+  if (fp_is_zero_2p(fp_sqr(R))) {
+    XYZZ p;
+    p.X = mem_ld(a, CX); p.Y = mem_ld(a, CY); p.ZZ = mem_ld(a, CZZ); p.ZZZ = mem_ld(a, CZZZ);
+    XYZZ d = xyzz_dbl(p);
+    mem_st(a, CX, d.X); mem_st(a, CY, d.Y); mem_st(a, CZZ, d.ZZ); mem_st(a, CZZZ, d.ZZZ);
+  } else {
+    mem_set_inf(a);
+  }
+}
+
+// acc (memory, finite) += p (packed affine, finite; y negated when neg).
+__device__ __forceinline__ bool madd_mem(const XyzzRef& acc, const AffPacked* p, bool neg) {
+  Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
+  bool same_x = false;
+#pragma unroll 1
+  for (int step = 0; step < 10; step++) {
+    Fq a, b;
+    switch (step) {
+      case 0: a = aff_ld_x(p); b = mem_ld(acc, CZZ); break;          // U2 = x2 ZZ1
+      case 1: a = aff_ld_y(p, neg); b = mem_ld(acc, CZZZ); break;    // S2 = y2 ZZZ1
+      case 2: a = T0; b = T0; break;                                 // PP = P^2
+      case 3: a = T0; b = T2; break;                                 // PPP = P PP
+      case 4: a = mem_ld(acc, CZZ); b = T2; break;                   // ZZ3 = ZZ1 PP
+      case 5: a = mem_ld(acc, CZZZ); b = T3; break;                  // ZZZ3 = ZZZ1 PPP
+      case 6: a = mem_ld(acc, CX); b = T2; break;                    // Q = X1 PP
+      case 7: a = T1; b = T1; break;                                 // RR = R^2
+      case 8: a = T1; b = fp_sub<FqParams, 16>(T0, T2); break;       // Y3a = R (Q - X3)
+      default: a = mem_ld(acc, CY); b = T3; break;                   // Y3b = Y1 PPP
+    }
+    Fq r = fp_mul(a, b);
+    switch (step) {
+      case 0: T0 = fp_sub<FqParams, 16>(r, mem_ld(acc, CX)); break;  // P  [18]
+      case 1: T1 = fp_sub<FqParams, 4>(r, mem_ld(acc, CY)); break;   // R  [6]
+      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
+      case 3: T3 = r; break;                                         // PPP
+      case 4: mem_st(acc, CZZ, r); break;
+      case 5: mem_st(acc, CZZZ, r); break;
+      case 6: T0 = r; break;                                         // Q
+      case 7: T2 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T3), fp_dbl(T0)); mem_st(acc, CX, T2); break;   // X3 [10]
+      case 8: T0 = r; break;                                         // Y3a
+      default: mem_st(acc, CY, fp_sub<FqParams, 2>(T0, r)); break;   // Y3 [4]
+    }
+    if (same_x) break;
+  }
+  if (same_x) madd_same_x(acc, p, neg);
+  return same_x;
+}
+
+// a (memory) += b (memory); both may be infinite.  a is updated in place; b is not written.
+__device__ __forceinline__ void add_mem(const XyzzRef& A, const XyzzRef& B) {
+  if (mem_is_inf(B)) return;
+  if (mem_is_inf(A)) { mem_copy(A, B); return; }
+  Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
+  bool same_x = false;
+#pragma unroll 1
+  for (int step = 0; step < 14; step++) {
+    Fq a, b;
+    switch (step) {
+      case 0: a = mem_ld(A, CX); b = mem_ld(B, CZZ); break;          // U1
+      case 1: a = mem_ld(B, CX); b = mem_ld(A, CZZ); break;          // U2
+      case 2: a = T1; b = T1; break;                                 // PP
+      case 3: a = T1; b = T2; break;                                 // PPP
+      case 4: a = T0; b = T2; break;                                 // Q = U1 PP
+      case 5: a = mem_ld(A, CZZ); b = T2; break;                     // ZZ1 PP
+      case 6: a = mem_ld(A, CZZ); b = mem_ld(B, CZZ); break;         // (ZZ1 PP) ZZ2
+      case 7: a = mem_ld(A, CY); b = mem_ld(B, CZZZ); break;         // S1
+      case 8: a = mem_ld(B, CY); b = mem_ld(A, CZZZ); break;         // S2
+      case 9: a = mem_ld(A, CZZZ); b = T1; break;                    // ZZZ1 PPP
+      case 10: a = mem_ld(A, CZZZ); b = mem_ld(B, CZZZ); break;      // (ZZZ1 PPP) ZZZ2
+      case 11: a = T2; b = T1; break;                                // Y3b = S1 PPP
+      case 12: a = T3; b = T3; break;                                // RR
+      default: a = T3; b = fp_sub<FqParams, 16>(T0, T1); break;      // Y3a = R (Q - X3)
+    }
+    Fq r = fp_mul(a, b);
+    switch (step) {
+      case 0: T0 = r; break;                                         // U1
+      case 1: T1 = fp_sub<FqParams, 2>(r, T0); break;                // P [4]
+      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
+      case 3: T1 = r; break;                                         // PPP
+      case 4: T0 = r; break;                                         // Q
+      case 5: mem_st(A, CZZ, r); break;
+      case 6: mem_st(A, CZZ, r); break;                              // ZZ3
+      case 7: T2 = r; break;                                         // S1
+      case 8: T3 = fp_sub<FqParams, 2>(r, T2); break;                // R [4]
+      case 9: mem_st(A, CZZZ, r); break;
+      case 10: mem_st(A, CZZZ, r); break;                            // ZZZ3
+      case 11: T2 = r; break;                                        // Y3b
+      case 12: T1 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T1), fp_dbl(T0)); mem_st(A, CX, T1); break;   // X3 [10]
+      default: mem_st(A, CY, fp_sub<FqParams, 2>(r, T2)); break;     // Y3 [4]
+    }
+    if (same_x) break;
+  }
+  if (same_x) add_same_x(A, B);
+}
+
+// a (memory) = 2 a.   dbl-2008-s-1 as a micro-program: 9 multiplications
+__device__ __forceinline__ void dbl_mem(const XyzzRef& A) {
+  if (mem_is_inf(A)) return;
+  Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
+#pragma unroll 1
+  for (int step = 0; step < 9; step++) {
+    Fq a, b;
+    switch (step) {
+      case 0: a = fp_dbl(mem_ld(A, CY)); b = a; break;               // V = U^2, U = 2 Y1 [8]
+      case 1: a = fp_dbl(mem_ld(A, CY)); b = T0; break;              // W = U V
+      case 2: a = mem_ld(A, CX); b = T0; break;                      // S = X1 V
+      case 3: a = mem_ld(A, CZZ); b = T0; break;                     // ZZ3 = V ZZ1
+      case 4: a = mem_ld(A, CZZZ); b = T1; break;                    // ZZZ3 = W ZZZ1
+      case 5: a = mem_ld(A, CX); b = a; break;                       // X1^2
+      case 6: a = T3; b = T3; break;                                 // M^2
+      case 7: a = T1; b = mem_ld(A, CY); break;                      // W Y1
+      default: a = T3; b = fp_sub<FqParams, 8>(T2, T0); break;       // M (S - X3)
+    }
+    Fq r = fp_mul(a, b);
+    switch (step) {
+      case 0: T0 = r; break;                                         // V
+      case 1: T1 = r; break;                                         // W
+      case 2: T2 = r; break;                                         // S
+      case 3: mem_st(A, CZZ, r); break;                              // (U = 0 gives ZZ3 = 0: infinity)
+      case 4: mem_st(A, CZZZ, r); break;
+      case 5: T3 = fp_add(fp_dbl(r), r); break;                      // M = 3 X1^2 [6]
+      case 6: T0 = fp_sub<FqParams, 4>(r, fp_dbl(T2)); mem_st(A, CX, T0); break;   // X3 = M^2 - 2S [6]
+      case 7: T1 = r; break;                                         // W Y1
+      default: mem_st(A, CY, fp_sub<FqParams, 2>(r, T1)); break;     // Y3 [4]
+    }
+  }
+}
+
+}  // namespace zkhip

@@ -12,6 +12,8 @@ struct AffPacked;
 
 struct MsmCtx {
   int c, W, L, logL;
+  uint16_t win_off[96];
+  uint8_t win_bits[96];
   size_t B, max_n;
   hipStream_t stream, stream2;
   hipEvent_t ev, ev_acc0, ev_acc1;

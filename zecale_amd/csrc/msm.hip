@@ -19,7 +19,7 @@
 #include <string.h>
 #include <vector>
 
-#include "ec.cuh"
+#include "ec_mem.cuh"
 #include "host_field.hpp"
 #include "msm.h"
 
@@ -50,10 +50,19 @@ __global__ void __launch_bounds__(256) k_bases_to_dev(const uint64_t* __restrict
   out[i] = p;
 }
 
-// one thread per scalar.  digits[w*n + i] = signed digit of window w (|d| <= 2^(c-1));
-// counts[w*B + |d|-1] += 1 for d != 0.
+// Window layout: W windows tile exactly 378 bits (scalars < r < 2^377, plus one bit for the
+// signed-digit carry); window sizes differ by at most one bit (c or c-1) so that no window is a
+// sparsely populated remainder - a short top window would funnel all n points of that window
+// into a few hundred buckets, i.e. into a few hundred lanes.
+struct WindowPlan {
+  uint16_t off[96];   // first bit of window w
+  uint8_t bits[96];   // size of window w
+};
+
+// one thread per scalar.  digits[w*n + i] = signed digit of window w (|d| <= 2^(bits_w - 1));
+// counts[w*B + |d|-1] += 1 for d != 0   (B = 2^(c-1) bucket slots per window).
 __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restrict__ scalars, size_t n, int c, int W,
-                                                        int montgomery, int32_t* __restrict__ digits,
+                                                        WindowPlan plan, int montgomery, int32_t* __restrict__ digits,
                                                         uint32_t* __restrict__ counts) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -69,20 +78,15 @@ __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restric
   }
   w32[12] = 0;
   const uint32_t B = 1u << (c - 1);
-  const uint32_t mask = (1u << c) - 1;
   uint32_t carry = 0;
   for (int w = 0; w < W; w++) {
-    int bit = w * c;
-    uint32_t d = 0;
-    if (bit < 384) {
-      int j = bit >> 5, sh = bit & 31;
-      uint64_t v = (uint64_t)w32[j] >> sh;
-      if (j + 1 < 13) v |= (uint64_t)w32[j + 1] << (32 - sh);
-      d = (uint32_t)v & mask;
-    }
-    d += carry;
+    const int bit = plan.off[w], cw = plan.bits[w];
+    const int j = bit >> 5, sh = bit & 31;
+    uint64_t v = (uint64_t)w32[j] >> sh;
+    if (j + 1 < 13) v |= (uint64_t)w32[j + 1] << (32 - sh);
+    uint32_t d = ((uint32_t)v & ((1u << cw) - 1)) + carry;
     int32_t sd;
-    if (d > B) { sd = (int32_t)d - (int32_t)(1u << c); carry = 1; }
+    if (d > (1u << (cw - 1))) { sd = (int32_t)d - (int32_t)(1u << cw); carry = 1; }
     else { sd = (int32_t)d; carry = 0; }
     digits[(size_t)w * n + i] = sd;
     if (sd != 0) {
@@ -161,73 +165,78 @@ __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ dig
   }
 }
 
-// One lane per bucket.  `order` (optional) maps thread -> bucket so that lanes of a wave get
-// buckets of similar population.
+// One lane per bucket; the bucket accumulator lives in `out` (limb-major, coalesced), see ec_mem.cuh.
 __global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ entries,
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                         size_t nbuckets, uint32_t* __restrict__ out /* XYZZ limb-major, stride nbuckets */) {
   size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   uint32_t start = offsets[b], cnt = counts[b];
-  XYZZ acc = xyzz_infinity();
+  XyzzRef acc = make_ref(out, (uint32_t)nbuckets, (uint32_t)b);
+  bool inf = true;
   for (uint32_t k = 0; k < cnt; k++) {
     uint32_t e = entries[start + k];
-    AffineDev p = aff_load(&bases[e & 0x7fffffffu]);
-    if (p.inf) continue;
-    if (e & 0x80000000u) p.y = fp_sub<FqParams, 2>(fp_zero<FqParams>(), p.y);   // [2]... value p - y, < 2p
-    xyzz_madd(acc, p.x, p.y);
+    const AffPacked* p = &bases[e & 0x7fffffffu];
+    bool neg = (e >> 31) != 0;
+    if (aff_is_inf(p)) continue;
+    if (inf) {
+      mem_st(acc, CX, aff_ld_x(p));
+      mem_st(acc, CY, aff_ld_y(p, neg));
+      mem_st(acc, CZZ, fp_one<FqParams>());
+      mem_st(acc, CZZZ, fp_one<FqParams>());
+      inf = false;
+      continue;
+    }
+    if (madd_mem(acc, p, neg)) inf = mem_is_inf(acc);   // same-x path may have cancelled to infinity
   }
-  xyzz_store(out, nbuckets, b, acc);
+  if (inf) mem_set_inf(acc);
 }
 
 // Segment pass of the bucket reduction.  in: n_in items (XYZZ limb-major, stride n_in), grouped in
 // runs of L.  For segment t: S_t = sum_u item[tL+u],  R_t = sum_u (u + o) item[tL+u]   (o in {0,1}).
-__global__ void __launch_bounds__(256, 2) k_seg(const uint32_t* __restrict__ in, size_t n_in, int L, int o,
+// The running sums live in the output arrays themselves (memory-resident accumulators).
+__global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_t n_in, int L, int o,
                                                  uint32_t* __restrict__ outS, uint32_t* __restrict__ outR) {
   size_t n_out = n_in / L;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_out) return;
-  XYZZ run = xyzz_infinity(), acc = xyzz_infinity();
+  XyzzRef run = make_ref(outS, (uint32_t)n_out, (uint32_t)t), acc = make_ref(outR, (uint32_t)n_out, (uint32_t)t);
+  mem_set_inf(run);
+  mem_set_inf(acc);
   for (int u = L - 1; u >= 0; u--) {
-    XYZZ it = xyzz_load(in, n_in, t * L + u);
-    xyzz_add(run, it);
-    if (u + o > 0) xyzz_add(acc, run);
+    XyzzRef it = make_ref(in, (uint32_t)n_in, (uint32_t)(t * L + u));
+    add_mem(run, it);
+    if (u + o > 0) add_mem(acc, run);
   }
-  xyzz_store(outS, n_out, t, run);
-  xyzz_store(outR, n_out, t, acc);
 }
 
 // out[t] = sum_u in[tL + u]
-__global__ void __launch_bounds__(256, 2) k_sum(const uint32_t* __restrict__ in, size_t n_in, int L, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_t n_in, int L, uint32_t* __restrict__ out) {
   size_t n_out = n_in / L;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_out) return;
-  XYZZ run = xyzz_load(in, n_in, t * L);
-  for (int u = 1; u < L; u++) {
-    XYZZ it = xyzz_load(in, n_in, t * L + u);
-    xyzz_add(run, it);
-  }
-  xyzz_store(out, n_out, t, run);
+  XyzzRef acc = make_ref(out, (uint32_t)n_out, (uint32_t)t);
+  mem_copy(acc, make_ref(in, (uint32_t)n_in, (uint32_t)(t * L)));
+  for (int u = 1; u < L; u++) add_mem(acc, make_ref(in, (uint32_t)n_in, (uint32_t)(t * L + u)));
 }
 
-// per window w: out[w] = R[0][w] + L (R[1][w] + L (R[2][w] + ...)), levels-1 .. 0.
-// R_all: `levels` arrays of W XYZZ points each, limb-major with stride W, consecutive (108*W words apart).
+// per window w: out[w] = R[0][w] + L_0 (R[1][w] + L_1 (R[2][w] + ...)).
+// R_all: `levels` arrays of W XYZZ points each, limb-major with stride W, consecutive (108*W words apart);
+// `work`: scratch for W accumulators.
 struct LevelShifts { uint8_t log_l[32]; };
-__global__ void __launch_bounds__(64, 2) k_window_combine(const uint32_t* __restrict__ R_all, int levels, int W, LevelShifts ls,
-                                                           uint64_t* __restrict__ out_abi /* W x 4 x 12 u64 */) {
+__global__ void __launch_bounds__(64, 2) k_window_combine(uint32_t* __restrict__ R_all, int levels, int W, LevelShifts ls,
+                                                           uint32_t* __restrict__ work, uint64_t* __restrict__ out_abi /* W x 4 x 12 u64 */) {
   int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
-  XYZZ acc = xyzz_load(R_all + (size_t)(levels - 1) * 108 * W, W, w);
+  XyzzRef acc = make_ref(work, (uint32_t)W, (uint32_t)w);
+  mem_copy(acc, make_ref(R_all + (size_t)(levels - 1) * 108 * W, (uint32_t)W, (uint32_t)w));
   for (int k = levels - 2; k >= 0; k--) {
-    for (int d = 0; d < ls.log_l[k]; d++) acc = xyzz_dbl(acc);
-    XYZZ r = xyzz_load(R_all + (size_t)k * 108 * W, W, w);
-    xyzz_add(acc, r);
+    for (int d = 0; d < ls.log_l[k]; d++) dbl_mem(acc);
+    add_mem(acc, make_ref(R_all + (size_t)k * 108 * W, (uint32_t)W, (uint32_t)w));
   }
   uint64_t* o = out_abi + (size_t)w * 48;
-  fp_to_abi<FqParams>(acc.X, o);
-  fp_to_abi<FqParams>(acc.Y, o + 12);
-  fp_to_abi<FqParams>(acc.ZZ, o + 24);
-  fp_to_abi<FqParams>(acc.ZZZ, o + 36);
+#pragma unroll 1
+  for (int c = 0; c < 4; c++) fp_to_abi<FqParams>(mem_ld(acc, c), o + 12 * c);
 }
 
 // ---- batch fixed-base scalar multiplication: out[i] = k_i * G (the inner loop of Groth16 setup:
@@ -253,7 +262,8 @@ __device__ __forceinline__ Fq fq_inv_fermat(const Fq& a) {
 }
 
 __global__ void __launch_bounds__(256, 2) k_fixed_base_mul(const AffPacked* __restrict__ table, const uint64_t* __restrict__ scalars,
-                                                            size_t n, int montgomery, uint64_t* __restrict__ out_abi /* n x 24 */) {
+                                                            size_t n, int montgomery, uint32_t* __restrict__ work /* 108 x n */,
+                                                            uint64_t* __restrict__ out_abi /* n x 24 */) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t s[6];
@@ -266,23 +276,52 @@ __global__ void __launch_bounds__(256, 2) k_fixed_base_mul(const AffPacked* __re
 #pragma unroll
     for (int k = 0; k < 6; k++) { w32[2 * k] = (uint32_t)s[k]; w32[2 * k + 1] = (uint32_t)(s[k] >> 32); }
   }
-  XYZZ acc = xyzz_infinity();
+  XyzzRef acc = make_ref(work, (uint32_t)n, (uint32_t)i);
+  bool inf = true;
   for (int w = 0; w < 95; w++) {
     uint32_t d = (w32[w >> 3] >> ((w & 7) * 4)) & 15u;
     if (d == 0) continue;
-    AffineDev p = aff_load(&table[w * 15 + (d - 1)]);
-    xyzz_madd(acc, p.x, p.y);
+    const AffPacked* p = &table[w * 15 + (d - 1)];
+    if (aff_is_inf(p)) continue;
+    if (inf) {
+      mem_st(acc, CX, aff_ld_x(p)); mem_st(acc, CY, aff_ld_y(p, false));
+      mem_st(acc, CZZ, fp_one<FqParams>()); mem_st(acc, CZZZ, fp_one<FqParams>());
+      inf = false;
+      continue;
+    }
+    if (madd_mem(acc, p, false)) inf = mem_is_inf(acc);
   }
   uint64_t* o = out_abi + i * 24;
-  if (xyzz_is_inf(acc)) {
+  if (inf) {
 #pragma unroll
     for (int k = 0; k < 24; k++) o[k] = 0;
     return;
   }
-  Fq zi = fq_inv_fermat(fp_mul(acc.ZZ, acc.ZZZ));     // 1 / (ZZ * ZZZ)
-  Fq izz = fp_mul(zi, acc.ZZZ), izzz = fp_mul(zi, acc.ZZ);
-  fp_to_abi<FqParams>(fp_mul(acc.X, izz), o);
-  fp_to_abi<FqParams>(fp_mul(acc.Y, izzz), o + 12);
+  // x = X / ZZ, y = Y / ZZZ with one inversion: zi = 1 / (ZZ ZZZ).  A rolled 6-step micro-program.
+  Fq zi = fp_zero<FqParams>(), t = zi;
+#pragma unroll 1
+  for (int step = 0; step < 6; step++) {
+    Fq a, b;
+    switch (step) {
+      case 0: a = mem_ld(acc, CZZ); b = mem_ld(acc, CZZZ); break;
+      case 1: a = zi; b = mem_ld(acc, CZZZ); break;       // 1/ZZ
+      case 2: a = t; b = mem_ld(acc, CX); break;          // x
+      case 3: a = zi; b = mem_ld(acc, CZZ); break;        // 1/ZZZ
+      case 4: a = t; b = mem_ld(acc, CY); break;          // y
+      default: a = zi; b = zi; break;
+    }
+    Fq r = fp_mul(a, b);
+    switch (step) {
+      case 0: zi = fq_inv_fermat(r); break;
+      case 1: t = r; break;
+      case 2: mem_st(acc, CX, r); break;
+      case 3: t = r; break;
+      case 4: mem_st(acc, CY, r); break;
+      default: break;
+    }
+  }
+  fp_to_abi<FqParams>(mem_ld(acc, CX), o);
+  fp_to_abi<FqParams>(mem_ld(acc, CY), o + 12);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -301,9 +340,17 @@ static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs -
 
 int msm_plan_init(MsmCtx* ctx, size_t max_n, int c) {
   memset(ctx, 0, sizeof *ctx);
-  if (c < 4 || c > 20) return ZKHIP_ERR_ARG;
+  if (c < 4 || c > 18) return ZKHIP_ERR_ARG;   // 108 * W * 2^(c-1) * 4 bytes must stay below 4 GiB (buffer descriptor)
   ctx->c = c;
   ctx->W = (378 + c - 1) / c;   // scalars < 2^377, +1 bit for the signed-digit carry
+  {
+    int n_small = ctx->W * c - 378, bit = 0;   // that many windows get c-1 bits (the top ones)
+    for (int w = 0; w < ctx->W; w++) {
+      int cw = (w >= ctx->W - n_small) ? c - 1 : c;
+      ctx->win_off[w] = (uint16_t)bit; ctx->win_bits[w] = (uint8_t)cw;
+      bit += cw;
+    }
+  }
   ctx->B = (size_t)1 << (c - 1);
   ctx->max_n = max_n;
   ctx->L = 4; ctx->logL = 2;
@@ -367,7 +414,10 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, si
   }
   HIP_TRY(hipMemsetAsync(ctx->counts, 0, nb * 4, st));
   HIP_TRY(hipMemsetAsync(ctx->cursor, 0, nb * 4, st));
-  hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(n, 256)), dim3(256), 0, st, d_scalars, n, c, W, scalars_montgomery,
+  WindowPlan plan;
+  memset(&plan, 0, sizeof plan);
+  for (int w = 0; w < W; w++) { plan.off[w] = ctx->win_off[w]; plan.bits[w] = ctx->win_bits[w]; }
+  hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(n, 256)), dim3(256), 0, st, d_scalars, n, c, W, plan, scalars_montgomery,
                      ctx->digits, ctx->counts);
   unsigned sb = nblk(nb, 1024);
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->counts, ctx->offsets, ctx->block_tot, nb);
@@ -382,7 +432,7 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, si
   HIP_TRY(hipGetLastError());
 
   // bucket reduction: F(items) = sum_t R_t + L * F0(S), recursively; levels until one item per window
-  const uint32_t* cur = ctx->buckets;
+  uint32_t* cur = ctx->buckets;
   size_t n_cur = nb;   // W groups of n_cur / W
   int level = 0;
   LevelShifts ls;
@@ -396,7 +446,7 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, si
     uint32_t* S = ctx->segS[level & 1];
     hipLaunchKernelGGL(k_seg, dim3(nblk(n_out, 256)), dim3(256), 0, st, cur, n_cur, L, level == 0 ? 1 : 0, S, ctx->segR);
     // reduce R (n_out items, W groups) to W items: Rlevels[level]
-    const uint32_t* rc = ctx->segR;
+    uint32_t* rc = ctx->segR;
     size_t rn = n_out;
     int pp = 0;
     while (rn > (size_t)W) {
@@ -413,7 +463,7 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, si
     cur = S; n_cur = n_out; level++;
   }
   // the last S (one item per window) has weight 0 at its level (o = 0 for level >= 1) and is dropped.
-  hipLaunchKernelGGL(k_window_combine, dim3(nblk(W, 64)), dim3(64), 0, st, ctx->Rlevels, level, W, ls, ctx->win_abi);
+  hipLaunchKernelGGL(k_window_combine, dim3(nblk(W, 64)), dim3(64), 0, st, ctx->Rlevels, level, W, ls, ctx->sumR[0], ctx->win_abi);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ctx->win_host, ctx->win_abi, (size_t)W * 48 * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -424,7 +474,7 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, si
   // host: sum_w 2^(c w) W_w  (Horner from the top window)
   HJac acc = HJac::infinity();
   for (int w = W - 1; w >= 0; w--) {
-    for (int d = 0; d < c; d++) acc = acc.dbl();
+    for (int d = 0; d < ctx->win_bits[w]; d++) acc = acc.dbl();
     const uint64_t* p = ctx->win_host + (size_t)w * 48;
     HFq X = HFq::from_limbs(p), Y = HFq::from_limbs(p + 12), ZZ = HFq::from_limbs(p + 24), ZZZ = HFq::from_limbs(p + 36);
     if (ZZ.is_zero()) continue;
@@ -462,20 +512,23 @@ int fixed_base_mul(const uint64_t base_aff[24], const uint64_t* d_scalars, size_
   }
   uint64_t* d_tab_abi = nullptr;
   AffPacked* d_tab = nullptr;
+  uint32_t* d_work = nullptr;
   int rc = ZKHIP_OK;
   do {
     hipError_t e;
     if ((e = hipMalloc(&d_tab_abi, tab.size() * 8)) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
     if ((e = hipMalloc(&d_tab, (size_t)95 * 15 * sizeof(AffPacked))) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
+    if ((e = hipMalloc(&d_work, n * 108 * 4)) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
     if ((e = hipMemcpy(d_tab_abi, tab.data(), tab.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
     hipLaunchKernelGGL(k_bases_to_dev, dim3(nblk(95 * 15, 256)), dim3(256), 0, 0, d_tab_abi, d_tab, (size_t)95 * 15);
-    hipLaunchKernelGGL(k_fixed_base_mul, dim3(nblk(n, 256)), dim3(256), 0, 0, d_tab, d_scalars, n, montgomery, d_out);
+    hipLaunchKernelGGL(k_fixed_base_mul, dim3(nblk(n, 256)), dim3(256), 0, 0, d_tab, d_scalars, n, montgomery, d_work, d_out);
     if ((e = hipGetLastError()) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
     if ((e = hipDeviceSynchronize()) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
   } while (0);
   if (rc != ZKHIP_OK && errbuf) snprintf(errbuf, errlen, "fixed_base_mul: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
   if (d_tab_abi) (void)hipFree(d_tab_abi);
   if (d_tab) (void)hipFree(d_tab);
+  if (d_work) (void)hipFree(d_work);
   return rc;
 }
 

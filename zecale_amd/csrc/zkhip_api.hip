@@ -98,7 +98,7 @@ const char* zkhip_strerror(int code) {
 const char* zkhip_last_error(void) { return g.err; }
 
 int zkhip_set_msm_window(int c) {
-  if (c != 0 && (c < 4 || c > 20)) return fail(ZKHIP_ERR_ARG, "window must be 0 or in [4, 20]");
+  if (c != 0 && (c < 4 || c > 18)) return fail(ZKHIP_ERR_ARG, "window must be 0 or in [4, 18]");
   g.forced_c = c;
   return ZKHIP_OK;
 }
