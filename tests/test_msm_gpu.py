@@ -119,3 +119,24 @@ def test_full_size_2_20_closed_form(zk, oracle_lib):
     mst = b.msm(st, montgomery=False)
     assert (zk.jac_to_affine(zk.jac_add(ms, mt)) == zk.jac_to_affine(mst)).all()
     b.free()
+
+
+def test_heavy_buckets_are_stitched(zk, oracle_lib):
+    """Buckets far larger than a slice (half the scalars equal to 1, a fifth equal to one constant):
+    exercises the logarithmic stitching of cut buckets (k_fixup_round)."""
+    O = oracle_lib
+    n = 1 << 14
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(71, n), montgomery=False)
+    scal = random_fr_canonical(72, n)
+    rng = np.random.default_rng(9)
+    sel = rng.random(n)
+    one = np.zeros(6, dtype=np.uint64); one[0] = 1
+    scal[sel < 0.5] = one
+    scal[(sel >= 0.5) & (sel < 0.7)] = scal[0]
+    for window in (0, 8):
+        zk.set_msm_window(window)
+        got = zk.jac_to_affine(zk.msm_raw(bases, scal, montgomery=False))
+        # oracle takes Montgomery scalars: convert canonical -> Montgomery on the oracle side
+        scal_m = np.array([O.f_op("from_canonical", 1, s) for s in scal])
+        assert (got == O.jac_to_affine(O.msm(bases, scal_m))).all()
+    zk.set_msm_window(0)

@@ -15,6 +15,7 @@ struct MsmCtx {
   uint16_t win_off[96];
   uint8_t win_bits[96];
   size_t B, max_n;
+  uint32_t S, T, slot_stride;   // slice length, slice count, words per row of the slot array
   hipStream_t stream, stream2;
   hipEvent_t ev, ev_acc0, ev_acc1;
   int32_t* digits;

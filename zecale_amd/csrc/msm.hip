@@ -165,17 +165,54 @@ __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ dig
   }
 }
 
-// One lane per bucket; the bucket accumulator lives in `out` (limb-major, coalesced), see ec_mem.cuh.
+// Bucket accumulation, load-balanced: lane t owns the fixed-size slice [tS, (t+1)S) of the
+// bucket-sorted entry list, whatever buckets it crosses.  A run of entries that covers a whole
+// bucket is accumulated straight into that bucket's slot; a run cut by a slice boundary goes to a
+// per-slice boundary slot (F = the slice starts inside the bucket, L = the slice ends inside it)
+// and k_fixup stitches the pieces.  All slots live in ONE limb-major array (one buffer
+// descriptor): [0, nb) buckets, [nb, nb+T) F slots, [nb+T, nb+2T) L slots.  Every lane performs
+// exactly S point operations, so waves do not wait on their most loaded lane (thread-per-bucket
+// loses ~45 % to the spread of bucket populations).  The array is zero-filled beforehand
+// (all-zero = infinity), so empty buckets need no work.
+__device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offsets, uint32_t nb, uint32_t pos) {
+  // last b with offsets[b] <= pos  (offsets is non-decreasing; empty buckets repeat the next offset)
+  uint32_t lo = 0, hi = nb;   // invariant: offsets[lo] <= pos, (hi == nb or offsets[hi] > pos)
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= pos) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 __global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ entries,
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                        size_t nbuckets, uint32_t* __restrict__ out /* XYZZ limb-major, stride nbuckets */) {
-  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbuckets) return;
-  uint32_t start = offsets[b], cnt = counts[b];
-  XyzzRef acc = make_ref(out, (uint32_t)nbuckets, (uint32_t)b);
+                                                        uint32_t nb, uint32_t S, uint32_t T, uint32_t* __restrict__ slots,
+                                                        uint32_t stride, uint32_t* __restrict__ max_span) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t M = offsets[nb - 1] + counts[nb - 1];
+  uint32_t pos0 = t * S;
+  if (t >= T || pos0 >= M) return;
+  uint32_t pos1 = min(pos0 + S, M);
+  uint32_t b = bucket_of(offsets, nb, pos0);
+  if (offsets[b] < pos0) {   // this slice starts inside bucket b: an F piece; record how many F pieces b has
+    uint32_t span = (offsets[b] + counts[b] - 1) / S - offsets[b] / S;
+    if (span > 1) atomicMax(max_span, span);
+  }
+  uint32_t bend = pos0;            // forces the run set-up on the first iteration
+  bool first = true;
+  XyzzRef acc = make_ref(slots, stride, 0);
   bool inf = true;
-  for (uint32_t k = 0; k < cnt; k++) {
-    uint32_t e = entries[start + k];
+  for (uint32_t k = pos0; k < pos1; k++) {
+    if (k == bend) {
+      if (!first) { b++; while (offsets[b] + counts[b] <= k) b++; }   // next non-empty bucket
+      first = false;
+      bend = offsets[b] + counts[b];
+      bool starts = (k == offsets[b]), ends = (bend <= pos1);
+      uint32_t slot = (starts && ends) ? b : (!starts ? nb + t : nb + T + t);
+      acc.voff = slot * 4u;
+      inf = true;
+    }
+    uint32_t e = entries[k];
     const AffPacked* p = &bases[e & 0x7fffffffu];
     bool neg = (e >> 31) != 0;
     if (aff_is_inf(p)) continue;
@@ -189,13 +226,49 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restri
     }
     if (madd_mem(acc, p, neg)) inf = mem_is_inf(acc);   // same-x path may have cancelled to infinity
   }
-  if (inf) mem_set_inf(acc);
+}
+
+// Stitch buckets that were cut by slice boundaries.  A bucket that starts in slice t0 and ends in
+// slice t1 > t0 has pieces L[t0], F[t0+1], ..., F[t1].  k_fixup_round(d), d = 1, 2, 4, ... folds the
+// F pieces pairwise (F[t] += F[t+d] for t - (t0+1) divisible by 2d), so a bucket of any
+// population - e.g. "scalar == 1" in a boolean-heavy witness - is stitched in log2(pieces) steps;
+// rounds beyond the largest span exit at once (max_span is written by k_accumulate).
+__global__ void __launch_bounds__(256, 2) k_fixup_round(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                         uint32_t nb, uint32_t S, uint32_t T, uint32_t d,
+                                                         const uint32_t* __restrict__ max_span, uint32_t* __restrict__ slots,
+                                                         uint32_t stride) {
+  if (d >= *max_span) return;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t M = offsets[nb - 1] + counts[nb - 1];
+  uint32_t pos0 = t * S;
+  if (t >= T || pos0 >= M) return;
+  uint32_t b = bucket_of(offsets, nb, pos0);
+  if (offsets[b] >= pos0) return;                       // slice does not start inside a bucket
+  uint32_t tF0 = offsets[b] / S + 1, tF1 = (offsets[b] + counts[b] - 1) / S;
+  if ((t - tF0) % (2 * d) != 0 || t + d > tF1) return;
+  add_mem(make_ref(slots, stride, nb + t), make_ref(slots, stride, nb + t + d));
+}
+
+// final stitch: the slice in which a cut bucket STARTS owns it: bucket = L[t0] + F[t0+1] (folded).
+__global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                   uint32_t nb, uint32_t S, uint32_t T, uint32_t* __restrict__ slots, uint32_t stride) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t M = offsets[nb - 1] + counts[nb - 1];
+  uint32_t pos0 = t * S;
+  if (t >= T || pos0 >= M) return;
+  uint32_t pos1 = min(pos0 + S, M);
+  uint32_t b = bucket_of(offsets, nb, pos1 - 1);
+  uint32_t bend = offsets[b] + counts[b];
+  if (bend <= pos1 || offsets[b] < pos0) return;      // not cut at this slice's end, or started earlier
+  XyzzRef dst = make_ref(slots, stride, b);
+  mem_copy(dst, make_ref(slots, stride, nb + T + t));
+  add_mem(dst, make_ref(slots, stride, nb + t + 1));
 }
 
 // Segment pass of the bucket reduction.  in: n_in items (XYZZ limb-major, stride n_in), grouped in
 // runs of L.  For segment t: S_t = sum_u item[tL+u],  R_t = sum_u (u + o) item[tL+u]   (o in {0,1}).
 // The running sums live in the output arrays themselves (memory-resident accumulators).
-__global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_t n_in, int L, int o,
+__global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_t n_in, uint32_t in_stride, int L, int o,
                                                  uint32_t* __restrict__ outS, uint32_t* __restrict__ outR) {
   size_t n_out = n_in / L;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,7 +277,7 @@ __global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_
   mem_set_inf(run);
   mem_set_inf(acc);
   for (int u = L - 1; u >= 0; u--) {
-    XyzzRef it = make_ref(in, (uint32_t)n_in, (uint32_t)(t * L + u));
+    XyzzRef it = make_ref(in, in_stride, (uint32_t)(t * L + u));
     add_mem(run, it);
     if (u + o > 0) add_mem(acc, run);
   }
@@ -366,7 +439,20 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c) {
   HIP_TRY(hipMalloc(&ctx->cursor, nb * 4));
   HIP_TRY(hipMalloc(&ctx->block_tot, (nb / 1024 + 2) * 4));
   HIP_TRY(hipMalloc(&ctx->entries, (size_t)ctx->W * max_n * 4));
-  HIP_TRY(hipMalloc(&ctx->buckets, nb * 108 * 4));
+  // slice length: every lane gets the same number of point operations; aim at a whole number of
+  // machine fills (256 CUs x 8 waves x 64 lanes at two waves per SIMD)
+  {
+    const size_t lanes = 131072, m_max = (size_t)ctx->W * max_n;
+    size_t fills = (m_max + lanes * 48 - 1) / (lanes * 48);     // ~48 entries per lane and fill
+    if (fills < 1) fills = 1;
+    size_t S = (m_max + lanes * fills - 1) / (lanes * fills);
+    if (S < 16) S = 16;
+    ctx->S = (uint32_t)S;
+    ctx->T = (uint32_t)((m_max + S - 1) / S);
+    ctx->slot_stride = (uint32_t)(nb + 2 * (size_t)ctx->T);
+    if ((size_t)ctx->slot_stride * 108 * 4 >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;
+  }
+  HIP_TRY(hipMalloc(&ctx->buckets, (size_t)ctx->slot_stride * 108 * 4));
   // reduction scratch: S ping-pong (<= nb/L each) and R arrays (sum over levels <= nb/L * L/(L-1)), R sums
   HIP_TRY(hipMalloc(&ctx->segS[0], (nb / ctx->L + 1) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->segS[1], (nb / ctx->L + 1) * 108 * 4));
@@ -425,10 +511,28 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, si
   hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, ctx->offsets, ctx->block_tot, nb);
   hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->digits, n, c, W, ctx->offsets, ctx->cursor,
                      ctx->entries);
+  HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 4, st));   // block_tot[0] is reused as the max-span cell (scan is done)
+  // slice length for THIS n (the plan's slot array is sized for max_n)
+  uint32_t S_run, T_run;
+  {
+    const size_t lanes = 131072, m = (size_t)W * n;
+    size_t fills = (m + lanes * 48 - 1) / (lanes * 48);
+    if (fills < 1) fills = 1;
+    size_t S = (m + lanes * fills - 1) / (lanes * fills);
+    if (S < 16) S = 16;
+    while ((m + S - 1) / S > ctx->T) S++;
+    S_run = (uint32_t)S; T_run = (uint32_t)((m + S - 1) / S);
+  }
+  HIP_TRY(hipMemsetAsync(ctx->buckets, 0, (size_t)ctx->slot_stride * 108 * 4, st));
   HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
-  hipLaunchKernelGGL(k_accumulate, dim3(nblk(nb, 256)), dim3(256), 0, st, d_bases, ctx->entries, ctx->offsets, ctx->counts,
-                     nb, ctx->buckets);
+  hipLaunchKernelGGL(k_accumulate, dim3(nblk(T_run, 256)), dim3(256), 0, st, d_bases, ctx->entries, ctx->offsets, ctx->counts,
+                     (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
+  for (uint32_t d = 1; d < T_run; d <<= 1)
+    hipLaunchKernelGGL(k_fixup_round, dim3(nblk(T_run, 256)), dim3(256), 0, st, ctx->offsets, ctx->counts, (uint32_t)nb, S_run, T_run, d,
+                       ctx->block_tot + 0, ctx->buckets, ctx->slot_stride);
+  hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, ctx->offsets, ctx->counts, (uint32_t)nb, S_run, T_run,
+                     ctx->buckets, ctx->slot_stride);
   HIP_TRY(hipGetLastError());
 
   // bucket reduction: F(items) = sum_t R_t + L * F0(S), recursively; levels until one item per window
@@ -444,7 +548,8 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, si
     ls.log_l[level] = (uint8_t)lg;
     size_t n_out = n_cur / L;
     uint32_t* S = ctx->segS[level & 1];
-    hipLaunchKernelGGL(k_seg, dim3(nblk(n_out, 256)), dim3(256), 0, st, cur, n_cur, L, level == 0 ? 1 : 0, S, ctx->segR);
+    hipLaunchKernelGGL(k_seg, dim3(nblk(n_out, 256)), dim3(256), 0, st, cur, n_cur, level == 0 ? ctx->slot_stride : (uint32_t)n_cur, L,
+                       level == 0 ? 1 : 0, S, ctx->segR);
     // reduce R (n_out items, W groups) to W items: Rlevels[level]
     uint32_t* rc = ctx->segR;
     size_t rn = n_out;
