@@ -74,6 +74,14 @@ int zkhip_fixed_base_mul(const uint64_t base_affine[24], const uint64_t* scalars
 int zkhip_fixed_base_mul_dev(const uint64_t base_affine[24], const void* d_scalars, size_t len, int scalars_montgomery,
                              void* d_out_affine);
 
+/* replaces: libfqfft::basic_radix2_domain<Fr>::FFT / iFFT / cosetFFT / icosetFFT as used by
+ * r1cs_to_qap_witness_map (reached from aggregator_circuit.tcc:168).  In place, natural order in
+ * and out, 2^log_d elements of 6 limbs (Montgomery form); domain <omega>, omega = 15^((r-1)/2^log_d),
+ * coset generator g = 15.   dir: 0 = forward, 1 = inverse.   coset: 0 / 1.   log_d <= 22.
+ *   forward, coset:   a_i <- a_i g^i, then FFT          inverse, coset:   iFFT, then a_i <- a_i g^-i */
+int zkhip_ntt(uint64_t* data, unsigned log_d, int dir, int coset);
+int zkhip_ntt_dev(void* d_data, unsigned log_d, int dir, int coset);
+
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
 

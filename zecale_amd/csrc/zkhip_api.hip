@@ -7,6 +7,7 @@
 #include "ec.cuh"
 #include "host_field.hpp"
 #include "msm.h"
+#include "ntt.h"
 
 using namespace zkhip;
 
@@ -198,6 +199,28 @@ int zkhip_fixed_base_mul(const uint64_t base_affine[24], const uint64_t* scalars
   int rc = zkhip_fixed_base_mul_dev(base_affine, ds, len, scalars_montgomery, dp);
   if (rc == ZKHIP_OK) API_HIP(hipMemcpy(out_affine, dp, len * 192, hipMemcpyDeviceToHost));
   (void)hipFree(ds); (void)hipFree(dp);
+  return rc;
+}
+
+int zkhip_ntt_dev(void* d_data, unsigned log_d, int dir, int coset) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!d_data) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (log_d > 22) return fail(ZKHIP_ERR_ARG, "log_d must be <= 22");
+  return ntt_dev_abi((uint64_t*)d_data, (int)log_d, dir != 0, coset != 0, g.err, sizeof g.err);
+}
+
+int zkhip_ntt(uint64_t* data, unsigned log_d, int dir, int coset) {
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!data) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (log_d > 22) return fail(ZKHIP_ERR_ARG, "log_d must be <= 22");
+  size_t bytes = ((size_t)48) << log_d;
+  void* d = nullptr;
+  API_HIP(hipMalloc(&d, bytes));
+  API_HIP(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice));
+  int rc = zkhip_ntt_dev(d, log_d, dir, coset);
+  if (rc == ZKHIP_OK) API_HIP(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
   return rc;
 }
 

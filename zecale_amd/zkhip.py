@@ -14,7 +14,7 @@ EXPORTS = [
     "zkhip_init", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window",
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_last_accumulate_ms",
-    "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev",
+    "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_jac_to_affine", "zkhip_jac_add",
 ]
 
@@ -50,6 +50,8 @@ def load():
     lib.zkhip_msm_raw.argtypes = [c_u64p, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
     lib.zkhip_fixed_base_mul.argtypes = [c_u64p, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
     lib.zkhip_fixed_base_mul_dev.argtypes = [c_u64p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    lib.zkhip_ntt.argtypes = [c_u64p, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
+    lib.zkhip_ntt_dev.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
     lib.zkhip_last_accumulate_ms.restype = ctypes.c_float
     lib.zkhip_jac_to_affine.argtypes = [c_u64p, c_u64p]
     lib.zkhip_jac_add.argtypes = [c_u64p, c_u64p, c_u64p]
@@ -135,6 +137,18 @@ def fixed_base_mul(base_affine, scalars, montgomery=True):
 def fixed_base_mul_dev(base_affine, d_scalars_ptr, n, d_out_ptr, montgomery=True):
     b = np.ascontiguousarray(base_affine, dtype=np.uint64).reshape(24)
     _check(load().zkhip_fixed_base_mul_dev(_p(b), ctypes.c_void_p(d_scalars_ptr), n, int(montgomery), ctypes.c_void_p(d_out_ptr)))
+
+
+def ntt(data, log_d, inverse=False, coset=False):
+    """FFT / iFFT / cosetFFT / icosetFFT of 2^log_d Fr elements (n x 6 limbs); returns a new array."""
+    a = np.array(data, dtype=np.uint64).reshape(-1, 6).copy()
+    assert a.shape[0] == 1 << log_d
+    _check(load().zkhip_ntt(_p(a), log_d, int(inverse), int(coset)))
+    return a
+
+
+def ntt_dev(dev_ptr, log_d, inverse=False, coset=False):
+    _check(load().zkhip_ntt_dev(ctypes.c_void_p(dev_ptr), log_d, int(inverse), int(coset)))
 
 
 def jac_to_affine(jac):
