@@ -82,6 +82,49 @@ int zkhip_fixed_base_mul_dev(const uint64_t base_affine[24], const void* d_scala
 int zkhip_ntt(uint64_t* data, unsigned log_d, int dir, int coset);
 int zkhip_ntt_dev(void* d_data, unsigned log_d, int dir, int coset);
 
+/* ---- R1CS, QAP witness map and the Groth16 prover ---------------------------------------- */
+/* A constraint system <A_i,z> * <B_i,z> = <C_i,z>, i < n_constraints, in CSR form; z = (1, primary,
+ * auxiliary) has n_vars entries.  Replaces libsnark::r1cs_constraint_system<Fr<wppT>> as returned by
+ * aggregator_circuit::get_constraint_system() (libzecale/circuits/aggregator_circuit.hpp:99-101). */
+typedef struct {
+  size_t n_constraints, n_vars, n_primary;
+  const uint32_t *a_row_ptr, *a_col; const uint64_t* a_val;   /* row_ptr: n+1, col: nnz, val: nnz x 6 limbs */
+  const uint32_t *b_row_ptr, *b_col; const uint64_t* b_val;
+  const uint32_t *c_row_ptr, *c_col; const uint64_t* c_val;
+} zkhip_r1cs_desc;
+typedef struct zkhip_r1cs zkhip_r1cs;
+int zkhip_r1cs_upload(const zkhip_r1cs_desc* d, zkhip_r1cs** out);
+void zkhip_r1cs_free(zkhip_r1cs* r);
+unsigned zkhip_r1cs_log_domain(const zkhip_r1cs* r);   /* log2 of the QAP domain size d */
+
+/* replaces: protoboard::is_satisfied() under DEBUG (aggregator_circuit.tcc:159-164); *ok = 1/0 */
+int zkhip_r1cs_is_satisfied(zkhip_r1cs* r, const uint64_t* z, int* ok);
+
+/* replaces: libsnark::r1cs_to_qap_witness_map(cs, primary, auxiliary, 0, 0, 0, force_pow_2) -
+ * coefficients_for_H.  h_out: d x 6 limbs (h_{d-1} = 0). */
+int zkhip_qap_h(zkhip_r1cs* r, const uint64_t* z, uint64_t* h_out);
+
+/* The proving key (replaces r1cs_gg_ppzksnark_proving_key<bw6_761_pp> held by the server,
+ * aggregator_server/aggregator_server.cpp:483-514).  All points affine, 24 limbs each.
+ * Lengths: a_query, b_g2_query, b_g1_query: n_vars;  h_query: d - 1;  l_query: n_vars - n_primary - 1. */
+typedef struct {
+  size_t n_vars, n_primary, domain_size;
+  const uint64_t *alpha_g1, *beta_g1, *beta_g2, *delta_g1, *delta_g2;
+  const uint64_t *a_query, *b_g2_query, *b_g1_query, *h_query, *l_query;
+} zkhip_crs_desc;
+typedef struct zkhip_crs zkhip_crs;
+int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out);
+void zkhip_crs_free(zkhip_crs* c);
+
+/* replaces: wsnarkT::generate_proof(pk, pb) = libsnark::r1cs_gg_ppzksnark_prover (called at
+ * libzecale/circuits/aggregator_circuit.tcc:168), with the randomisers (r, s) injected so that
+ * results can be compared bit for bit.  z: n_vars x 6 limbs.  proof_affine: A (G1), B (G2), C (G1). */
+int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, const uint64_t r[6], const uint64_t s[6],
+                        uint64_t proof_affine[72]);
+/* phase timings of the last zkhip_groth16_prove, milliseconds: [0] upload z, [1] QAP (SpMV + 7 NTT),
+ * [2..6] the five MSMs A, B2, B1, H, L, [7] host tail */
+int zkhip_last_prove_timings(double out_ms[8]);
+
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
 

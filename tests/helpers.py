@@ -71,3 +71,57 @@ def random_fr_canonical(seed, n):
     a = splitmix64(seed, n * 6).reshape(n, 6)
     a[:, 5] &= np.uint64((1 << 56) - 1)
     return a
+
+
+# ---------------------------------------------------------------- synthetic R1CS / CRS (tests + bench)
+def make_r1cs(seed, n_constraints, n_primary, n_aux, bool_frac=0.0):
+    """Satisfiable-by-construction R1CS in Python ints: rows are lists of (var, coeff).
+    Constraint j: (sum a z)(sum b z) = c1 z_k + c0 with c0 solved for.  bool_frac of the auxiliary
+    variables are 0/1 (boolean-heavy witness)."""
+    import random
+    rng = random.Random(seed)
+    m = 1 + n_primary + n_aux
+    z = [1] + [rng.randrange(R.R_MOD) for _ in range(m - 1)]
+    for i in range(1 + n_primary, m):
+        if rng.random() < bool_frac:
+            z[i] = rng.randrange(2)
+    A, B, C = [], [], []
+    for _ in range(n_constraints):
+        ra = [(rng.randrange(m), rng.randrange(1, 1 << 30)) for _ in range(rng.randrange(1, 4))]
+        rb = [(rng.randrange(m), rng.randrange(1, R.R_MOD)) for _ in range(rng.randrange(1, 3))]
+        va, vb = R.r1cs_eval_row(ra, z), R.r1cs_eval_row(rb, z)
+        k = rng.randrange(1, m)
+        c1 = rng.randrange(1, R.R_MOD)
+        c0 = (va * vb - c1 * z[k]) % R.R_MOD
+        A.append(ra); B.append(rb); C.append([(k, c1), (0, c0)])
+    return A, B, C, z
+
+
+def csr_from_rows(rows):
+    rp, col, val = [0], [], []
+    for row in rows:
+        for i, c in row:
+            col.append(i)
+            val.append(h2i(c) if isinstance(c, str) else c)
+        rp.append(len(col))
+    return (np.array(rp, dtype=np.uint32), np.array(col, dtype=np.uint32), fr_array(val))
+
+
+def crs_from_trapdoor(zk, A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
+    """Proving key with known toxic waste: exponents from oracle/pyref (big ints), group elements by the
+    product's fixed-base kernel (checked against the oracle in test_msm_gpu)."""
+    st = R.groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta)
+    d = 1 << st["log_d"]
+    dinv = pow(delta, -1, R.R_MOD)
+    g1, g2 = aff_limbs(R.G1_GEN), aff_limbs(R.G2_GEN)
+    can = lambda xs: np.array([R.int_to_limbs(x % R.R_MOD, 6) for x in xs], dtype=np.uint64).reshape(-1, 6)
+    fb = lambda g, xs: zk.fixed_base_mul(g, can(xs), montgomery=False) if len(xs) else np.zeros((0, 24), dtype=np.uint64)
+    hs, t = [], st["Zt"] * dinv % R.R_MOD
+    for _ in range(d - 1):
+        hs.append(t)
+        t = t * tau % R.R_MOD
+    ls = [(beta * st["At"][i] + alpha * st["Bt"][i] + st["Ct"][i]) * dinv % R.R_MOD for i in range(n_primary + 1, n_vars)]
+    pk = dict(alpha_g1=fb(g1, [alpha])[0], beta_g1=fb(g1, [beta])[0], beta_g2=fb(g2, [beta])[0],
+              delta_g1=fb(g1, [delta])[0], delta_g2=fb(g2, [delta])[0],
+              A=fb(g1, st["At"]), B2=fb(g2, st["Bt"]), B1=fb(g1, st["Bt"]), H=fb(g1, hs), L=fb(g1, ls))
+    return pk, st["log_d"]

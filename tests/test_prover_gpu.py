@@ -1,0 +1,92 @@
+"""Parity of the HIP Groth16 prover (zkhip_groth16_prove: SpMV + 7 NTT + 5 MSM + tail) with the CPU
+oracle and with the trapdoor closed form; mirrors the checks of the reference's
+libzecale/tests/aggregator/aggregator_dummy_test.cpp:61-62 (proof verifies) at the level this
+path is pinned: limb-exact proof elements for injected (r, s)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyref as R
+from tests.helpers import (aff_limbs, aff_point, crs_from_trapdoor, csr_from_rows, fr_array, fr_ints, fr_limbs, golden, h2i,
+                           make_r1cs, pt_from_json)
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden_case():
+    g = golden("groth16_small.json")
+    pts = lambda L: np.array([aff_limbs(pt_from_json(p)) for p in L]).reshape(-1, 24)
+    pk = {k: (aff_limbs(pt_from_json(v)) if k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2") else pts(v))
+          for k, v in g["pk"].items()}
+    return g, pk
+
+
+def test_golden_small_circuit(zk):
+    g, pk = _golden_case()
+    A, B, C = (csr_from_rows(g[k]) for k in "ABC")
+    z = fr_array([h2i(x) for x in g["z"]])
+    r1 = zk.R1cs(A, B, C, len(g["z"]), g["n_primary"])
+    assert r1.log_d == g["log_d"]
+    assert r1.is_satisfied(z)
+    zbad = z.copy(); zbad[3] = fr_limbs(12345)
+    assert not r1.is_satisfied(zbad)
+    assert fr_ints(r1.qap_h(z)) == [h2i(x) for x in g["h"]]
+    crs = zk.Crs(pk, len(g["z"]), g["n_primary"], 1 << g["log_d"])
+    proof = zk.groth16_prove(crs, r1, z, fr_limbs(h2i(g["r"])), fr_limbs(h2i(g["s"])))
+    assert aff_point(proof[:24]) == pt_from_json(g["proof"]["a"])
+    assert aff_point(proof[24:48]) == pt_from_json(g["proof"]["b"])
+    assert aff_point(proof[48:]) == pt_from_json(g["proof"]["c"])
+    crs.free(); r1.free()
+
+
+@pytest.mark.parametrize("n,bool_frac", [(3000, 0.0), (4000, 0.6)])
+def test_synthetic_circuit_vs_oracle_and_trapdoor(zk, oracle_lib, n, bool_frac):
+    O = oracle_lib
+    n_primary, n_aux = 4, n                # the wrapping circuit has 4 primary inputs (aggregator_circuit.tcc:172-180)
+    A, B, C, z = make_r1cs(11 + n, n, n_primary, n_aux, bool_frac)
+    m = len(z)
+    rng = random.Random(5)
+    tau, alpha, beta, delta, r, s = (rng.randrange(1, R.R_MOD) for _ in range(6))
+    pk, log_d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta)
+    Ac, Bc, Cc = csr_from_rows(A), csr_from_rows(B), csr_from_rows(C)
+    zl = fr_array(z)
+    r1 = zk.R1cs(Ac, Bc, Cc, m, n_primary)
+    assert r1.log_d == log_d and r1.is_satisfied(zl)
+    h = r1.qap_h(zl)
+    h_or = O.qap_h(Ac, Bc, Cc, zl, n, n_primary)
+    assert (h == h_or).all()
+    assert (h[-1] == 0).all()
+    crs = zk.Crs(pk, m, n_primary, 1 << log_d)
+    proof = zk.groth16_prove(crs, r1, zl, fr_limbs(r), fr_limbs(s))
+    proof_or = O.groth16_prove(pk, zl, n_primary, h_or, fr_limbs(r), fr_limbs(s))
+    assert (proof == proof_or).all()
+    # trapdoor closed form: A = (alpha + a(tau) + r delta) G1 etc. with h from the oracle
+    st = R.groth16_setup_scalars(A, B, C, m, n_primary, tau, alpha, beta, delta)
+    hi = fr_ints(h_or)
+    d = 1 << log_d
+    a_t = sum(zi * x for zi, x in zip(z, st["At"])) % R.R_MOD
+    b_t = sum(zi * x for zi, x in zip(z, st["Bt"])) % R.R_MOD
+    dinv = pow(delta, -1, R.R_MOD)
+    h_t = R.poly_eval(hi[: d - 1], tau) * st["Zt"] % R.R_MOD * dinv % R.R_MOD
+    l_t = sum(z[i] * ((beta * st["At"][i] + alpha * st["Bt"][i] + st["Ct"][i]) % R.R_MOD) for i in range(n_primary + 1, m)) % R.R_MOD * dinv % R.R_MOD
+    sa = (alpha + a_t + r * delta) % R.R_MOD
+    sb = (beta + b_t + s * delta) % R.R_MOD
+    sc = (h_t + l_t + s * sa + r * sb - r * s % R.R_MOD * delta) % R.R_MOD
+    g1, g2 = aff_limbs(R.G1_GEN), aff_limbs(R.G2_GEN)
+    assert (proof[:24] == O.jac_to_affine(O.scalar_mul(g1, fr_limbs(sa)))).all()
+    assert (proof[24:48] == O.jac_to_affine(O.scalar_mul(g2, fr_limbs(sb)))).all()
+    assert (proof[48:] == O.jac_to_affine(O.scalar_mul(g1, fr_limbs(sc)))).all()
+    print(zk.last_prove_timings())
+    crs.free(); r1.free()
+
+
+def test_bad_arguments(zk):
+    g, pk = _golden_case()
+    A, B, C = (csr_from_rows(g[k]) for k in "ABC")
+    r1 = zk.R1cs(A, B, C, len(g["z"]), g["n_primary"])
+    with pytest.raises(zk.ZkhipError):           # proving key for another size
+        crs = zk.Crs(pk, len(g["z"]), g["n_primary"], 1 << g["log_d"])
+        r2 = zk.R1cs(A, B, C, len(g["z"]), g["n_primary"] + 1)
+        zk.groth16_prove(crs, r2, fr_array([h2i(x) for x in g["z"]]), fr_limbs(1), fr_limbs(1))
+    r1.free()

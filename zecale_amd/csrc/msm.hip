@@ -70,11 +70,16 @@ __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restric
 #pragma unroll
   for (int k = 0; k < 6; k++) s[k] = scalars[i * 6 + k];
   uint32_t w32[13];
-  if (montgomery) {
+  if (montgomery == 1) {
     fp_abi_to_canonical_words<FrParams>(s, w32);
   } else {
 #pragma unroll
     for (int k = 0; k < 6; k++) { w32[2 * k] = (uint32_t)s[k]; w32[2 * k + 1] = (uint32_t)(s[k] >> 32); }
+    if (montgomery == 2) {   // packed device form (value * 2^406, < 2^384), as the NTT kernels leave it
+      Fp<FrParams> v = fp_unpack32<FrParams>(w32), one_raw = fp_zero<FrParams>();
+      one_raw.l[0] = 1;
+      fp_pack32<FrParams>(fp_cond_sub_p(fp_mul(v, one_raw)), w32);
+    }
   }
   w32[12] = 0;
   const uint32_t B = 1u << (c - 1);

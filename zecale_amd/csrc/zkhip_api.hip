@@ -8,6 +8,8 @@
 #include "host_field.hpp"
 #include "msm.h"
 #include "ntt.h"
+#include "qap.h"
+#include <chrono>
 
 using namespace zkhip;
 
@@ -16,7 +18,18 @@ struct zkhip_bases {
   size_t len;
 };
 
+struct zkhip_r1cs {
+  R1csDev* dev;
+};
+
+struct zkhip_crs {
+  size_t n_vars, n_primary, domain_size;
+  zkhip_bases *A, *B2, *B1, *H, *L;
+  uint64_t alpha_g1[24], beta_g1[24], beta_g2[24], delta_g1[24], delta_g2[24];
+};
+
 namespace {
+double g_prove_ms[8];
 struct Lib {
   bool inited = false;
   int device = -1;
@@ -222,6 +235,141 @@ int zkhip_ntt(uint64_t* data, unsigned log_d, int dir, int coset) {
   if (rc == ZKHIP_OK) API_HIP(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost));
   (void)hipFree(d);
   return rc;
+}
+
+int zkhip_r1cs_upload(const zkhip_r1cs_desc* d, zkhip_r1cs** out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!d || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  R1csDev* dev = nullptr;
+  int rc = r1cs_upload(d, &dev, g.err, sizeof g.err);
+  if (rc != ZKHIP_OK) return rc;
+  *out = new zkhip_r1cs{dev};
+  return ZKHIP_OK;
+}
+
+void zkhip_r1cs_free(zkhip_r1cs* r) {
+  if (!r) return;
+  r1cs_free(r->dev);
+  delete r;
+}
+
+unsigned zkhip_r1cs_log_domain(const zkhip_r1cs* r) { return r ? (unsigned)r->dev->log_d : 0; }
+
+int zkhip_r1cs_is_satisfied(zkhip_r1cs* r, const uint64_t* z, int* ok) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!r || !z || !ok) return fail(ZKHIP_ERR_ARG, "null pointer");
+  uint64_t* dz = nullptr;
+  API_HIP(hipMalloc(&dz, r->dev->n_vars * 48));
+  API_HIP(hipMemcpy(dz, z, r->dev->n_vars * 48, hipMemcpyHostToDevice));
+  int rc = r1cs_is_satisfied_dev(r->dev, dz, 0, ok, g.err, sizeof g.err);
+  (void)hipFree(dz);
+  return rc;
+}
+
+int zkhip_qap_h(zkhip_r1cs* r, const uint64_t* z, uint64_t* h_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!r || !z || !h_out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  size_t d = (size_t)1 << r->dev->log_d;
+  uint64_t *dz = nullptr, *dh = nullptr;
+  API_HIP(hipMalloc(&dz, r->dev->n_vars * 48));
+  API_HIP(hipMalloc(&dh, d * 48));
+  API_HIP(hipMemcpy(dz, z, r->dev->n_vars * 48, hipMemcpyHostToDevice));
+  int rc = qap_h_dev(r->dev, dz, 0, g.err, sizeof g.err);
+  if (rc == ZKHIP_OK) {
+    fr_dev_to_abi(r->dev->bufA, dh, d, 0);
+    API_HIP(hipMemcpy(h_out, dh, d * 48, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(dz); (void)hipFree(dh);
+  return rc;
+}
+
+int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) {
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!d || !out || !d->alpha_g1 || !d->beta_g1 || !d->beta_g2 || !d->delta_g1 || !d->delta_g2)
+    return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (d->n_vars < d->n_primary + 1 || d->domain_size < 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
+  zkhip_crs* c = new zkhip_crs();
+  c->n_vars = d->n_vars; c->n_primary = d->n_primary; c->domain_size = d->domain_size;
+  memcpy(c->alpha_g1, d->alpha_g1, 192); memcpy(c->beta_g1, d->beta_g1, 192); memcpy(c->beta_g2, d->beta_g2, 192);
+  memcpy(c->delta_g1, d->delta_g1, 192); memcpy(c->delta_g2, d->delta_g2, 192);
+  int rc;
+  if ((rc = zkhip_bases_upload(d->a_query, d->n_vars, &c->A)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->b_g2_query, d->n_vars, &c->B2)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->b_g1_query, d->n_vars, &c->B1)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->h_query, d->domain_size - 1, &c->H)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->l_query, d->n_vars - d->n_primary - 1, &c->L)) != ZKHIP_OK) return rc;
+  *out = c;
+  return ZKHIP_OK;
+}
+
+void zkhip_crs_free(zkhip_crs* c) {
+  if (!c) return;
+  zkhip_bases_free(c->A); zkhip_bases_free(c->B2); zkhip_bases_free(c->B1); zkhip_bases_free(c->H); zkhip_bases_free(c->L);
+  delete c;
+}
+
+int zkhip_last_prove_timings(double out_ms[8]) {
+  if (!out_ms) return ZKHIP_ERR_ARG;
+  memcpy(out_ms, g_prove_ms, sizeof g_prove_ms);
+  return ZKHIP_OK;
+}
+
+int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6],
+                        uint64_t proof_affine[72]) {
+  using namespace host;
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!crs || !r1cs || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+  R1csDev* rd = r1cs->dev;
+  const size_t m = crs->n_vars, l = crs->n_primary, d = (size_t)1 << rd->log_d;
+  if (rd->n_vars != m || rd->n_primary != l || crs->domain_size != d)
+    return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+  auto t0 = clk::now();
+  uint64_t* dz = nullptr;
+  API_HIP(hipMalloc(&dz, m * 48));
+  API_HIP(hipMemcpy(dz, z, m * 48, hipMemcpyHostToDevice));
+  g_prove_ms[0] = ms_since(t0);
+  t0 = clk::now();
+  int rc = qap_h_dev(rd, dz, 0, g.err, sizeof g.err);
+  if (rc != ZKHIP_OK) { (void)hipFree(dz); return rc; }
+  API_HIP(hipDeviceSynchronize());
+  g_prove_ms[1] = ms_since(t0);
+  size_t maxlen = m > d ? m : d;
+  if ((rc = ensure_msm(maxlen)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
+  uint64_t evA[36], evB2[36], evB1[36], evH[36], evL[36];
+  struct { const zkhip_bases* b; const uint64_t* sc; size_t len; int mode; uint64_t* out; } jobs[5] = {
+      {crs->A, dz, m, 1, evA}, {crs->B2, dz, m, 1, evB2}, {crs->B1, dz, m, 1, evB1},
+      {crs->H, (const uint64_t*)rd->bufA, d - 1, 2, evH}, {crs->L, dz + (l + 1) * 6, m - l - 1, 1, evL}};
+  for (int j = 0; j < 5; j++) {
+    t0 = clk::now();
+    rc = msm_run(&g.msm, jobs[j].b->d_pts, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].out);
+    g_prove_ms[2 + j] = ms_since(t0);
+    if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", g.msm.errbuf); (void)hipFree(dz); return rc; }
+  }
+  (void)hipFree(dz);
+  // tail: A = alpha + evA + r delta1;  B = beta + evB + s delta;  C = evH + evL + s A + r B1 - rs delta1
+  t0 = clk::now();
+  auto jac = [](const uint64_t* p) { HJac q; q.X = HFq::from_limbs(p); q.Y = HFq::from_limbs(p + 12); q.Z = HFq::from_limbs(p + 24); return q; };
+  auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
+  HFr r = HFr::from_limbs(r_m), s = HFr::from_limbs(s_m), rs = r * s;
+  uint64_t rc_[6], sc_[6], rsc_[6];
+  r.to_canonical(rc_); s.to_canonical(sc_); rs.to_canonical(rsc_);
+  HJac d1 = aff(crs->delta_g1), d2 = aff(crs->delta_g2);
+  HJac gA = jac(evA).add(aff(crs->alpha_g1)).add(d1.mul_canonical(rc_, 6));
+  HJac gB2 = jac(evB2).add(aff(crs->beta_g2)).add(d2.mul_canonical(sc_, 6));
+  HJac gB1 = jac(evB1).add(aff(crs->beta_g1)).add(d1.mul_canonical(sc_, 6));
+  HJac gC = jac(evH).add(jac(evL)).add(gA.mul_canonical(sc_, 6)).add(gB1.mul_canonical(rc_, 6)).add(d1.mul_canonical(rsc_, 6).neg());
+  HFq x, y;
+  gA.to_affine(x, y); x.to_limbs(proof_affine); y.to_limbs(proof_affine + 12);
+  gB2.to_affine(x, y); x.to_limbs(proof_affine + 24); y.to_limbs(proof_affine + 36);
+  gC.to_affine(x, y); x.to_limbs(proof_affine + 48); y.to_limbs(proof_affine + 60);
+  g_prove_ms[7] = ms_since(t0);
+  return ZKHIP_OK;
 }
 
 float zkhip_last_accumulate_ms(void) { return g.msm_ready ? g.msm.last_accumulate_ms : 0.f; }

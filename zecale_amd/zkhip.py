@@ -15,12 +15,25 @@ EXPORTS = [
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_last_accumulate_ms",
     "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
+    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
+    "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings",
     "zkhip_jac_to_affine", "zkhip_jac_add",
 ]
 
 
 class ZkhipError(RuntimeError):
     pass
+
+
+class R1csDesc(ctypes.Structure):
+    _fields_ = [("n_constraints", ctypes.c_size_t), ("n_vars", ctypes.c_size_t), ("n_primary", ctypes.c_size_t)] + [
+        (f"{m}_{k}", ctypes.c_void_p) for m in "abc" for k in ("row_ptr", "col", "val")]
+
+
+class CrsDesc(ctypes.Structure):
+    _fields_ = [("n_vars", ctypes.c_size_t), ("n_primary", ctypes.c_size_t), ("domain_size", ctypes.c_size_t)] + [
+        (k, ctypes.c_void_p) for k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2",
+                                       "a_query", "b_g2_query", "b_g1_query", "h_query", "l_query")]
 
 
 _lib = None
@@ -52,6 +65,16 @@ def load():
     lib.zkhip_fixed_base_mul_dev.argtypes = [c_u64p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     lib.zkhip_ntt.argtypes = [c_u64p, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
     lib.zkhip_ntt_dev.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
+    lib.zkhip_r1cs_upload.argtypes = [ctypes.POINTER(R1csDesc), ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_r1cs_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_r1cs_log_domain.argtypes = [ctypes.c_void_p]
+    lib.zkhip_r1cs_log_domain.restype = ctypes.c_uint
+    lib.zkhip_r1cs_is_satisfied.argtypes = [ctypes.c_void_p, c_u64p, ctypes.POINTER(ctypes.c_int)]
+    lib.zkhip_qap_h.argtypes = [ctypes.c_void_p, c_u64p, c_u64p]
+    lib.zkhip_crs_upload.argtypes = [ctypes.POINTER(CrsDesc), ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_crs_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_groth16_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
+    lib.zkhip_last_prove_timings.argtypes = [ctypes.POINTER(ctypes.c_double)]
     lib.zkhip_last_accumulate_ms.restype = ctypes.c_float
     lib.zkhip_jac_to_affine.argtypes = [c_u64p, c_u64p]
     lib.zkhip_jac_add.argtypes = [c_u64p, c_u64p, c_u64p]
@@ -149,6 +172,89 @@ def ntt(data, log_d, inverse=False, coset=False):
 
 def ntt_dev(dev_ptr, log_d, inverse=False, coset=False):
     _check(load().zkhip_ntt_dev(ctypes.c_void_p(dev_ptr), log_d, int(inverse), int(coset)))
+
+
+class R1cs:
+    """A constraint system resident in HBM.  A, B, C: CSR triples (row_ptr u32[n+1], col u32[nnz], val u64[nnz, 6])."""
+
+    def __init__(self, A, B, C, n_vars, n_primary):
+        self._keep = []
+        d = R1csDesc()
+        d.n_constraints = len(A[0]) - 1
+        d.n_vars, d.n_primary = n_vars, n_primary
+        for name, (rp, col, val) in zip("abc", (A, B, C)):
+            rp = np.ascontiguousarray(rp, dtype=np.uint32)
+            col = np.ascontiguousarray(col, dtype=np.uint32)
+            val = np.ascontiguousarray(val, dtype=np.uint64).reshape(-1, 6)
+            assert len(rp) == d.n_constraints + 1 and len(col) == len(val) == int(rp[-1])
+            self._keep += [rp, col, val]
+            setattr(d, name + "_row_ptr", rp.ctypes.data)
+            setattr(d, name + "_col", col.ctypes.data if len(col) else None)
+            setattr(d, name + "_val", val.ctypes.data if len(val) else None)
+        self.n_vars, self.n_primary, self.n_constraints = n_vars, n_primary, d.n_constraints
+        h = ctypes.c_void_p()
+        _check(load().zkhip_r1cs_upload(ctypes.byref(d), ctypes.byref(h)))
+        self.handle = h
+        self._keep = []
+        self.log_d = int(load().zkhip_r1cs_log_domain(h))
+
+    def is_satisfied(self, z):
+        zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(self.n_vars, 6)
+        ok = ctypes.c_int(0)
+        _check(load().zkhip_r1cs_is_satisfied(self.handle, _p(zz), ctypes.byref(ok)))
+        return bool(ok.value)
+
+    def qap_h(self, z):
+        zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(self.n_vars, 6)
+        h = np.zeros((1 << self.log_d, 6), dtype=np.uint64)
+        _check(load().zkhip_qap_h(self.handle, _p(zz), _p(h)))
+        return h
+
+    def free(self):
+        if self.handle:
+            load().zkhip_r1cs_free(self.handle)
+            self.handle = None
+
+
+class Crs:
+    """The Groth16 proving key resident in HBM.  pk: dict with alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2
+    (24 limbs) and the query arrays A, B2, B1, H, L (n x 24 limbs)."""
+
+    def __init__(self, pk, n_vars, n_primary, domain_size):
+        d = CrsDesc()
+        d.n_vars, d.n_primary, d.domain_size = n_vars, n_primary, domain_size
+        keep = []
+        for field, key, rows in (("alpha_g1", "alpha_g1", 1), ("beta_g1", "beta_g1", 1), ("beta_g2", "beta_g2", 1),
+                                 ("delta_g1", "delta_g1", 1), ("delta_g2", "delta_g2", 1), ("a_query", "A", n_vars),
+                                 ("b_g2_query", "B2", n_vars), ("b_g1_query", "B1", n_vars), ("h_query", "H", domain_size - 1),
+                                 ("l_query", "L", n_vars - n_primary - 1)):
+            a = np.ascontiguousarray(pk[key], dtype=np.uint64).reshape(-1, 24)
+            assert a.shape[0] == rows, (key, a.shape, rows)
+            keep.append(a)
+            setattr(d, field, a.ctypes.data if a.size else None)
+        h = ctypes.c_void_p()
+        _check(load().zkhip_crs_upload(ctypes.byref(d), ctypes.byref(h)))
+        self.handle = h
+
+    def free(self):
+        if self.handle:
+            load().zkhip_crs_free(self.handle)
+            self.handle = None
+
+
+def groth16_prove(crs, r1cs, z, r, s):
+    """Proof (A in G1, B in G2, C in G1) as 72 limbs, affine.  r, s: Fr in Montgomery form (6 limbs)."""
+    zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(r1cs.n_vars, 6)
+    out = np.zeros(72, dtype=np.uint64)
+    _check(load().zkhip_groth16_prove(crs.handle, r1cs.handle, _p(zz), _p(np.ascontiguousarray(r, dtype=np.uint64)),
+                                      _p(np.ascontiguousarray(s, dtype=np.uint64)), _p(out)))
+    return out
+
+
+def last_prove_timings():
+    t = (ctypes.c_double * 8)()
+    _check(load().zkhip_last_prove_timings(t))
+    return dict(zip(["upload_z", "qap", "msm_A", "msm_B2", "msm_B1", "msm_H", "msm_L", "host_tail"], list(t)))
 
 
 def jac_to_affine(jac):
