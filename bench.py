@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py - G1 MSM over BW6-761 at 2^20 (BASELINE.json config 2) on N GPUs, one process per GPU.
+"""bench.py - the hot path of the Zecale wrapping prover on N MI355X GPUs, one process per GPU.
 
-A "step" is one pass of the hot path over one batch: one 2^20-term G1 multi-scalar multiplication
-(fresh scalars already resident in HBM; base points resident as the proving key is).  For N > 1 the
-path shards by independent units: every rank owns its own 2^20-term slice of a
-N * 2^20-term MSM (weak scaling); the only exchange is an all-gather of the N partial sums
-(288 B each) followed by N-1 group additions on every rank.
+Default workload (BASELINE.json configs[1], the configuration `metric` is quoted on):
+  one G1 multi-scalar multiplication over BW6-761 with 2^20 terms per GPU.
+A "step" is one pass of the hot path over one batch: one MSM with a fresh scalar vector that is
+already resident in HBM; the base points are resident too (they are the proving key, uploaded once:
+reference aggregator_server/aggregator_server.cpp:483-514).  For N > 1 the path shards by
+independent units: rank r owns its own 2^20-term slice of an N * 2^20-term MSM (weak
+scaling); the only exchange is an all-gather of the N partial sums (288 B each) over RCCL and
+N - 1 group additions on every rank (zecale_amd/dist.py).
+
+`--workload prover` times BASELINE configs[2] instead (full Groth16 prover: SpMV + 7 NTT + 5 MSM +
+tail at 2^log_n constraints, synthetic R1CS and proving key of that shape).
 
 Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` and `cpu_baseline`.
 """
@@ -21,13 +27,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOG_N = 20
-ALG_BYTES_PER_TERM = 240          # 192 B affine base + 48 B scalar, each read once
-HBM_PEAK_GBPS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md
-# second (honest) bound: Fq multiplications. 25.2 M mixed additions x (8 M + 2 S) ... see DESIGN.md
-FQ_MUL_PEAK_PER_S = 19.5e9        # measured chip-wide peak of fp_mul (tools/ubench/fqmul_bench.hip)
+ALG_BYTES_PER_TERM = 240      # 192 B affine base + 48 B scalar, each read once
+HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md (spec; 6.29 TB/s measured copy)
+FQ_MUL_PEAK_PER_S = 19.5e9    # chip-wide peak of the Fq Montgomery multiplier, measured (tools/ubench/fqmul_bench.hip)
+MULS_PER_MIXED_ADD = 10       # madd-2008-s: 8 M + 2 S, every one through the same multiplier
 
 
 def random_fr_canonical(seed, n):
+    """n x 6 limbs of canonical scalars < 2^376 < r from a splitmix64 stream."""
     x = (np.arange(1, n * 6 + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)).astype(np.uint64)
     x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
     x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
@@ -37,15 +44,27 @@ def random_fr_canonical(seed, n):
     return a
 
 
-def cpu_baseline(bases_sample, scal_sample):
-    """CPU restatement (oracle/bw6_oracle.c: BDLO12 chunked over OpenMP threads), timed on this host."""
-    from oracle import oracle as O
-    O.load()
-    threads = O.max_threads()
-    t = time.time()
-    out = O.msm(bases_sample, scal_sample, chunks=threads, with_mixed=True)
-    dt = time.time() - t
-    return out, dt, threads
+def g1_generator_limbs():
+    """G1 generator in ABI form (reference client/test_commands/test_bw6_761_groth16_contract.py:28-31)."""
+    q = 0x0122e824fb83ce0ad187c94004faff3eb926186a81d14688528275ef8087be41707ba638e584e91903cebaff25b423048689c8ed12f9fd9071dcd3dc73ebff2e98a116c25667a8f8160cf8aeeaf0a437e6913e6870000082f49d00000000008b
+    gx = 0x01075b020ea190c8b277ce98a477beaee6a0cfb7551b27f0ee05c54b85f56fc779017ffac15520ac11dbfcd294c2e746a17a54ce47729b905bd71fa0c9ea097103758f9a280ca27f6750dd0356133e82055928aca6af603f4088f3af66e5b43d
+    gy = 0x0058b84e0a6fc574e6fd637b45cc2a420f952589884c9ec61a7348d2a2e573a3265909f1af7e0dbac5b8fa1771b5b806cc685d31717a4c55be3fb90b6fc2cdd49f9df141b3053253b2b08119cad0fb93ad1cb2be0b20d2a1bafc8f2db4e95363
+    out = []
+    for v in (gx, gy):
+        m = (v << 768) % q
+        out += [(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(12)]
+    return np.array(out, dtype=np.uint64)
+
+
+def measured_traffic():
+    """HBM bytes per k_accumulate launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("k_accumulate_hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
 
 
 def main():
@@ -54,125 +73,163 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--workload", choices=["msm", "prover"], default="msm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log", type=int, default=17)
     args = ap.parse_args()
 
     import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernels are the only compute path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from zecale_amd import dist as zdist
     from zecale_amd import zkhip
     zkhip.init(local)
     n = 1 << args.log_n
+    g1 = g1_generator_limbs()
 
-    # synthetic inputs (seeded): bases k_i * G1 generated ON the GPU by the product's fixed-base
-    # kernel (k_i from splitmix64), scalars uniform canonical < 2^376, one fresh set per step.
-    g1 = np.array(list(zkhip_g1_generator()), dtype=np.uint64)
-    ks = torch.from_numpy(random_fr_canonical(0x5EED + 1000 * rank, n).view(np.int64)).to(dev)
-    bases_dev = torch.empty((n, 24), dtype=torch.int64, device=dev)
-    zkhip.fixed_base_mul_dev(g1, ks.data_ptr(), n, bases_dev.data_ptr(), montgomery=False)
-    torch.cuda.synchronize()
-    bases = zkhip.Bases.upload_dev(bases_dev.data_ptr(), n)
-    n_sets = args.steps + args.warmup
-    scal_dev = [torch.from_numpy(random_fr_canonical(0xABC0 + 17 * i + 1000 * rank, n).view(np.int64)).to(dev)
-                for i in range(min(n_sets, 4))]
-    torch.cuda.synchronize()
-
-    def step(i):
-        s = scal_dev[i % len(scal_dev)]
-        part = bases.msm_dev(s.data_ptr(), n, montgomery=False)
-        if world > 1:
-            import torch.distributed as dist
-            mine = torch.from_numpy(part.view(np.int64)).to(dev)
-            allp = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allp, mine)
-            acc = allp[0].cpu().numpy().view(np.uint64)
-            for q in allp[1:]:
-                acc = zkhip.jac_add(acc, q.cpu().numpy().view(np.uint64))
-            return acc
-        return part
+    def gen_bases(seed, count):
+        """count points k_i * G1 (k_i from splitmix64), generated ON the GPU by the product's fixed-base kernel."""
+        ks = torch.from_numpy(random_fr_canonical(seed, count).view(np.int64)).to(dev)
+        out = torch.empty((count, 24), dtype=torch.int64, device=dev)
+        zkhip.fixed_base_mul_dev(g1, ks.data_ptr(), count, out.data_ptr(), montgomery=False)
+        torch.cuda.synchronize()
+        return out
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    extra = {}
+    if args.workload == "msm":
+        bases_dev = gen_bases(0x5EED + 1000 * rank, n)
+        bases = zkhip.Bases.upload_dev(bases_dev.data_ptr(), n)
+        scal_dev = [torch.from_numpy(random_fr_canonical(0xABC0 + 17 * i + 1000 * rank, n).view(np.int64)).to(dev)
+                    for i in range(min(args.steps + args.warmup, 4))]
+        torch.cuda.synchronize()
+
+        def step(i):
+            s = scal_dev[i % len(scal_dev)]
+            part = bases.msm_dev(s.data_ptr(), n, montgomery=False)
+            return zdist.combine_partial_sums(part, device=dev) if world > 1 else part
+        units_per_step = n * world
+    else:
+        # synthetic R1CS of the wrapping circuit's shape: n constraints, n + 5 variables, 4 primary inputs, <= 3 terms per row
+        rng = np.random.default_rng(1234 + rank)
+        m, l = n + 5, 4
+        def rand_csr(terms):
+            cols = rng.integers(0, m, size=(n, terms), dtype=np.uint32).reshape(-1)
+            rp = (np.arange(n + 1, dtype=np.uint32) * terms)
+            vals = random_fr_canonical(int(rng.integers(1 << 30)), n * terms)
+            return rp, cols, vals
+        r1 = zkhip.R1cs(rand_csr(2), rand_csr(2), rand_csr(2), m, l)
+        d = 1 << r1.log_d
+        pk = dict(alpha_g1=g1, beta_g1=g1, beta_g2=g1, delta_g1=g1, delta_g2=g1)
+        for key, cnt, seed in (("A", m, 1), ("B2", m, 2), ("B1", m, 3), ("H", d - 1, 4), ("L", m - l - 1, 5)):
+            pk[key] = gen_bases(seed * 7919 + rank, cnt).cpu().numpy().view(np.uint64)
+        crs = zkhip.Crs(pk, m, l, d)
+        del pk
+        # boolean-heavy witness: 60 % of the variables in {0, 1} (Montgomery form), the rest uniform
+        z = random_fr_canonical(99 + rank, m)
+        sel = rng.random(m)
+        one_m = np.array(zkhip_fr_one(), dtype=np.uint64)
+        z[sel < 0.3] = 0
+        z[(sel >= 0.3) & (sel < 0.6)] = one_m
+        z[0] = one_m
+        rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
+
+        def step(i):
+            return zkhip.groth16_prove(crs, r1, z, rr, ss)
+        units_per_step = world
 
     for i in range(args.warmup):
         step(i)
     barrier()
-    acc_ms = []
+    kernel_ms, phase = [], []
     t0 = time.time()
     for i in range(args.steps):
-        res = step(args.warmup + i)
-        acc_ms.append(zkhip.last_accumulate_ms())
+        step(args.warmup + i)
+        kernel_ms.append(zkhip.last_accumulate_ms())
+        if args.workload == "prover":
+            phase.append(zkhip.last_prove_timings())
     barrier()
     dt = time.time() - t0
     if world > 1:
-        import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        total_terms = n * world * args.steps
-        value = total_terms / dt / 1e6
-        kernel_ms = float(np.mean(acc_ms))
-        achieved = ALG_BYTES_PER_TERM * n / (kernel_ms * 1e-3) / 1e9
+        k_ms = float(np.mean(kernel_ms))
+        if args.workload == "msm":
+            value, unit = units_per_step * args.steps / dt / 1e6, "Mscalar/s"
+            metric = "G1-MSM Mscalar/s (BW6_761, 2^%d terms per GPU)" % args.log_n
+            workload = "BASELINE configs[1]: single MI355X G1_BW6_761 Pippenger MSM, 2^%d random scalars/points" % args.log_n
+            terms_in_kernel = n
+        else:
+            value, unit = units_per_step * args.steps / dt, "proofs/s"
+            metric = "wrapping proofs/sec (Groth16 over BW6_761, 2^%d constraints)" % args.log_n
+            workload = ("BASELINE configs[2]: full Groth16 BW6_761 prover (SpMV + 7 NTT + 5 MSM), synthetic R1CS 2^%d constraints, "
+                        "4 primary inputs, random proving key of that shape" % args.log_n)
+            terms_in_kernel = n - 5       # the last MSM of a proof is L
+            extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
+        achieved = ALG_BYTES_PER_TERM * terms_in_kernel / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "G1-MSM Mscalar/s (BW6_761, 2^%d terms per GPU)" % args.log_n,
-            "value": round(value, 3), "unit": "Mscalar/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": round(value, 4), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32x27 (29-bit limbs, 761-bit Montgomery integers)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: single MI355X G1_BW6_761 Pippenger MSM, 2^%d random scalars/points"
-                                   % args.log_n, "terms_per_gpu": n, "window_bits": 16, "bases": "resident (proving key)",
-                       "parallelism": "point-partitioned x%d, all-gather of partial sums" % world},
+            "dtype": "u32 (27 x 29-bit limbs: 761-bit Montgomery integers)", "data": "synthetic",
+            "config": {"workload": workload, "terms_per_gpu": n, "bases": "resident in HBM (proving key)",
+                       "parallelism": "point-partitioned x%d, RCCL all-gather of 288-byte partial sums" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
-                         "kernel": "k_accumulate", "kernel_ms": round(kernel_ms, 3),
-                         "note": "integer-VALU bound, not HBM bound (SURVEY 0.5): see fq_mul_frac",
-                         "fq_mul_frac": round((n * 24 * 9.52) / (kernel_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4)},
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": measured_traffic(),
+                         "kernel": "zkhip::k_accumulate", "kernel_ms": round(k_ms, 3),
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_TERM * terms_in_kernel,
+                         "note": "this path is integer-multiply bound, not HBM bound (SURVEY 0.5): fq_mul_frac = Fq "
+                                 "multiplications per second in the kernel / measured chip peak of the multiplier",
+                         "fq_mul_frac": round(terms_in_kernel * 24 * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4)},
         }
+        out.update(extra)
         if not args.no_cpu_baseline:
-            ns = 1 << min(args.cpu_sample_log, args.log_n)
-            bs = bases_dev[:ns].cpu().numpy().view(np.uint64)
-            ss = scal_dev[0][:ns].cpu().numpy().view(np.uint64)
-            # canonical words used as Montgomery residues on both sides: same MSM instance for CPU and GPU
-            cpu_out, cpu_dt, threads = cpu_baseline(bs, ss)
-            b2 = zkhip.Bases.upload(bs)
-            gpu_out = b2.msm(ss, montgomery=True)
             from oracle import oracle as O
-            parity = bool((zkhip.jac_to_affine(gpu_out) == O.jac_to_affine(cpu_out)).all())
-            out["cpu_baseline"] = {"value": round(ns / cpu_dt / 1e6, 5), "unit": "Mscalar/s", "cores": threads, "kind": "port",
-                                   "sample": "one 2^%d-term G1 MSM (same generator), CPU restatement of libff multi_exp "
-                                             "(BDLO12, OpenMP chunks), %.1f s; not libsnark itself" % (ns.bit_length() - 1, cpu_dt),
-                                   "parity_with_gpu_on_sample": parity}
+            O.load()
+            ns = 1 << min(args.cpu_sample_log, args.log_n)
+            bs = gen_bases(0x5EED, ns).cpu().numpy().view(np.uint64)
+            ss_ = random_fr_canonical(0xABC0, ns)
+            threads = O.max_threads()
+            t = time.time()
+            cpu_out = O.msm(bs, ss_, chunks=threads, with_mixed=True)   # canonical words used as Montgomery residues on both sides
+            cpu_dt = time.time() - t
+            b2 = zkhip.Bases.upload(bs)
+            parity = bool((zkhip.jac_to_affine(b2.msm(ss_, montgomery=True)) == O.jac_to_affine(cpu_out)).all())
+            b2.free()
+            cpu_val = ns / cpu_dt / 1e6
+            out["cpu_baseline"] = {
+                "value": round(cpu_val if args.workload == "msm" else cpu_val * 1e6 / (5.0 * n), 6), "unit": unit, "cores": threads, "kind": "port",
+                "sample": "one 2^%d-term G1 MSM, CPU restatement of libff multi_exp (BDLO12, %d OpenMP chunks, -O2), %.1f s; "
+                          "not libsnark itself (its sources are absent from the reference tree)%s"
+                          % (ns.bit_length() - 1, threads, cpu_dt,
+                             "" if args.workload == "msm" else "; proofs/s extrapolated as 5 MSMs of 2^%d terms per proof" % args.log_n),
+                "parity_with_gpu_on_sample": parity}
         print(json.dumps(out))
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 
-def zkhip_g1_generator():
-    """G1 generator in ABI form (reference client/test_commands/test_bw6_761_groth16_contract.py:28-31)."""
-    q = 0x0122e824fb83ce0ad187c94004faff3eb926186a81d14688528275ef8087be41707ba638e584e91903cebaff25b423048689c8ed12f9fd9071dcd3dc73ebff2e98a116c25667a8f8160cf8aeeaf0a437e6913e6870000082f49d00000000008b
-    gx = 0x01075b020ea190c8b277ce98a477beaee6a0cfb7551b27f0ee05c54b85f56fc779017ffac15520ac11dbfcd294c2e746a17a54ce47729b905bd71fa0c9ea097103758f9a280ca27f6750dd0356133e82055928aca6af603f4088f3af66e5b43d
-    gy = 0x0058b84e0a6fc574e6fd637b45cc2a420f952589884c9ec61a7348d2a2e573a3265909f1af7e0dbac5b8fa1771b5b806cc685d31717a4c55be3fb90b6fc2cdd49f9df141b3053253b2b08119cad0fb93ad1cb2be0b20d2a1bafc8f2db4e95363
-    for v in (gx, gy):
-        m = (v << 768) % q
-        for i in range(12):
-            yield (m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+def zkhip_fr_one():
+    r = 0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001
+    m = (1 << 384) % r
+    return [(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]
 
 
 if __name__ == "__main__":

@@ -1,0 +1,40 @@
+"""Multi-GPU exchange for the point-partitioned MSM: every rank owns a slice of the base
+points and of the scalar vector, computes its partial sum with the HIP MSM, and the ranks exchange
+ONLY the partial sums (one Jacobian point, 288 bytes, per MSM).  Group addition is not a reduction
+operator RCCL knows, so the "all-reduce" is an all-gather of the 288-byte points followed by the same
+rank-ordered additions on every rank (exact arithmetic: every rank ends with identical limbs).
+One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" for CPU tests)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import zkhip
+
+
+def partition(n, world, rank):
+    """Contiguous slice [lo, hi) of n items owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def combine_partial_sums(part_jac, group=None, device=None):
+    """part_jac: this rank's partial sum(s), uint64 array of shape (36,) or (k, 36).  Returns the sum over
+    all ranks with the same shape.  Collective: every rank must call it."""
+    p = np.ascontiguousarray(part_jac, dtype=np.uint64)
+    shape = p.shape
+    p2 = p.reshape(-1, 36)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return p.copy()
+    world = dist.get_world_size(group)
+    mine = torch.from_numpy(p2.view(np.int64).copy())
+    if device is not None:
+        mine = mine.to(device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    parts = [g.cpu().numpy().view(np.uint64) for g in gathered]
+    out = parts[0].copy()
+    for q in parts[1:]:
+        for k in range(out.shape[0]):
+            out[k] = zkhip.jac_add(out[k], q[k])
+    return out.reshape(shape)
