@@ -126,6 +126,7 @@ def main():
     else:
         # synthetic R1CS of the wrapping circuit's shape: n constraints, n + 5 variables, 4 primary inputs, <= 3 terms per row
         rng = np.random.default_rng(1234 + rank)
+        n = n - 8                    # n + l + 1 <= 2^log_n: the QAP domain (and the H query) has exactly 2^log_n points
         m, l = n + 5, 4
         def rand_csr(terms):
             cols = rng.integers(0, m, size=(n, terms), dtype=np.uint32).reshape(-1)

@@ -143,6 +143,68 @@ __device__ __forceinline__ bool madd_mem(const XyzzRef& acc, const AffPacked* p,
   return same_x;
 }
 
+// ---- LDS-staged variant for the bucket accumulation --------------------------------------------
+// ZZ and ZZZ of the lane's current accumulator live in LDS for the whole run of additions into one
+// bucket ([27][256] images, word k of lane t at base[k*256 + t]: conflict-free); X and Y stay in the
+// memory slot.  That halves the accumulator traffic per addition (4 of the 8 coordinate loads and 2 of the
+// 4 stores never leave the CU) and removes four global-memory round trips from the critical path.
+#define ZK_LDS_STRIDE 256
+__device__ __forceinline__ Fq lds_ld(const uint32_t* base) {
+  Fq v;
+#pragma unroll
+  for (int i = 0; i < 27; i++) v.l[i] = base[i * ZK_LDS_STRIDE];
+  return v;
+}
+__device__ __forceinline__ void lds_st(uint32_t* base, const Fq& v) {
+#pragma unroll
+  for (int i = 0; i < 27; i++) base[i * ZK_LDS_STRIDE] = v.l[i];
+}
+
+// acc (X, Y in memory; ZZ, ZZZ in LDS; finite) += p.  Returns true if the rare same-x path ran
+// (the accumulator was then completed through memory and ZZ/ZZZ reloaded).
+__device__ __forceinline__ bool madd_mem_lds(const XyzzRef& acc, uint32_t* zz, uint32_t* zzz, const AffPacked* p, bool neg) {
+  Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
+  bool same_x = false;
+#pragma unroll 1
+  for (int step = 0; step < 10; step++) {
+    Fq a, b;
+    switch (step) {
+      case 0: a = aff_ld_x(p); b = lds_ld(zz); break;                // U2 = x2 ZZ1
+      case 1: a = aff_ld_y(p, neg); b = lds_ld(zzz); break;          // S2 = y2 ZZZ1
+      case 2: a = T0; b = T0; break;                                 // PP = P^2
+      case 3: a = T0; b = T2; break;                                 // PPP = P PP
+      case 4: a = lds_ld(zz); b = T2; break;                         // ZZ3 = ZZ1 PP
+      case 5: a = lds_ld(zzz); b = T3; break;                        // ZZZ3 = ZZZ1 PPP
+      case 6: a = mem_ld(acc, CX); b = T2; break;                    // Q = X1 PP
+      case 7: a = T1; b = T1; break;                                 // RR = R^2
+      case 8: a = T1; b = fp_sub<FqParams, 16>(T0, T2); break;       // Y3a = R (Q - X3)
+      default: a = mem_ld(acc, CY); b = T3; break;                   // Y3b = Y1 PPP
+    }
+    Fq r = fp_mul(a, b);
+    switch (step) {
+      case 0: T0 = fp_sub<FqParams, 16>(r, mem_ld(acc, CX)); break;  // P  [18]
+      case 1: T1 = fp_sub<FqParams, 4>(r, mem_ld(acc, CY)); break;   // R  [6]
+      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
+      case 3: T3 = r; break;                                         // PPP
+      case 4: lds_st(zz, r); break;
+      case 5: lds_st(zzz, r); break;
+      case 6: T0 = r; break;                                         // Q
+      case 7: T2 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T3), fp_dbl(T0)); mem_st(acc, CX, T2); break;   // X3 [10]
+      case 8: T0 = r; break;                                         // Y3a
+      default: mem_st(acc, CY, fp_sub<FqParams, 2>(T0, r)); break;   // Y3 [4]
+    }
+    if (same_x) break;
+  }
+  if (same_x) {
+    mem_st(acc, CZZ, lds_ld(zz));
+    mem_st(acc, CZZZ, lds_ld(zzz));
+    madd_same_x(acc, p, neg);
+    lds_st(zz, mem_ld(acc, CZZ));
+    lds_st(zzz, mem_ld(acc, CZZZ));
+  }
+  return same_x;
+}
+
 // a (memory) += b (memory); both may be infinite.  a is updated in place; b is not written.
 __device__ __forceinline__ void add_mem(const XyzzRef& A, const XyzzRef& B) {
   if (mem_is_inf(B)) return;

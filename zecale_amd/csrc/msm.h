@@ -28,9 +28,9 @@ struct MsmCtx {
 
 int msm_plan_init(MsmCtx* ctx, size_t max_n, int c);
 void msm_plan_free(MsmCtx* ctx);
-int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPacked* d_out);
-int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, size_t n, int scalars_montgomery,
-            uint64_t out_jac[36]);
+int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags);
+int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
+            int scalars_montgomery, uint64_t out_jac[36]);
 
 int fixed_base_mul(const uint64_t base_aff[24], const uint64_t* d_scalars, size_t n, int montgomery, uint64_t* d_out,
                    char* errbuf, size_t errlen);

@@ -30,7 +30,8 @@ namespace zkhip {
 // ------------------------------------------------------------------------------------------
 
 // one thread per point: 24 u64 (x, y in ABI Montgomery form; all-zero = infinity) -> AffPacked
-__global__ void __launch_bounds__(256) k_bases_to_dev(const uint64_t* __restrict__ in, AffPacked* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(256) k_bases_to_dev(const uint64_t* __restrict__ in, AffPacked* __restrict__ out,
+                                                       uint8_t* __restrict__ inf_flags /* may be null */, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t x[12], y[12];
@@ -48,6 +49,7 @@ __global__ void __launch_bounds__(256) k_bases_to_dev(const uint64_t* __restrict
     fp_pack32<FqParams>(fy, p.y);
   }
   out[i] = p;
+  if (inf_flags) inf_flags[i] = (nz == 0) ? 1 : 0;
 }
 
 // Window layout: W windows tile exactly 378 bits (scalars < r < 2^377, plus one bit for the
@@ -62,10 +64,12 @@ struct WindowPlan {
 // one thread per scalar.  digits[w*n + i] = signed digit of window w (|d| <= 2^(bits_w - 1));
 // counts[w*B + |d|-1] += 1 for d != 0   (B = 2^(c-1) bucket slots per window).
 __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restrict__ scalars, size_t n, int c, int W,
-                                                        WindowPlan plan, int montgomery, int32_t* __restrict__ digits,
-                                                        uint32_t* __restrict__ counts) {
+                                                        WindowPlan plan, int montgomery, const uint8_t* __restrict__ inf_flags,
+                                                        int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;
+  if (!live) i = n - 1;                    // keep whole waves in the loop: the hot-bucket atomics are wave-aggregated
+  const bool skip = !live || (inf_flags && inf_flags[i]);   // a base at infinity contributes nothing: drop it here
   uint64_t s[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) s[k] = scalars[i * 6 + k];
@@ -93,8 +97,16 @@ __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restric
     int32_t sd;
     if (d > (1u << (cw - 1))) { sd = (int32_t)d - (int32_t)(1u << cw); carry = 1; }
     else { sd = (int32_t)d; carry = 0; }
-    digits[(size_t)w * n + i] = sd;
-    if (sd != 0) {
+    if (skip) sd = 0;
+    if (live) digits[(size_t)w * n + i] = sd;
+    // "scalar == 1" (boolean-heavy witnesses) puts a third of all points into bucket (window 0, digit 1):
+    // one atomic per wave for that bucket instead of one per lane.
+    const bool hot = (w == 0) && (sd == 1);
+    const unsigned long long hot_mask = __ballot(hot);
+    if (hot_mask) {
+      if (hot && (__ffsll((long long)hot_mask) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&counts[0], (uint32_t)__popcll(hot_mask));
+    }
+    if (sd != 0 && !hot) {
       uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
       atomicAdd(&counts[(size_t)w * B + (mag - 1)], 1u);
     }
@@ -158,11 +170,22 @@ __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ dig
                                                   const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                                                   uint32_t* __restrict__ entries) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;
+  if (!live) i = n - 1;
   const uint32_t B = 1u << (c - 1);
+  const uint32_t lane = threadIdx.x & 63;
   for (int w = 0; w < W; w++) {
-    int32_t sd = digits[(size_t)w * n + i];
-    if (sd == 0) continue;
+    int32_t sd = live ? digits[(size_t)w * n + i] : 0;
+    const bool hot = (w == 0) && (sd == 1);            // wave-aggregated slot allocation for the hot bucket
+    const unsigned long long hot_mask = __ballot(hot);
+    if (hot_mask) {
+      const int leader = __ffsll((long long)hot_mask) - 1;
+      uint32_t base = 0;
+      if ((int)lane == leader) base = atomicAdd(&cursor[0], (uint32_t)__popcll(hot_mask));
+      base = __shfl(base, leader);
+      if (hot) entries[offsets[0] + base + (uint32_t)__popcll(hot_mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    }
+    if (sd == 0 || hot) continue;
     uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
     size_t b = (size_t)w * B + (mag - 1);
     uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
@@ -205,11 +228,18 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restri
   }
   uint32_t bend = pos0;            // forces the run set-up on the first iteration
   bool first = true;
+  __shared__ uint32_t lds_zz[27 * ZK_LDS_STRIDE], lds_zzz[27 * ZK_LDS_STRIDE];   // 2 x 27 KiB per 256-lane block
+  uint32_t* zz = lds_zz + threadIdx.x;
+  uint32_t* zzz = lds_zzz + threadIdx.x;
   XyzzRef acc = make_ref(slots, stride, 0);
   bool inf = true;
   for (uint32_t k = pos0; k < pos1; k++) {
     if (k == bend) {
-      if (!first) { b++; while (offsets[b] + counts[b] <= k) b++; }   // next non-empty bucket
+      if (!first) {
+        if (!inf) { mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz)); }   // close the finished run
+        b++;
+        while (offsets[b] + counts[b] <= k) b++;     // next non-empty bucket
+      }
       first = false;
       bend = offsets[b] + counts[b];
       bool starts = (k == offsets[b]), ends = (bend <= pos1);
@@ -219,18 +249,20 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restri
     }
     uint32_t e = entries[k];
     const AffPacked* p = &bases[e & 0x7fffffffu];
-    bool neg = (e >> 31) != 0;
-    if (aff_is_inf(p)) continue;
+    bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_scalar_digits drops them)
     if (inf) {
       mem_st(acc, CX, aff_ld_x(p));
       mem_st(acc, CY, aff_ld_y(p, neg));
-      mem_st(acc, CZZ, fp_one<FqParams>());
-      mem_st(acc, CZZZ, fp_one<FqParams>());
+      lds_st(zz, fp_one<FqParams>());
+      lds_st(zzz, fp_one<FqParams>());
       inf = false;
       continue;
     }
-    if (madd_mem(acc, p, neg)) inf = mem_is_inf(acc);   // same-x path may have cancelled to infinity
+    if (madd_mem_lds(acc, zz, zzz, p, neg)) inf = fp_is_zero_2p(lds_ld(zz));   // same-x path may have cancelled to infinity
   }
+  if (!inf) { mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz)); }
+  // a run that cancelled to infinity leaves ZZ = 0 in its slot: madd_same_x wrote the zeros, or the slot
+  // was never written (zero-filled array)
 }
 
 // Stitch buckets that were cut by slice boundaries.  A bucket that starts in slice t0 and ends in
@@ -483,16 +515,16 @@ void msm_plan_free(MsmCtx* ctx) {
   memset(ctx, 0, sizeof *ctx);
 }
 
-int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPacked* d_out) {
-  hipLaunchKernelGGL(k_bases_to_dev, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_bases_abi, d_out, n);
+int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags) {
+  hipLaunchKernelGGL(k_bases_to_dev, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_bases_abi, d_out, d_inf_flags, n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return ZKHIP_OK;
 }
 
 // d_bases: packed device-form points; d_scalars: n x 6 u64 (device memory).  Result: Jacobian, ABI form (host).
-int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, size_t n, int scalars_montgomery,
-            uint64_t out_jac[36]) {
+int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
+            int scalars_montgomery, uint64_t out_jac[36]) {
   using namespace host;
   if (n > ctx->max_n) return ZKHIP_ERR_ARG;
   const int c = ctx->c, W = ctx->W;
@@ -509,7 +541,7 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint64_t* d_scalars, si
   memset(&plan, 0, sizeof plan);
   for (int w = 0; w < W; w++) { plan.off[w] = ctx->win_off[w]; plan.bits[w] = ctx->win_bits[w]; }
   hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(n, 256)), dim3(256), 0, st, d_scalars, n, c, W, plan, scalars_montgomery,
-                     ctx->digits, ctx->counts);
+                     d_inf_flags, ctx->digits, ctx->counts);
   unsigned sb = nblk(nb, 1024);
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->counts, ctx->offsets, ctx->block_tot, nb);
   hipLaunchKernelGGL(k_scan_tot, dim3(1), dim3(1024), 0, st, ctx->block_tot, (size_t)sb);
@@ -630,7 +662,7 @@ int fixed_base_mul(const uint64_t base_aff[24], const uint64_t* d_scalars, size_
     if ((e = hipMalloc(&d_tab, (size_t)95 * 15 * sizeof(AffPacked))) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
     if ((e = hipMalloc(&d_work, n * 108 * 4)) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
     if ((e = hipMemcpy(d_tab_abi, tab.data(), tab.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
-    hipLaunchKernelGGL(k_bases_to_dev, dim3(nblk(95 * 15, 256)), dim3(256), 0, 0, d_tab_abi, d_tab, (size_t)95 * 15);
+    hipLaunchKernelGGL(k_bases_to_dev, dim3(nblk(95 * 15, 256)), dim3(256), 0, 0, d_tab_abi, d_tab, (uint8_t*)nullptr, (size_t)95 * 15);
     hipLaunchKernelGGL(k_fixed_base_mul, dim3(nblk(n, 256)), dim3(256), 0, 0, d_tab, d_scalars, n, montgomery, d_work, d_out);
     if ((e = hipGetLastError()) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
     if ((e = hipDeviceSynchronize()) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }

@@ -15,6 +15,7 @@ using namespace zkhip;
 
 struct zkhip_bases {
   AffPacked* d_pts;
+  uint8_t* d_inf;    // 1 where the base is the point at infinity
   size_t len;
 };
 
@@ -121,12 +122,13 @@ int zkhip_bases_upload_dev(const void* d_bases_affine, size_t len, zkhip_bases**
   std::lock_guard<std::mutex> lk(g.mu);
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!out || (len && !d_bases_affine)) return fail(ZKHIP_ERR_ARG, "null pointer");
-  zkhip_bases* b = new zkhip_bases{nullptr, len};
+  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len};
   if (len) {
     API_HIP(hipMalloc(&b->d_pts, len * sizeof(AffPacked)));
+    API_HIP(hipMalloc(&b->d_inf, len));
     int rc = ensure_msm(len);
     if (rc != ZKHIP_OK) return rc;
-    rc = msm_bases_convert(&g.msm, (const uint64_t*)d_bases_affine, len, b->d_pts);
+    rc = msm_bases_convert(&g.msm, (const uint64_t*)d_bases_affine, len, b->d_pts, b->d_inf);
     if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", g.msm.errbuf); return rc; }
   }
   *out = b;
@@ -151,6 +153,7 @@ size_t zkhip_bases_len(const zkhip_bases* b) { return b ? b->len : 0; }
 void zkhip_bases_free(zkhip_bases* b) {
   if (!b) return;
   if (b->d_pts) (void)hipFree(b->d_pts);
+  if (b->d_inf) (void)hipFree(b->d_inf);
   delete b;
 }
 
@@ -162,7 +165,8 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
   int rc = ensure_msm(len ? len : 1);
   if (rc != ZKHIP_OK) return rc;
-  rc = msm_run(&g.msm, bases->d_pts + offset, (const uint64_t*)d_scalars, len, scalars_montgomery, out_jac);
+  rc = msm_run(&g.msm, bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
+               scalars_montgomery, out_jac);
   if (rc != ZKHIP_OK) snprintf(g.err, sizeof g.err, "%s", g.msm.errbuf);
   return rc;
 }
@@ -347,7 +351,7 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
       {crs->H, (const uint64_t*)rd->bufA, d - 1, 2, evH}, {crs->L, dz + (l + 1) * 6, m - l - 1, 1, evL}};
   for (int j = 0; j < 5; j++) {
     t0 = clk::now();
-    rc = msm_run(&g.msm, jobs[j].b->d_pts, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].out);
+    rc = msm_run(&g.msm, jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].out);
     g_prove_ms[2 + j] = ms_since(t0);
     if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", g.msm.errbuf); (void)hipFree(dz); return rc; }
   }
