@@ -285,4 +285,135 @@ __device__ __forceinline__ void dbl_mem(const XyzzRef& A) {
   }
 }
 
+
+// ================================================================================================
+// Quad-cooperative point operations for the latency-bound kernels (bucket reduction, stitching).
+// One lane needs ~6 us per Fq multiplication whatever the occupancy, and a full addition is a chain
+// of 14 of them; the reduction levels have far fewer additions than the chip has lanes.  So FOUR
+// lanes (a DPP quad) execute one addition: the formula's independent products run side by side
+// (4 + 4 + 3 + 3 products in 4 rounds instead of 14 in sequence), operands travel between the lanes
+// of a quad with DPP quad_perm moves.  Every lane of a quad is given the SAME operands; lane q of the
+// quad performs the q-th product of each round.  Results are written by the lane that computed them.
+// ================================================================================================
+template <int Q>
+__device__ __forceinline__ Fq quad_bcast(const Fq& v) {
+  Fq r;
+  constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);   // quad_perm: [Q, Q, Q, Q]
+#pragma unroll
+  for (int i = 0; i < 27; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], ctrl, 0xf, 0xf, true);
+  return r;
+}
+__device__ __forceinline__ Fq fq_sel(bool c, const Fq& a, const Fq& b) {
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 27; i++) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+// coordinate chosen per lane (the row base goes into the lane offset instead of the scalar offset)
+__device__ __forceinline__ Fq mem_ld_lane(const XyzzRef& r, uint32_t c) {
+  Fq v;
+  uint32_t vo = r.voff + c * 27u * r.stride_b;
+#pragma unroll
+  for (int i = 0; i < 27; i++) v.l[i] = __builtin_amdgcn_raw_buffer_load_b32(r.rs, vo, (uint32_t)i * r.stride_b, 0);
+  return v;
+}
+
+__device__ __forceinline__ void mem_st_lane(const XyzzRef& r, uint32_t c, const Fq& v) {
+  uint32_t vo = r.voff + c * 27u * r.stride_b;
+#pragma unroll
+  for (int i = 0; i < 27; i++) __builtin_amdgcn_raw_buffer_store_b32(v.l[i], r.rs, vo, (uint32_t)i * r.stride_b, 0);
+}
+
+// A += B, executed by the four lanes of a quad (all four pass the same A and B).
+__device__ __forceinline__ void add_mem_quad(const XyzzRef& A, const XyzzRef& B, uint32_t q) {
+  if (mem_is_inf(B)) return;
+  if (mem_is_inf(A)) { mem_st_lane(A, q, mem_ld_lane(B, q)); return; }   // lane q copies coordinate q
+  // round 1: q0 U1 = X1 ZZ2, q1 U2 = X2 ZZ1, q2 S1 = Y1 ZZZ2, q3 S2 = Y2 ZZZ1
+  // round 2: q0 PP = P^2,    q1 RR = R^2,     q2 zz = ZZ1 ZZ2,  q3 zzz = ZZZ1 ZZZ2
+  // round 3: q0 PPP = P PP,  q1 Q = U1 PP,    q2 ZZ3 = zz PP,   q3 -
+  // round 4: q0 Y3b = S1 PPP, q1 Y3a = R (Q - X3), q2 -,        q3 ZZZ3 = zzz PPP
+  Fq U1 = fp_zero<FqParams>(), P = U1, R = U1, S1 = U1, PP = U1, PPP = U1, keep = U1;   // keep: RR (q1), zz (q2), zzz (q3)
+  Fq Qv = U1;
+  bool same_x = false;
+#pragma unroll 1
+  for (int round = 0; round < 4; round++) {
+    Fq a, b;
+    if (round == 0) {
+      const bool odd = (q & 1u) != 0;                       // q1, q3 take the first factor from B
+      a = odd ? mem_ld_lane(B, q == 1 ? CX : CY) : mem_ld_lane(A, q == 0 ? CX : CY);
+      b = odd ? mem_ld_lane(A, q == 1 ? CZZ : CZZZ) : mem_ld_lane(B, q == 0 ? CZZ : CZZZ);
+    } else if (round == 1) {
+      a = (q == 0) ? P : (q == 1) ? R : mem_ld_lane(A, q == 2 ? CZZ : CZZZ);
+      b = (q == 0) ? P : (q == 1) ? R : mem_ld_lane(B, q == 2 ? CZZ : CZZZ);
+    } else if (round == 2) {
+      a = (q == 0) ? P : (q == 1) ? U1 : keep;              // q3: idle product (result unused)
+      b = PP;
+    } else {
+      a = (q == 0) ? S1 : (q == 1) ? R : keep;
+      b = (q == 1) ? fp_sub<FqParams, 16>(Qv, P /* holds X3 on q1 */) : PPP;
+    }
+    Fq r = fp_mul(a, b);
+    if (round == 0) {
+      Fq u1 = quad_bcast<0>(r), u2 = quad_bcast<1>(r), s1 = quad_bcast<2>(r), s2 = quad_bcast<3>(r);
+      U1 = u1; S1 = s1;
+      P = fp_sub<FqParams, 2>(u2, u1);                      // [4]
+      R = fp_sub<FqParams, 2>(s2, s1);                      // [4]
+    } else if (round == 1) {
+      keep = r;                                             // q1: RR, q2: zz, q3: zzz
+      PP = quad_bcast<0>(r);
+      same_x = fp_is_zero_2p(PP);
+    } else if (round == 2) {
+      PPP = quad_bcast<0>(r);
+      Qv = r;                                               // meaningful on q1 (Q)
+      if (q == 2) mem_st(A, CZZ, r);                        // ZZ3
+      // X3 = RR - PPP - 2Q on q1 (RR is its `keep`); parked in P, which q1 no longer needs
+      if (q == 1) { P = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(keep, PPP), fp_dbl(Qv)); mem_st(A, CX, P); }
+    } else {
+      Fq y3b = quad_bcast<0>(r);
+      if (q == 1) mem_st(A, CY, fp_sub<FqParams, 2>(r, y3b));   // Y3 [4]
+      if (q == 3) mem_st(A, CZZZ, r);                       // ZZZ3
+    }
+    if (same_x) break;
+  }
+  if (same_x && q == 0) add_same_x(A, B);
+}
+
+// A = 2 A by a quad.
+__device__ __forceinline__ void dbl_mem_quad(const XyzzRef& A, uint32_t q) {
+  if (mem_is_inf(A)) return;
+  // round 1: q0 V = U^2 (U = 2 Y1), q1 xx = X1^2
+  // round 2: q0 W = U V, q1 S = X1 V, q2 ZZ3 = V ZZ1, q3 MM = M^2 (M = 3 xx)
+  // round 3: q0 ZZZ3 = W ZZZ1, q1 wy = W Y1, q3 Y3a = M (S - X3), X3 = MM - 2 S
+  Fq V = fp_zero<FqParams>(), M = V, keep = V, W = V, S = V;
+#pragma unroll 1
+  for (int round = 0; round < 3; round++) {
+    Fq a, b;
+    if (round == 0) {
+      a = (q == 0) ? fp_dbl(mem_ld(A, CY)) : mem_ld(A, CX);          // q2, q3: idle
+      b = a;
+    } else if (round == 1) {
+      a = (q == 0) ? fp_dbl(mem_ld(A, CY)) : (q == 1) ? mem_ld(A, CX) : (q == 2) ? mem_ld(A, CZZ) : M;
+      b = (q == 3) ? M : V;
+    } else {
+      a = (q == 0) ? mem_ld(A, CZZZ) : (q == 1) ? mem_ld(A, CY) : M;
+      b = (q == 3) ? fp_sub<FqParams, 8>(S, keep /* X3 on q3 */) : W;
+    }
+    Fq r = fp_mul(a, b);
+    if (round == 0) {
+      V = quad_bcast<0>(r);
+      Fq xx = quad_bcast<1>(r);
+      M = fp_add(fp_dbl(xx), xx);                                     // [6]
+    } else if (round == 1) {
+      W = quad_bcast<0>(r);
+      S = quad_bcast<1>(r);
+      if (q == 2) mem_st(A, CZZ, r);                                  // ZZ3
+      if (q == 3) { keep = fp_sub<FqParams, 4>(r, fp_dbl(S)); }       // X3 = MM - 2S [6]
+    } else {
+      Fq wy = quad_bcast<1>(r);
+      if (q == 0) mem_st(A, CZZZ, r);
+      if (q == 3) { mem_st(A, CY, fp_sub<FqParams, 2>(r, wy)); mem_st(A, CX, keep); }
+    }
+  }
+}
+
 }  // namespace zkhip

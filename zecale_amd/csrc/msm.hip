@@ -265,17 +265,34 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restri
   // was never written (zero-filled array)
 }
 
+// Point operations on memory accumulators executed by one lane (QUAD = false: throughput-bound
+// launches with at least as many additions as lanes) or by a DPP quad (QUAD = true: latency-bound
+// launches; see ec_mem.cuh).  In quad mode all four lanes of a quad receive the same references.
+template <bool QUAD> __device__ __forceinline__ void pt_add(const XyzzRef& a, const XyzzRef& b, uint32_t q) {
+  if constexpr (QUAD) add_mem_quad(a, b, q); else add_mem(a, b);
+}
+template <bool QUAD> __device__ __forceinline__ void pt_dbl(const XyzzRef& a, uint32_t q) {
+  if constexpr (QUAD) dbl_mem_quad(a, q); else dbl_mem(a);
+}
+template <bool QUAD> __device__ __forceinline__ void pt_copy(const XyzzRef& dst, const XyzzRef& src, uint32_t q) {
+  if constexpr (QUAD) mem_st_lane(dst, q, mem_ld_lane(src, q)); else mem_copy(dst, src);
+}
+template <bool QUAD> __device__ __forceinline__ void pt_set_inf(const XyzzRef& dst, uint32_t q) {
+  if constexpr (QUAD) mem_st_lane(dst, q, fp_zero<FqParams>()); else mem_set_inf(dst);
+}
+
 // Stitch buckets that were cut by slice boundaries.  A bucket that starts in slice t0 and ends in
 // slice t1 > t0 has pieces L[t0], F[t0+1], ..., F[t1].  k_fixup_round(d), d = 1, 2, 4, ... folds the
 // F pieces pairwise (F[t] += F[t+d] for t - (t0+1) divisible by 2d), so a bucket of any
 // population - e.g. "scalar == 1" in a boolean-heavy witness - is stitched in log2(pieces) steps;
 // rounds beyond the largest span exit at once (max_span is written by k_accumulate).
+template <bool QUAD>
 __global__ void __launch_bounds__(256, 2) k_fixup_round(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                          uint32_t nb, uint32_t S, uint32_t T, uint32_t d,
                                                          const uint32_t* __restrict__ max_span, uint32_t* __restrict__ slots,
                                                          uint32_t stride) {
   if (d >= *max_span) return;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt, q = gt & 3u;   // one lane or one quad per slice
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
   uint32_t pos0 = t * S;
   if (t >= T || pos0 >= M) return;
@@ -283,13 +300,13 @@ __global__ void __launch_bounds__(256, 2) k_fixup_round(const uint32_t* __restri
   if (offsets[b] >= pos0) return;                       // slice does not start inside a bucket
   uint32_t tF0 = offsets[b] / S + 1, tF1 = (offsets[b] + counts[b] - 1) / S;
   if ((t - tF0) % (2 * d) != 0 || t + d > tF1) return;
-  add_mem(make_ref(slots, stride, nb + t), make_ref(slots, stride, nb + t + d));
+  pt_add<QUAD>(make_ref(slots, stride, nb + t), make_ref(slots, stride, nb + t + d), q);
 }
 
 // final stitch: the slice in which a cut bucket STARTS owns it: bucket = L[t0] + F[t0+1] (folded).
 __global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                    uint32_t nb, uint32_t S, uint32_t T, uint32_t* __restrict__ slots, uint32_t stride) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // throughput-bound (one addition per slice): one lane each
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
   uint32_t pos0 = t * S;
   if (t >= T || pos0 >= M) return;
@@ -305,29 +322,33 @@ __global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ o
 // Segment pass of the bucket reduction.  in: n_in items (XYZZ limb-major, stride n_in), grouped in
 // runs of L.  For segment t: S_t = sum_u item[tL+u],  R_t = sum_u (u + o) item[tL+u]   (o in {0,1}).
 // The running sums live in the output arrays themselves (memory-resident accumulators).
+template <bool QUAD>
 __global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_t n_in, uint32_t in_stride, int L, int o,
                                                  uint32_t* __restrict__ outS, uint32_t* __restrict__ outR) {
   size_t n_out = n_in / L;
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt;    // one lane / quad per segment
+  const uint32_t q = (uint32_t)(gt & 3);
   if (t >= n_out) return;
   XyzzRef run = make_ref(outS, (uint32_t)n_out, (uint32_t)t), acc = make_ref(outR, (uint32_t)n_out, (uint32_t)t);
-  mem_set_inf(run);
-  mem_set_inf(acc);
+  pt_set_inf<QUAD>(run, q);
+  pt_set_inf<QUAD>(acc, q);
   for (int u = L - 1; u >= 0; u--) {
     XyzzRef it = make_ref(in, in_stride, (uint32_t)(t * L + u));
-    add_mem(run, it);
-    if (u + o > 0) add_mem(acc, run);
+    pt_add<QUAD>(run, it, q);
+    if (u + o > 0) pt_add<QUAD>(acc, run, q);
   }
 }
 
 // out[t] = sum_u in[tL + u]
+template <bool QUAD>
 __global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_t n_in, int L, uint32_t* __restrict__ out) {
   size_t n_out = n_in / L;
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt;    // one lane / quad per output
+  const uint32_t q = (uint32_t)(gt & 3);
   if (t >= n_out) return;
   XyzzRef acc = make_ref(out, (uint32_t)n_out, (uint32_t)t);
-  mem_copy(acc, make_ref(in, (uint32_t)n_in, (uint32_t)(t * L)));
-  for (int u = 1; u < L; u++) add_mem(acc, make_ref(in, (uint32_t)n_in, (uint32_t)(t * L + u)));
+  pt_copy<QUAD>(acc, make_ref(in, (uint32_t)n_in, (uint32_t)(t * L)), q);
+  for (int u = 1; u < L; u++) pt_add<QUAD>(acc, make_ref(in, (uint32_t)n_in, (uint32_t)(t * L + u)), q);
 }
 
 // per window w: out[w] = R[0][w] + L_0 (R[1][w] + L_1 (R[2][w] + ...)).
@@ -336,17 +357,17 @@ __global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_
 struct LevelShifts { uint8_t log_l[32]; };
 __global__ void __launch_bounds__(64, 2) k_window_combine(uint32_t* __restrict__ R_all, int levels, int W, LevelShifts ls,
                                                            uint32_t* __restrict__ work, uint64_t* __restrict__ out_abi /* W x 4 x 12 u64 */) {
-  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  int gt = blockIdx.x * blockDim.x + threadIdx.x, w = gt >> 2;   // one quad per window
+  const uint32_t q = (uint32_t)(gt & 3);
   if (w >= W) return;
   XyzzRef acc = make_ref(work, (uint32_t)W, (uint32_t)w);
-  mem_copy(acc, make_ref(R_all + (size_t)(levels - 1) * 108 * W, (uint32_t)W, (uint32_t)w));
+  mem_st_lane(acc, q, mem_ld_lane(make_ref(R_all + (size_t)(levels - 1) * 108 * W, (uint32_t)W, (uint32_t)w), q));
   for (int k = levels - 2; k >= 0; k--) {
-    for (int d = 0; d < ls.log_l[k]; d++) dbl_mem(acc);
-    add_mem(acc, make_ref(R_all + (size_t)k * 108 * W, (uint32_t)W, (uint32_t)w));
+    for (int d = 0; d < ls.log_l[k]; d++) dbl_mem_quad(acc, q);
+    add_mem_quad(acc, make_ref(R_all + (size_t)k * 108 * W, (uint32_t)W, (uint32_t)w), q);
   }
   uint64_t* o = out_abi + (size_t)w * 48;
-#pragma unroll 1
-  for (int c = 0; c < 4; c++) fp_to_abi<FqParams>(mem_ld(acc, c), o + 12 * c);
+  fp_to_abi<FqParams>(mem_ld_lane(acc, q), o + 12 * q);            // lane q converts coordinate q
 }
 
 // ---- batch fixed-base scalar multiplication: out[i] = k_i * G (the inner loop of Groth16 setup:
@@ -468,6 +489,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c) {
   HIP_TRY(hipStreamCreate(&ctx->stream));
   HIP_TRY(hipStreamCreate(&ctx->stream2));
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&ctx->ev_acc0));
   HIP_TRY(hipEventCreate(&ctx->ev_acc1));
   HIP_TRY(hipMalloc(&ctx->digits, (size_t)ctx->W * max_n * sizeof(int32_t)));
@@ -493,7 +515,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c) {
   // reduction scratch: S ping-pong (<= nb/L each) and R arrays (sum over levels <= nb/L * L/(L-1)), R sums
   HIP_TRY(hipMalloc(&ctx->segS[0], (nb / ctx->L + 1) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->segS[1], (nb / ctx->L + 1) * 108 * 4));
-  HIP_TRY(hipMalloc(&ctx->segR, (nb / ctx->L + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->segR, (nb / 2 + 64 * (size_t)ctx->W) * 108 * 4));   // one R array per level, back to back (sum < nb/3 at L = 4)
   HIP_TRY(hipMalloc(&ctx->sumR[0], (nb / ctx->L / ctx->L + ctx->W + 1) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->sumR[1], (nb / ctx->L / ctx->L + ctx->W + 1) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->Rlevels, (size_t)32 * ctx->W * 108 * 4));
@@ -510,6 +532,7 @@ void msm_plan_free(MsmCtx* ctx) {
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->ev) (void)hipEventDestroy(ctx->ev);
+  if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->ev_acc0) (void)hipEventDestroy(ctx->ev_acc0);
   if (ctx->ev_acc1) (void)hipEventDestroy(ctx->ev_acc1);
   memset(ctx, 0, sizeof *ctx);
@@ -565,19 +588,31 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, c
   hipLaunchKernelGGL(k_accumulate, dim3(nblk(T_run, 256)), dim3(256), 0, st, d_bases, ctx->entries, ctx->offsets, ctx->counts,
                      (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
-  for (uint32_t d = 1; d < T_run; d <<= 1)
-    hipLaunchKernelGGL(k_fixup_round, dim3(nblk(T_run, 256)), dim3(256), 0, st, ctx->offsets, ctx->counts, (uint32_t)nb, S_run, T_run, d,
-                       ctx->block_tot + 0, ctx->buckets, ctx->slot_stride);
+  for (uint32_t d = 1; d < T_run; d <<= 1) {
+    // d = 1 touches up to every slice (throughput-bound: one lane per addition); later rounds only serve
+    // oversized buckets and are latency-bound (a quad per addition)
+    if (d == 1)
+      hipLaunchKernelGGL(k_fixup_round<false>, dim3(nblk(T_run, 256)), dim3(256), 0, st, ctx->offsets, ctx->counts, (uint32_t)nb, S_run, T_run,
+                         d, ctx->block_tot + 0, ctx->buckets, ctx->slot_stride);
+    else
+      hipLaunchKernelGGL(k_fixup_round<true>, dim3(nblk((size_t)T_run * 4, 256)), dim3(256), 0, st, ctx->offsets, ctx->counts, (uint32_t)nb, S_run,
+                         T_run, d, ctx->block_tot + 0, ctx->buckets, ctx->slot_stride);
+  }
   hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, ctx->offsets, ctx->counts, (uint32_t)nb, S_run, T_run,
                      ctx->buckets, ctx->slot_stride);
   HIP_TRY(hipGetLastError());
 
-  // bucket reduction: F(items) = sum_t R_t + L * F0(S), recursively; levels until one item per window
+  // bucket reduction: F(items) = sum_t R_t + L * F0(S), recursively; levels until one item per window.
+  // The k_seg chain (stream 1) produces one R array per level; reducing each R array to one point per
+  // window (k_sum chain) is independent of the later levels and runs on stream 2 behind an event.
   uint32_t* cur = ctx->buckets;
   size_t n_cur = nb;   // W groups of n_cur / W
   int level = 0;
   LevelShifts ls;
   memset(&ls, 0, sizeof ls);
+  const size_t QUAD_BELOW = 65536;   // fewer additions than half the chip's lanes: latency-bound, use quads
+  size_t r_off = 0;                  // this level's R array starts here inside segR (in points)
+  hipStream_t st2 = ctx->stream2;
   while (n_cur > (size_t)W) {
     int L = ctx->L;
     while ((size_t)L > n_cur / W) L >>= 1;      // last level: fewer items per window than L
@@ -585,10 +620,17 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, c
     ls.log_l[level] = (uint8_t)lg;
     size_t n_out = n_cur / L;
     uint32_t* S = ctx->segS[level & 1];
-    hipLaunchKernelGGL(k_seg, dim3(nblk(n_out, 256)), dim3(256), 0, st, cur, n_cur, level == 0 ? ctx->slot_stride : (uint32_t)n_cur, L,
-                       level == 0 ? 1 : 0, S, ctx->segR);
+    uint32_t* Rk = ctx->segR + r_off * 108;
+    if (n_out >= QUAD_BELOW)
+      hipLaunchKernelGGL(k_seg<false>, dim3(nblk(n_out, 256)), dim3(256), 0, st, cur, n_cur, level == 0 ? ctx->slot_stride : (uint32_t)n_cur, L,
+                         level == 0 ? 1 : 0, S, Rk);
+    else
+      hipLaunchKernelGGL(k_seg<true>, dim3(nblk(n_out * 4, 256)), dim3(256), 0, st, cur, n_cur, level == 0 ? ctx->slot_stride : (uint32_t)n_cur, L,
+                         level == 0 ? 1 : 0, S, Rk);
+    HIP_TRY(hipEventRecord(ctx->ev, st));
+    HIP_TRY(hipStreamWaitEvent(st2, ctx->ev, 0));
     // reduce R (n_out items, W groups) to W items: Rlevels[level]
-    uint32_t* rc = ctx->segR;
+    uint32_t* rc = Rk;
     size_t rn = n_out;
     int pp = 0;
     while (rn > (size_t)W) {
@@ -596,16 +638,20 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, c
       while ((size_t)Ls > rn / W) Ls >>= 1;
       size_t ro = rn / Ls;
       uint32_t* dst = (ro == (size_t)W) ? ctx->Rlevels + (size_t)level * 108 * W : ctx->sumR[pp];
-      hipLaunchKernelGGL(k_sum, dim3(nblk(ro, 256)), dim3(256), 0, st, rc, rn, Ls, dst);
+      if (ro >= QUAD_BELOW) hipLaunchKernelGGL(k_sum<false>, dim3(nblk(ro, 256)), dim3(256), 0, st2, rc, rn, Ls, dst);
+      else hipLaunchKernelGGL(k_sum<true>, dim3(nblk(ro * 4, 256)), dim3(256), 0, st2, rc, rn, Ls, dst);
       rc = dst; rn = ro; pp ^= 1;
     }
     if (n_out == (size_t)W) {   // R already one per window
-      HIP_TRY(hipMemcpyAsync(ctx->Rlevels + (size_t)level * 108 * W, ctx->segR, (size_t)108 * W * 4, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ctx->Rlevels + (size_t)level * 108 * W, Rk, (size_t)108 * W * 4, hipMemcpyDeviceToDevice, st2));
     }
+    r_off += n_out;
     cur = S; n_cur = n_out; level++;
   }
+  HIP_TRY(hipEventRecord(ctx->ev2, st2));
+  HIP_TRY(hipStreamWaitEvent(st, ctx->ev2, 0));
   // the last S (one item per window) has weight 0 at its level (o = 0 for level >= 1) and is dropped.
-  hipLaunchKernelGGL(k_window_combine, dim3(nblk(W, 64)), dim3(64), 0, st, ctx->Rlevels, level, W, ls, ctx->sumR[0], ctx->win_abi);
+  hipLaunchKernelGGL(k_window_combine, dim3(nblk((size_t)W * 4, 64)), dim3(64), 0, st, ctx->Rlevels, level, W, ls, ctx->sumR[0], ctx->win_abi);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ctx->win_host, ctx->win_abi, (size_t)W * 48 * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
