@@ -160,9 +160,23 @@ __device__ __forceinline__ void lds_st(uint32_t* base, const Fq& v) {
   for (int i = 0; i < 27; i++) base[i * ZK_LDS_STRIDE] = v.l[i];
 }
 
-// acc (X, Y in memory; ZZ, ZZZ in LDS; finite) += p.  Returns true if the rare same-x path ran
+// X is LDS-staged too, as 24 packed words (the CU's 160 KiB hold 27 + 27 + 24 words for each of 512 lanes)
+__device__ __forceinline__ Fq lds_ld_packed(const uint32_t* base) {
+  uint32_t w[24];
+#pragma unroll
+  for (int i = 0; i < 24; i++) w[i] = base[i * ZK_LDS_STRIDE];
+  return fp_unpack32<FqParams>(w);
+}
+__device__ __forceinline__ void lds_st_packed(uint32_t* base, const Fq& v) {   // v < 2^768, limbs normalised
+  uint32_t w[24];
+  fp_pack32<FqParams>(v, w);
+#pragma unroll
+  for (int i = 0; i < 24; i++) base[i * ZK_LDS_STRIDE] = w[i];
+}
+
+// acc (Y in memory; X (packed), ZZ, ZZZ in LDS; finite) += p.  Returns true if the rare same-x path ran
 // (the accumulator was then completed through memory and ZZ/ZZZ reloaded).
-__device__ __forceinline__ bool madd_mem_lds(const XyzzRef& acc, uint32_t* zz, uint32_t* zzz, const AffPacked* p, bool neg) {
+__device__ __forceinline__ bool madd_mem_lds(const XyzzRef& acc, uint32_t* xs, uint32_t* zz, uint32_t* zzz, const AffPacked* p, bool neg) {
   Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
   bool same_x = false;
 #pragma unroll 1
@@ -175,30 +189,32 @@ __device__ __forceinline__ bool madd_mem_lds(const XyzzRef& acc, uint32_t* zz, u
       case 3: a = T0; b = T2; break;                                 // PPP = P PP
       case 4: a = lds_ld(zz); b = T2; break;                         // ZZ3 = ZZ1 PP
       case 5: a = lds_ld(zzz); b = T3; break;                        // ZZZ3 = ZZZ1 PPP
-      case 6: a = mem_ld(acc, CX); b = T2; break;                    // Q = X1 PP
+      case 6: a = lds_ld_packed(xs); b = T2; break;                  // Q = X1 PP
       case 7: a = T1; b = T1; break;                                 // RR = R^2
       case 8: a = T1; b = fp_sub<FqParams, 16>(T0, T2); break;       // Y3a = R (Q - X3)
       default: a = mem_ld(acc, CY); b = T3; break;                   // Y3b = Y1 PPP
     }
     Fq r = fp_mul(a, b);
     switch (step) {
-      case 0: T0 = fp_sub<FqParams, 16>(r, mem_ld(acc, CX)); break;  // P  [18]
+      case 0: T0 = fp_sub<FqParams, 16>(r, lds_ld_packed(xs)); break; // P  [18]
       case 1: T1 = fp_sub<FqParams, 4>(r, mem_ld(acc, CY)); break;   // R  [6]
       case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
       case 3: T3 = r; break;                                         // PPP
       case 4: lds_st(zz, r); break;
       case 5: lds_st(zzz, r); break;
       case 6: T0 = r; break;                                         // Q
-      case 7: T2 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T3), fp_dbl(T0)); mem_st(acc, CX, T2); break;   // X3 [10]
+      case 7: T2 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T3), fp_dbl(T0)); lds_st_packed(xs, T2); break;   // X3 [10]
       case 8: T0 = r; break;                                         // Y3a
       default: mem_st(acc, CY, fp_sub<FqParams, 2>(T0, r)); break;   // Y3 [4]
     }
     if (same_x) break;
   }
   if (same_x) {
+    mem_st(acc, CX, lds_ld_packed(xs));
     mem_st(acc, CZZ, lds_ld(zz));
     mem_st(acc, CZZZ, lds_ld(zzz));
     madd_same_x(acc, p, neg);
+    lds_st_packed(xs, fp_cond_sub_p(fp_mul(mem_ld(acc, CX), fp_one<FqParams>())));   // any bound -> canonical
     lds_st(zz, mem_ld(acc, CZZ));
     lds_st(zzz, mem_ld(acc, CZZZ));
   }

@@ -228,15 +228,18 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restri
   }
   uint32_t bend = pos0;            // forces the run set-up on the first iteration
   bool first = true;
-  __shared__ uint32_t lds_zz[27 * ZK_LDS_STRIDE], lds_zzz[27 * ZK_LDS_STRIDE];   // 2 x 27 KiB per 256-lane block
+  // 78 KiB per 256-lane block, two blocks per CU: ZZ, ZZZ as 27 limbs, X as 24 packed words
+  __shared__ uint32_t lds_zz[27 * ZK_LDS_STRIDE], lds_zzz[27 * ZK_LDS_STRIDE], lds_x[24 * ZK_LDS_STRIDE];
   uint32_t* zz = lds_zz + threadIdx.x;
   uint32_t* zzz = lds_zzz + threadIdx.x;
+  uint32_t* xs = lds_x + threadIdx.x;
   XyzzRef acc = make_ref(slots, stride, 0);
   bool inf = true;
+  uint32_t e_next = entries[pos0];
   for (uint32_t k = pos0; k < pos1; k++) {
     if (k == bend) {
       if (!first) {
-        if (!inf) { mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz)); }   // close the finished run
+        if (!inf) { mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz)); }   // close the finished run
         b++;
         while (offsets[b] + counts[b] <= k) b++;     // next non-empty bucket
       }
@@ -247,20 +250,22 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restri
       acc.voff = slot * 4u;
       inf = true;
     }
-    uint32_t e = entries[k];
+    uint32_t e = e_next;
+    if (k + 1 < pos1) e_next = entries[k + 1];        // fetched a whole addition ahead of its use
     const AffPacked* p = &bases[e & 0x7fffffffu];
     bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_scalar_digits drops them)
     if (inf) {
-      mem_st(acc, CX, aff_ld_x(p));
+#pragma unroll
+      for (int i = 0; i < 24; i++) xs[i * ZK_LDS_STRIDE] = p->x[i];       // packed words straight into LDS
       mem_st(acc, CY, aff_ld_y(p, neg));
       lds_st(zz, fp_one<FqParams>());
       lds_st(zzz, fp_one<FqParams>());
       inf = false;
       continue;
     }
-    if (madd_mem_lds(acc, zz, zzz, p, neg)) inf = fp_is_zero_2p(lds_ld(zz));   // same-x path may have cancelled to infinity
+    if (madd_mem_lds(acc, xs, zz, zzz, p, neg)) inf = fp_is_zero_2p(lds_ld(zz));   // same-x path may have cancelled to infinity
   }
-  if (!inf) { mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz)); }
+  if (!inf) { mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz)); }
   // a run that cancelled to infinity leaves ZZ = 0 in its slot: madd_same_x wrote the zeros, or the slot
   // was never written (zero-filled array)
 }
