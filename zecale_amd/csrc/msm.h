@@ -23,12 +23,17 @@ struct MsmCtx {
   uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels;
   uint64_t *win_abi, *win_host;
   float last_accumulate_ms;
+  bool pending;       // an MSM has been enqueued by msm_launch and not yet collected by msm_finish
+  size_t pending_n;
   char errbuf[256];
 };
 
 int msm_plan_init(MsmCtx* ctx, size_t max_n, int c);
 void msm_plan_free(MsmCtx* ctx);
 int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags);
+int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
+               int scalars_montgomery);
+int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]);
 int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
             int scalars_montgomery, uint64_t out_jac[36]);
 

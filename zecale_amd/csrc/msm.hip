@@ -553,16 +553,22 @@ int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPac
 // d_bases: packed device-form points; d_scalars: n x 6 u64 (device memory).  Result: Jacobian, ABI form (host).
 int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
             int scalars_montgomery, uint64_t out_jac[36]) {
-  using namespace host;
+  int rc = msm_launch(ctx, d_bases, d_inf_flags, d_scalars, n, scalars_montgomery);
+  if (rc != ZKHIP_OK) return rc;
+  return msm_finish(ctx, out_jac);
+}
+
+// Enqueue one MSM on the context's streams and return without waiting (the prover keeps two contexts
+// in flight so that the latency-bound reduction of one MSM overlaps the accumulation of the next).
+int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
+               int scalars_montgomery) {
   if (n > ctx->max_n) return ZKHIP_ERR_ARG;
   const int c = ctx->c, W = ctx->W;
   const size_t B = ctx->B, nb = B * W;
   hipStream_t st = ctx->stream;
-  if (n == 0) {
-    HJac inf = HJac::infinity();
-    inf.X.to_limbs(out_jac); inf.Y.to_limbs(out_jac + 12); inf.Z.to_limbs(out_jac + 24);
-    return ZKHIP_OK;
-  }
+  ctx->pending_n = n;
+  ctx->pending = true;
+  if (n == 0) return ZKHIP_OK;
   HIP_TRY(hipMemsetAsync(ctx->counts, 0, nb * 4, st));
   HIP_TRY(hipMemsetAsync(ctx->cursor, 0, nb * 4, st));
   WindowPlan plan;
@@ -659,7 +665,21 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, c
   hipLaunchKernelGGL(k_window_combine, dim3(nblk((size_t)W * 4, 64)), dim3(64), 0, st, ctx->Rlevels, level, W, ls, ctx->sumR[0], ctx->win_abi);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ctx->win_host, ctx->win_abi, (size_t)W * 48 * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  return ZKHIP_OK;
+}
+
+// Wait for the MSM enqueued by msm_launch and finish it on the host.
+int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]) {
+  using namespace host;
+  if (!ctx->pending) return ZKHIP_ERR_STATE;
+  ctx->pending = false;
+  const int W = ctx->W;
+  if (ctx->pending_n == 0) {
+    HJac inf = HJac::infinity();
+    inf.X.to_limbs(out_jac); inf.Y.to_limbs(out_jac + 12); inf.Z.to_limbs(out_jac + 24);
+    return ZKHIP_OK;
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
   ctx->last_accumulate_ms = ms;

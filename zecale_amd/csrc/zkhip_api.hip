@@ -10,6 +10,7 @@
 #include "ntt.h"
 #include "qap.h"
 #include <chrono>
+#include <future>
 
 using namespace zkhip;
 
@@ -37,6 +38,8 @@ struct Lib {
   int forced_c = 0;
   MsmCtx msm;
   bool msm_ready = false;
+  MsmCtx msm2;              // second context: the prover keeps two MSMs in flight
+  bool msm2_ready = false;
   char err[512] = {0};
   std::mutex mu;
 } g;
@@ -61,6 +64,16 @@ int auto_window(size_t n) {
   if (n <= (1u << 16)) return 12;
   if (n <= (1u << 18)) return 14;
   return 16;
+}
+
+int ensure_msm2(size_t n) {
+  int c = auto_window(n);
+  if (g.msm2_ready && g.msm2.max_n >= n && g.msm2.c == c) return ZKHIP_OK;
+  if (g.msm2_ready) { msm_plan_free(&g.msm2); g.msm2_ready = false; }
+  int rc = msm_plan_init(&g.msm2, n, c);
+  if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "msm_plan_init: %s", g.msm2.errbuf); return rc; }
+  g.msm2_ready = true;
+  return ZKHIP_OK;
 }
 
 int ensure_msm(size_t n) {
@@ -97,6 +110,7 @@ int zkhip_init(int device) {
 void zkhip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g.mu);
   if (g.msm_ready) { msm_plan_free(&g.msm); g.msm_ready = false; }
+  if (g.msm2_ready) { msm_plan_free(&g.msm2); g.msm2_ready = false; }
   g.inited = false;
 }
 
@@ -349,11 +363,25 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
   struct { const zkhip_bases* b; const uint64_t* sc; size_t len; int mode; uint64_t* out; } jobs[5] = {
       {crs->A, dz, m, 1, evA}, {crs->B2, dz, m, 1, evB2}, {crs->B1, dz, m, 1, evB1},
       {crs->H, (const uint64_t*)rd->bufA, d - 1, 2, evH}, {crs->L, dz + (l + 1) * 6, m - l - 1, 1, evL}};
+  if ((rc = ensure_msm2(maxlen)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
+  // two MSMs in flight: while MSM j reduces its buckets (latency-bound, few lanes), MSM j+1 accumulates
+  MsmCtx* ctxs[2] = {&g.msm, &g.msm2};
+  clk::time_point tl[5];
   for (int j = 0; j < 5; j++) {
-    t0 = clk::now();
-    rc = msm_run(&g.msm, jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].out);
-    g_prove_ms[2 + j] = ms_since(t0);
-    if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", g.msm.errbuf); (void)hipFree(dz); return rc; }
+    MsmCtx* cx = ctxs[j & 1];
+    if (j >= 2) {
+      rc = msm_finish(cx, jobs[j - 2].out);
+      g_prove_ms[2 + j - 2] = ms_since(tl[j - 2]);
+      if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", cx->errbuf); (void)hipFree(dz); return rc; }
+    }
+    tl[j] = clk::now();
+    rc = msm_launch(cx, jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode);
+    if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", cx->errbuf); (void)hipFree(dz); return rc; }
+  }
+  for (int j = 3; j < 5; j++) {
+    rc = msm_finish(ctxs[j & 1], jobs[j].out);
+    g_prove_ms[2 + j] = ms_since(tl[j]);
+    if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", ctxs[j & 1]->errbuf); (void)hipFree(dz); return rc; }
   }
   (void)hipFree(dz);
   // tail: A = alpha + evA + r delta1;  B = beta + evB + s delta;  C = evH + evL + s A + r B1 - rs delta1
@@ -364,10 +392,15 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
   uint64_t rc_[6], sc_[6], rsc_[6];
   r.to_canonical(rc_); s.to_canonical(sc_); rs.to_canonical(rsc_);
   HJac d1 = aff(crs->delta_g1), d2 = aff(crs->delta_g2);
-  HJac gA = jac(evA).add(aff(crs->alpha_g1)).add(d1.mul_canonical(rc_, 6));
-  HJac gB2 = jac(evB2).add(aff(crs->beta_g2)).add(d2.mul_canonical(sc_, 6));
-  HJac gB1 = jac(evB1).add(aff(crs->beta_g1)).add(d1.mul_canonical(sc_, 6));
-  HJac gC = jac(evH).add(jac(evL)).add(gA.mul_canonical(sc_, 6)).add(gB1.mul_canonical(rc_, 6)).add(d1.mul_canonical(rsc_, 6).neg());
+  // six independent 377-bit scalar multiplications of single points: serial chains, one host thread each
+  auto smul = [](HJac p, const uint64_t* k) { return std::async(std::launch::async, [p, k]() { return p.mul_canonical(k, 6); }); };
+  auto f_rd1 = smul(d1, rc_), f_sd2 = smul(d2, sc_), f_sd1 = smul(d1, sc_), f_rsd1 = smul(d1, rsc_);
+  HJac gA = jac(evA).add(aff(crs->alpha_g1)).add(f_rd1.get());
+  auto f_sA = smul(gA, sc_);
+  HJac gB1 = jac(evB1).add(aff(crs->beta_g1)).add(f_sd1.get());
+  auto f_rB1 = smul(gB1, rc_);
+  HJac gB2 = jac(evB2).add(aff(crs->beta_g2)).add(f_sd2.get());
+  HJac gC = jac(evH).add(jac(evL)).add(f_sA.get()).add(f_rB1.get()).add(f_rsd1.get().neg());
   HFq x, y;
   gA.to_affine(x, y); x.to_limbs(proof_affine); y.to_limbs(proof_affine + 12);
   gB2.to_affine(x, y); x.to_limbs(proof_affine + 24); y.to_limbs(proof_affine + 36);
