@@ -125,6 +125,15 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
  * [2..6] the five MSMs A, B2, B1, H, L, [7] host tail */
 int zkhip_last_prove_timings(double out_ms[8]);
 
+/* replaces: wsnarkT::verify(primary_inputs, proof, vk) (libzecale/tests/aggregator/aggregator_dummy_test.cpp:61-62)
+ * = libsnark r1cs_gg_ppzksnark_verifier_strong_IC for the Clearmatics Groth16 (no gamma in the key:
+ * testdata/dummy_app/aggregator_vk.json), i.e. the equation of contracts/Groth16BW6_761.sol:166-176.
+ * Host code (verification is not on the prover's hot path); needs no device and no zkhip_init.
+ * vk_abc: (n_inputs + 1) x 24 limbs; inputs: n_inputs x 6 limbs; proof: A (G1), B (G2), C (G1) affine. */
+int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_g2[24], const uint64_t vk_delta_g2[24],
+                         const uint64_t* vk_abc, const uint64_t* inputs, size_t n_inputs, const uint64_t proof_affine[72],
+                         int* ok);
+
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
 

@@ -121,7 +121,9 @@ def crs_from_trapdoor(zk, A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
         hs.append(t)
         t = t * tau % R.R_MOD
     ls = [(beta * st["At"][i] + alpha * st["Bt"][i] + st["Ct"][i]) * dinv % R.R_MOD for i in range(n_primary + 1, n_vars)]
-    pk = dict(alpha_g1=fb(g1, [alpha])[0], beta_g1=fb(g1, [beta])[0], beta_g2=fb(g2, [beta])[0],
+    abc = [(beta * st["At"][i] + alpha * st["Bt"][i] + st["Ct"][i]) % R.R_MOD for i in range(n_primary + 1)]
+    vk = dict(alpha=fb(g1, [alpha])[0], beta=fb(g2, [beta])[0], delta=fb(g2, [delta])[0], ABC=fb(g1, abc))
+    pk = dict(vk=vk, alpha_g1=fb(g1, [alpha])[0], beta_g1=fb(g1, [beta])[0], beta_g2=fb(g2, [beta])[0],
               delta_g1=fb(g1, [delta])[0], delta_g2=fb(g2, [delta])[0],
               A=fb(g1, st["At"]), B2=fb(g2, st["Bt"]), B1=fb(g1, st["Bt"]), H=fb(g1, hs), L=fb(g1, ls))
     return pk, st["log_d"]

@@ -77,6 +77,11 @@ def test_synthetic_circuit_vs_oracle_and_trapdoor(zk, oracle_lib, n, bool_frac):
     assert (proof[:24] == O.jac_to_affine(O.scalar_mul(g1, fr_limbs(sa)))).all()
     assert (proof[24:48] == O.jac_to_affine(O.scalar_mul(g2, fr_limbs(sb)))).all()
     assert (proof[48:] == O.jac_to_affine(O.scalar_mul(g1, fr_limbs(sc)))).all()
+    # and the proof verifies under the key's verification half (wsnark::verify, aggregator_dummy_test.cpp:61-62);
+    # a bumped public input does not (aggregator_dummy_test.cpp:162-186 does the same to a nested input)
+    assert zk.groth16_verify(pk["vk"], zl[1:1 + n_primary], proof)
+    bad = zl[1:1 + n_primary].copy(); bad[1] = fr_limbs(z[2] + 1)
+    assert not zk.groth16_verify(pk["vk"], bad, proof)
     print(zk.last_prove_timings())
     crs.free(); r1.free()
 

@@ -9,6 +9,7 @@
 #include "msm.h"
 #include "ntt.h"
 #include "qap.h"
+#include "pairing_host.hpp"
 #include <chrono>
 #include <future>
 
@@ -406,6 +407,38 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
   gB2.to_affine(x, y); x.to_limbs(proof_affine + 24); y.to_limbs(proof_affine + 36);
   gC.to_affine(x, y); x.to_limbs(proof_affine + 48); y.to_limbs(proof_affine + 60);
   g_prove_ms[7] = ms_since(t0);
+  return ZKHIP_OK;
+}
+
+int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_g2[24], const uint64_t vk_delta_g2[24],
+                         const uint64_t* vk_abc, const uint64_t* inputs, size_t n_inputs, const uint64_t proof_affine[72],
+                         int* ok) {
+  using namespace host;
+  if (!vk_alpha_g1 || !vk_beta_g2 || !vk_delta_g2 || !vk_abc || !proof_affine || !ok || (n_inputs && !inputs))
+    return fail(ZKHIP_ERR_ARG, "null pointer");
+  auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
+  // acc = ABC_0 + sum x_i ABC_i
+  HJac acc = aff(vk_abc);
+  for (size_t i = 0; i < n_inputs; i++) {
+    uint64_t k[6];
+    HFr::from_limbs(inputs + i * 6).to_canonical(k);
+    acc = acc.add(aff(vk_abc + (i + 1) * 24).mul_canonical(k, 6));
+  }
+  uint64_t acc_aff[24], neg_g2[24], neg_beta[24], neg_delta[24];
+  HFq x, y;
+  acc.to_affine(x, y); x.to_limbs(acc_aff); y.to_limbs(acc_aff + 12);
+  auto neg_pt = [](const uint64_t* p, uint64_t* o) {
+    memcpy(o, p, 96);
+    HFq yy = HFq::from_limbs(p + 12);
+    bool inf = HFq::from_limbs(p).is_zero() && yy.is_zero();
+    (inf ? yy : yy.neg()).to_limbs(o + 12);
+  };
+  uint64_t g2[24];
+  memcpy(g2, FqParams::G2_GEN_X64, 96); memcpy(g2 + 12, FqParams::G2_GEN_Y64, 96);
+  neg_pt(g2, neg_g2); neg_pt(vk_beta_g2, neg_beta); neg_pt(vk_delta_g2, neg_delta);
+  std::vector<const uint64_t*> p1 = {proof_affine, acc_aff, vk_alpha_g1, proof_affine + 48};
+  std::vector<const uint64_t*> p2 = {proof_affine + 24, neg_g2, neg_beta, neg_delta};
+  *ok = pairing_product_is_one(p1, p2) ? 1 : 0;
   return ZKHIP_OK;
 }
 

@@ -16,7 +16,7 @@ EXPORTS = [
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_last_accumulate_ms",
     "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
-    "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings",
+    "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings", "zkhip_groth16_verify",
     "zkhip_jac_to_affine", "zkhip_jac_add",
 ]
 
@@ -75,6 +75,7 @@ def load():
     lib.zkhip_crs_free.argtypes = [ctypes.c_void_p]
     lib.zkhip_groth16_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
     lib.zkhip_last_prove_timings.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    lib.zkhip_groth16_verify.argtypes = [c_u64p, c_u64p, c_u64p, c_u64p, c_u64p, ctypes.c_size_t, c_u64p, ctypes.POINTER(ctypes.c_int)]
     lib.zkhip_last_accumulate_ms.restype = ctypes.c_float
     lib.zkhip_jac_to_affine.argtypes = [c_u64p, c_u64p]
     lib.zkhip_jac_add.argtypes = [c_u64p, c_u64p, c_u64p]
@@ -228,7 +229,7 @@ class Crs:
                                  ("delta_g1", "delta_g1", 1), ("delta_g2", "delta_g2", 1), ("a_query", "A", n_vars),
                                  ("b_g2_query", "B2", n_vars), ("b_g1_query", "B1", n_vars), ("h_query", "H", domain_size - 1),
                                  ("l_query", "L", n_vars - n_primary - 1)):
-            a = np.ascontiguousarray(pk[key], dtype=np.uint64).reshape(-1, 24)
+            a = np.ascontiguousarray(pk[key], dtype=np.uint64).reshape(-1, 24)  # (extra keys such as "vk" are ignored)
             assert a.shape[0] == rows, (key, a.shape, rows)
             keep.append(a)
             setattr(d, field, a.ctypes.data if a.size else None)
@@ -249,6 +250,19 @@ def groth16_prove(crs, r1cs, z, r, s):
     _check(load().zkhip_groth16_prove(crs.handle, r1cs.handle, _p(zz), _p(np.ascontiguousarray(r, dtype=np.uint64)),
                                       _p(np.ascontiguousarray(s, dtype=np.uint64)), _p(out)))
     return out
+
+
+def groth16_verify(vk, inputs, proof):
+    """vk: dict alpha (G1), beta, delta (G2), ABC ((n+1) x 24 limbs); inputs: n x 6 limbs; proof: 72 limbs.
+    Host code: works without a GPU."""
+    c = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+    abc = c(vk["ABC"]).reshape(-1, 24)
+    inp = c(inputs).reshape(-1, 6)
+    assert abc.shape[0] == inp.shape[0] + 1
+    ok = ctypes.c_int(0)
+    _check(load().zkhip_groth16_verify(_p(c(vk["alpha"])), _p(c(vk["beta"])), _p(c(vk["delta"])), _p(abc), _p(inp), inp.shape[0],
+                                       _p(c(proof)), ctypes.byref(ok)))
+    return bool(ok.value)
 
 
 def last_prove_timings():
