@@ -549,11 +549,27 @@ def bls_g2_neg(Q):
     return (Q[0], ((-Q[1][0]) % BLS_Q, (-Q[1][1]) % BLS_Q))
 
 
-# G2 generator of BLS12-377 is not in the reference tree; the nested verification only needs
-# e(A,B) = e(alpha,beta) e(acc,gamma) e(C,delta) with gamma = G2 generator.  The Clearmatics
-# Groth16 has no gamma in the VK (testdata/dummy_app/vk.json) -> gamma is the fixed libff
-# generator, which the reference tree does not state.  We therefore check the nested proofs
-# RELATIVE to each other (see tests/test_oracle_pins.py): for two proofs under the same VK,
-# e(A1,B1)/e(A2,B2) * e(C2-C1 ... ) cannot eliminate gamma either, so the nested fixtures pin
-# curve membership and subgroup order only.  BW6-761 has its G2 generator in-tree and is pinned
-# by the full verification equation.
+# G2 generator of BLS12-377 (libff bls12_377_G2::G2_one).  It is NOT stated anywhere in the reference tree (the
+# Clearmatics Groth16 key has no gamma: testdata/dummy_app/vk.json; verification pairs the input accumulator
+# with the fixed generator).  The constant below is [UPSTREAM-RECALL] and is CONFIRMED by the reference's own
+# fixtures: extproof1..6.json verify under vk.json with this gamma and with no other candidate tried
+# (tests/test_oracle_pins.py::test_reference_nested_bls12_377_groth16_kats) - a wrong point would not verify.
+BLS_G2_GEN = (
+    (111583945774695116443911226257823823434468740249883042837745151039122196680777376765707574547389190084887628324746,
+     129066980656703085518157301154335215886082112524378686555873161080604845924984124025594590925548060469686767592854),
+    (168863299724668977183029941347596462608978380503965103341003918678547611204475537878680436662916294540335494194722,
+     233892497287475762251335351893618429603672921469864392767514552093535653615809913098097380147379993375817193725968),
+)
+BLS_G1_B = 1
+
+
+def bls12_377_groth16_verify(vk, proof, inputs):
+    """Nested (BLS12-377) Groth16 verification, Clearmatics variant without gamma:
+    e(A,B) = e(alpha,beta) e(ABC_0 + sum x_i ABC_i, G2_one) e(C,delta).
+    vk: dict alpha (G1), beta, delta (G2 as ((c0,c1),(c0,c1))), ABC (list of G1); proof: a, b, c."""
+    acc = vk["ABC"][0]
+    for x, P in zip(inputs, vk["ABC"][1:]):
+        acc = ec_add(acc, ec_mul(x, P, BLS_Q), BLS_Q)
+    return bls12_377_pairing_product_is_one([
+        (proof["a"], proof["b"]), (acc, bls_g2_neg(BLS_G2_GEN)),
+        (vk["alpha"], bls_g2_neg(vk["beta"])), (proof["c"], bls_g2_neg(vk["delta"]))])

@@ -84,6 +84,31 @@ def test_reference_nested_bls12_377_fixtures():
     assert not R.bls12_377_pairing_product_is_one(pairs)
 
 
+def load_nested_fixtures():
+    vk = golden("dummy_app/vk.json")
+    g2 = lambda p: ((h2i(p[0][1]), h2i(p[0][0])), (h2i(p[1][1]), h2i(p[1][0])))   # JSON order is [c1, c0]
+    nvk = dict(alpha=pt_from_json(vk["alpha"]), beta=g2(vk["beta"]), delta=g2(vk["delta"]), ABC=[pt_from_json(p) for p in vk["ABC"]])
+    proofs = []
+    for i in range(1, 7):
+        j = golden(f"dummy_app/extproof{i}.json")["extended_proof"]
+        proofs.append((dict(a=pt_from_json(j["proof"]["a"]), b=g2(j["proof"]["b"]), c=pt_from_json(j["proof"]["c"])),
+                       [h2i(x) for x in j["inputs"]]))
+    return nvk, proofs
+
+
+def test_reference_nested_bls12_377_groth16_kats():
+    """All six nested proofs (a * a^-1 = 1 for a = 7..12, libzecale/tests/circuits/dummy_application_test.cpp:32-44)
+    verify under vk.json with the BLS12-377 G2 generator as gamma; a bumped input does not (the reference makes a
+    proof invalid the same way, aggregator_dummy_test.cpp:162-168).  This is what confirms BLS_G2_GEN."""
+    nvk, proofs = load_nested_fixtures()
+    assert R.bls_g2_on_curve(R.BLS_G2_GEN)
+    for k, (pr, inputs) in enumerate(proofs):
+        assert inputs == [7 + k]
+        assert R.bls12_377_groth16_verify(nvk, pr, inputs), k
+    pr, inputs = proofs[1]
+    assert not R.bls12_377_groth16_verify(nvk, pr, [inputs[0] + 1])
+
+
 # ---------------------------------------------------------------- 2. C oracle vs golden vectors
 def test_c_oracle_fields(oracle_lib):
     O = oracle_lib
