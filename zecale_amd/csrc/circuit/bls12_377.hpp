@@ -1,0 +1,165 @@
+// BLS12-377 (the nested curve, npp = other_curve<bw6_761_pp>: aggregator_server.cpp:48) generic over the DSL
+// field type: group law in affine coordinates with witnessed slopes, optimal ate Miller loop, final
+// exponentiation, and the Groth16 verification equation of the Clearmatics variant without gamma.
+// Instantiated with NF this is a native verifier (pinned on testdata/dummy_app/{vk,extproof1..6}.json);
+// instantiated with CV it is the in-circuit verifier the reference takes from libsnark
+// (r1cs_gg_ppzksnark_*_gadget<bw6_761_pp>, groth16_verifier_parameters.hpp:16-27).
+//
+// E : y^2 = x^3 + 1 over Fq;  E' : y^2 = x^3 + 1/u over Fq2 (D-twist);  psi(x', y') = (x' w^2, y' w^3).
+// Loop parameter u = 0x8508c00000000001 (r = u^4 - u^2 + 1).
+#pragma once
+#include "tower.hpp"
+
+namespace zkhip {
+namespace circuit {
+
+static const uint64_t BLS_U = 0x8508c00000000001ull;
+
+template <class F> struct G1 { F x, y; };
+template <class F> struct G2 { Fq2<F> x, y; };
+
+template <class F> inline G1<F> g1_add(const G1<F>& p, const G1<F>& q) {       // p != +-q
+  F lam = f_div(q.y - p.y, q.x - p.x);
+  F x3 = lam * lam - p.x - q.x;
+  F y3 = lam * (p.x - x3) - p.y;
+  return G1<F>{x3, y3};
+}
+template <class F> inline G1<F> g1_dbl(const G1<F>& p) {
+  F xx = p.x * p.x;
+  F lam = f_div(xx + xx + xx, p.y + p.y);
+  F x3 = lam * lam - p.x - p.x;
+  F y3 = lam * (p.x - x3) - p.y;
+  return G1<F>{x3, y3};
+}
+template <class F> inline G1<F> g1_select(const F& bit, const G1<F>& a, const G1<F>& b) {
+  return G1<F>{f_select(bit, a.x, b.x), f_select(bit, a.y, b.y)};
+}
+
+// Line through psi(T) with slope lambda' w, evaluated at P in G1:  yP - lambda' xP w + (lambda' xT - yT) w^3
+template <class F> inline Fq12<F> line_eval(const Fq2<F>& lam, const Fq2<F>& xT, const Fq2<F>& yT, const G1<F>& P) {
+  Fq12<F> l;
+  Fq2<F> a = lam.mul_base(P.x).neg();
+  Fq2<F> b = lam * xT - yT;
+  l.c[0] = P.y;
+  l.c[1] = a.c0; l.c[7] = a.c1;
+  l.c[3] = b.c0; l.c[9] = b.c1;
+  return l;
+}
+
+template <class F> struct MillerState { G2<F> T; G2<F> Q; G1<F> P; };
+
+template <class F> inline Fq12<F> miller_dbl_step(MillerState<F>& s) {
+  Fq2<F> xx = s.T.x.sqr();
+  Fq2<F> lam = fq2_div(xx + xx + xx, s.T.y + s.T.y);
+  Fq12<F> l = line_eval(lam, s.T.x, s.T.y, s.P);
+  Fq2<F> x3 = lam.sqr() - s.T.x - s.T.x;
+  Fq2<F> y3 = lam * (s.T.x - x3) - s.T.y;
+  s.T.x = x3; s.T.y = y3;
+  return l;
+}
+template <class F> inline Fq12<F> miller_add_step(MillerState<F>& s) {
+  Fq2<F> lam = fq2_div(s.Q.y - s.T.y, s.Q.x - s.T.x);
+  Fq12<F> l = line_eval(lam, s.T.x, s.T.y, s.P);
+  Fq2<F> x3 = lam.sqr() - s.T.x - s.Q.x;
+  Fq2<F> y3 = lam * (s.T.x - x3) - s.T.y;
+  s.T.x = x3; s.T.y = y3;
+  return l;
+}
+
+// prod_i f_{u,Q_i}(P_i): one shared accumulator (one squaring per bit for the whole product)
+template <class F> inline Fq12<F> multi_miller_loop(std::vector<MillerState<F>>& ps) {
+  Fq12<F> f = Fq12<F>::one();
+  for (auto& s : ps) s.T = s.Q;
+  bool first = true;
+  for (int i = 62; i >= 0; i--) {
+    if (!first) f = f.sqr();
+    for (auto& s : ps) { Fq12<F> l = miller_dbl_step(s); f = first ? l : f * l; first = false; }
+    if ((BLS_U >> i) & 1)
+      for (auto& s : ps) f = f * miller_add_step(s);
+  }
+  return f;
+}
+
+template <class F> inline Fq12<F> exp_by_u(const Fq12<F>& x) {
+  Fq12<F> acc = x;
+  for (int i = 62; i >= 0; i--) {
+    acc = acc.sqr();
+    if ((BLS_U >> i) & 1) acc = acc * x;
+  }
+  return acc;
+}
+
+// f^(3 (q^12 - 1) / r): easy part (q^6 - 1)(q^2 + 1), then 3 (q^4 - q^2 + 1)/r = l0 + l1 q + l2 q^2 + l3 q^3 with
+// l3 = (u-1)^2, l2 = l3 u, l1 = l2 u - l3, l0 = l1 u + 3  (identity checked in tests against big integers).
+// The factor 3 is coprime to r: the cube of the reduced ate pairing is as good a pairing for an "== 1" check.
+template <class F> inline Fq12<F> final_exponentiation(const Fq12<F>& f) {
+  Fq12<F> f1 = f.conjugate() * fq12_inverse(f);
+  Fq12<F> f2 = f1.frobenius(2) * f1;
+  Fq12<F> t0 = exp_by_u(f2) * f2.conjugate();          // f2^(u-1)      (inverse = conjugate in the cyclotomic subgroup)
+  Fq12<F> t1 = exp_by_u(t0) * t0.conjugate();          // f2^l3
+  Fq12<F> t2 = exp_by_u(t1);                           // f2^l2
+  Fq12<F> t3 = exp_by_u(t2) * t1.conjugate();          // f2^l1
+  Fq12<F> t4 = exp_by_u(t3) * (f2.sqr() * f2);         // f2^l0
+  return t4 * t3.frobenius(1) * t2.frobenius(2) * t1.frobenius(3);
+}
+
+// [x == 1] in Fq12 as a field element (1 / 0)
+template <class F> inline F fq12_is_one(const Fq12<F>& x) {
+  F acc = f_is_zero(x.c[0] - f_one<F>());
+  for (int i = 1; i < 12; i++) acc = acc * f_is_zero(x.c[i]);
+  return acc;
+}
+
+// libff's bls12_377_G2::G2_one (not in the reference tree; confirmed by the nested fixtures: see oracle/pyref.py BLS_G2_GEN)
+struct BlsG2Gen {
+  HFr x0, x1, y0, y1;
+  static HFr dec(const char* s) {
+    HFr acc = HFr::zero(), ten = HFr::from_u64(10);
+    for (; *s; s++) acc = acc * ten + HFr::from_u64((uint64_t)(*s - '0'));
+    return acc;
+  }
+  BlsG2Gen() {
+    x0 = dec("111583945774695116443911226257823823434468740249883042837745151039122196680777376765707574547389190084887628324746");
+    x1 = dec("129066980656703085518157301154335215886082112524378686555873161080604845924984124025594590925548060469686767592854");
+    y0 = dec("168863299724668977183029941347596462608978380503965103341003918678547611204475537878680436662916294540335494194722");
+    y1 = dec("233892497287475762251335351893618429603672921469864392767514552093535653615809913098097380147379993375817193725968");
+  }
+};
+inline const BlsG2Gen& bls_g2_gen() { static BlsG2Gen g; return g; }
+
+template <class F> struct NestedVk { G1<F> alpha; G2<F> beta, delta; std::vector<G1<F>> abc; };
+template <class F> struct NestedProof { G1<F> a; G2<F> b; G1<F> c; };
+
+template <class F> inline G2<F> g2_neg(const G2<F>& p) { return G2<F>{p.x, p.y.neg()}; }
+
+// acc = ABC_0 + sum_j bits_j (2^j ABC_1) ...: one input, bits little-endian
+template <class F> inline G1<F> input_accumulator(const NestedVk<F>& vk, const std::vector<std::vector<F>>& input_bits) {
+  G1<F> acc = vk.abc[0];
+  for (size_t k = 0; k < input_bits.size(); k++) {
+    G1<F> pw = vk.abc[k + 1];
+    for (size_t j = 0; j < input_bits[k].size(); j++) {
+      G1<F> s = g1_add(acc, pw);
+      acc = g1_select(input_bits[k][j], s, acc);
+      if (j + 1 < input_bits[k].size()) pw = g1_dbl(pw);
+    }
+  }
+  return acc;
+}
+
+// 1 / 0 : e(A,B) e(acc,-G2_one) e(alpha,-beta) e(C,-delta) == 1
+// (reference: the check the online verifier gadget performs; result is NOT enforced to be 1:
+//  aggregator_circuit.hpp:51-54)
+template <class F> inline F groth16_verify_bit(const NestedVk<F>& vk, const NestedProof<F>& pr, const G1<F>& acc) {
+  const BlsG2Gen& g = bls_g2_gen();
+  G2<F> gen{Fq2<F>::constant(g.x0, g.x1), Fq2<F>::constant(g.y0, g.y1)};
+  std::vector<MillerState<F>> ps(4);
+  ps[0].Q = pr.b; ps[0].P = pr.a;
+  ps[1].Q = g2_neg(gen); ps[1].P = acc;
+  ps[2].Q = g2_neg(vk.beta); ps[2].P = vk.alpha;
+  ps[3].Q = g2_neg(vk.delta); ps[3].P = pr.c;
+  Fq12<F> f = multi_miller_loop(ps);
+  return fq12_is_one(final_exponentiation(f));
+}
+
+}  // namespace circuit
+}  // namespace zkhip

@@ -1,0 +1,179 @@
+// A small arithmetic-circuit DSL for the wrapping circuit (host C++).
+//
+// The reference builds its circuit out of libsnark gadgets: each gadget has a constructor that allocates
+// variables and a pair generate_r1cs_constraints / generate_r1cs_witness (libzecale/circuits/
+// aggregator_gadget.tcc:13-112, aggregator_circuit.tcc:17-98, 120-170).  Those gadget sources
+// (libsnark gadgetlib1 pairing gadgets, libzeth MiMC) are not in the reference tree, so the circuit here is
+// restated from the mathematics with one mechanism instead of two: every algorithm of the circuit (tower
+// arithmetic, group law, Miller loop, final exponentiation, MiMC) is written ONCE as a template over a field
+// type F and instantiated with
+//     NF  native field element                      -> plain evaluation (used to cross-check and in tests)
+//     CV  circuit value = linear combination + value  -> the same code emits the R1CS constraints and
+//                                                       computes the witness in one pass
+// Products of two CVs allocate a variable and emit  <a,z> * <b,z> = <c,z>;  sums and constant multiples stay
+// linear combinations and cost nothing.  A witness-only pass (Builder::record = false) replays the same code
+// and only fills the assignment; the structure of the code never depends on values.
+//
+// The field is Fr of BW6-761 = Fq of BLS12-377 (aggregator_gadget.hpp:20-30: nested coordinates are native
+// wrapper scalars).
+#pragma once
+#include <algorithm>
+#include <stdexcept>
+#include <vector>
+
+#include "../host_field.hpp"
+
+namespace zkhip {
+namespace circuit {
+
+using host::HFr;
+
+struct Term {
+  uint32_t var;
+  HFr coeff;
+};
+typedef std::vector<Term> LC;
+
+inline void lc_normalise(LC& l) {
+  std::sort(l.begin(), l.end(), [](const Term& a, const Term& b) { return a.var < b.var; });
+  size_t o = 0;
+  for (size_t i = 0; i < l.size();) {
+    HFr c = l[i].coeff;
+    size_t j = i + 1;
+    while (j < l.size() && l[j].var == l[i].var) { c = c + l[j].coeff; j++; }
+    if (!c.is_zero()) { l[o].var = l[i].var; l[o].coeff = c; o++; }
+    i = j;
+  }
+  l.resize(o);
+}
+
+struct Builder {
+  std::vector<HFr> z;       // full assignment, z[0] = 1
+  std::vector<LC> A, B, C;  // constraints (recorded when `record`)
+  bool record = true;
+  Builder() { z.push_back(HFr::one()); }
+  uint32_t alloc(const HFr& value) { z.push_back(value); return (uint32_t)(z.size() - 1); }
+  void enforce(LC a, LC b, LC c) {
+    if (!record) return;
+    lc_normalise(a); lc_normalise(b); lc_normalise(c);
+    A.push_back(std::move(a)); B.push_back(std::move(b)); C.push_back(std::move(c));
+  }
+  size_t num_constraints() const { return A.size(); }
+};
+
+inline Builder*& current_builder() {
+  static thread_local Builder* b = nullptr;
+  return b;
+}
+
+// ---- native instantiation --------------------------------------------------------------------
+struct NF {
+  HFr v;
+  NF() : v(HFr::zero()) {}
+  explicit NF(const HFr& x) : v(x) {}
+  static NF constant(const HFr& c) { return NF(c); }
+  static NF witness(const HFr& value) { return NF(value); }
+  static NF witness_bit(bool b) { return NF(b ? HFr::one() : HFr::zero()); }
+  const HFr& value() const { return v; }
+  NF operator+(const NF& o) const { return NF(v + o.v); }
+  NF operator-(const NF& o) const { return NF(v - o.v); }
+  NF operator*(const NF& o) const { return NF(v * o.v); }
+  NF mulc(const HFr& c) const { return NF(v * c); }
+  NF neg() const { return NF(v.neg()); }
+  static void assert_eq(const NF& a, const NF& b) {
+    if (a.v != b.v) throw std::runtime_error("native assert_eq failed");
+  }
+  static void assert_product(const NF& a, const NF& b, const NF& c) {
+    if (a.v * b.v != c.v) throw std::runtime_error("native assert_product failed");
+  }
+};
+
+// ---- circuit instantiation -------------------------------------------------------------------
+struct CV {
+  LC lc;
+  HFr val;
+  CV() : val(HFr::zero()) {}
+  static CV constant(const HFr& c) {
+    CV r;
+    if (!c.is_zero()) r.lc.push_back({0, c});
+    r.val = c;
+    return r;
+  }
+  static CV witness(const HFr& value) {
+    CV r;
+    r.lc.push_back({current_builder()->alloc(value), HFr::one()});
+    r.val = value;
+    return r;
+  }
+  static CV witness_bit(bool b) {
+    CV r = witness(b ? HFr::one() : HFr::zero());
+    CV m = r - constant(HFr::one());
+    current_builder()->enforce(r.lc, m.lc, LC());      // b (b - 1) = 0
+    return r;
+  }
+  const HFr& value() const { return val; }
+  bool is_const() const { return lc.empty() || (lc.size() == 1 && lc[0].var == 0); }
+  void compact() { if (lc.size() > 48) lc_normalise(lc); }
+  CV operator+(const CV& o) const {
+    CV r = *this;
+    r.lc.insert(r.lc.end(), o.lc.begin(), o.lc.end());
+    r.val = val + o.val;
+    r.compact();
+    return r;
+  }
+  CV operator-(const CV& o) const { return *this + o.neg(); }
+  CV neg() const {
+    CV r = *this;
+    for (auto& t : r.lc) t.coeff = t.coeff.neg();
+    r.val = val.neg();
+    return r;
+  }
+  CV mulc(const HFr& c) const {
+    CV r;
+    if (c.is_zero()) return r;
+    r = *this;
+    for (auto& t : r.lc) t.coeff = t.coeff * c;
+    r.val = val * c;
+    return r;
+  }
+  CV operator*(const CV& o) const {
+    if (is_const()) return o.mulc(val);          // products with constants stay linear: no variable, no constraint
+    if (o.is_const()) return mulc(o.val);
+    CV r = witness(val * o.val);
+    current_builder()->enforce(lc, o.lc, r.lc);
+    return r;
+  }
+  static void assert_eq(const CV& a, const CV& b) {
+    CV d = a - b;
+    current_builder()->enforce(d.lc, constant(HFr::one()).lc, LC());   // (a - b) * 1 = 0
+  }
+  static void assert_product(const CV& a, const CV& b, const CV& c) { current_builder()->enforce(a.lc, b.lc, c.lc); }
+};
+
+// helpers shared by both instantiations
+template <class F> inline F f_const_u64(uint64_t x) { return F::constant(HFr::from_u64(x)); }
+template <class F> inline F f_zero() { return F::constant(HFr::zero()); }
+template <class F> inline F f_one() { return F::constant(HFr::one()); }
+// a / b with b != 0 (value 0 if b == 0: the structure pass runs on dummy values): witness q, enforce q b = a
+inline bool f_is_const(const NF&) { return false; }
+inline bool f_is_const(const CV& x) { return x.is_const(); }
+template <class F> inline F f_div(const F& a, const F& b) {
+  HFr bi = b.value().is_zero() ? HFr::zero() : b.value().inv();
+  if (f_is_const(a) && f_is_const(b)) return F::constant(a.value() * bi);
+  F q = F::witness(a.value() * bi);
+  F::assert_product(q, b, a);
+  return q;
+}
+// [x == 0] as a field element (1 or 0): m = 1/x (or 0), z = 1 - x m, enforce x z = 0      (2 constraints)
+template <class F> inline F f_is_zero(const F& x) {
+  HFr m = x.value().is_zero() ? HFr::zero() : x.value().inv();
+  F mw = F::witness(m);
+  F z = f_one<F>() - x * mw;
+  F::assert_product(x, z, f_zero<F>());
+  return z;
+}
+// sel ? a : b   (sel boolean)
+template <class F> inline F f_select(const F& sel, const F& a, const F& b) { return b + sel * (a - b); }
+
+}  // namespace circuit
+}  // namespace zkhip

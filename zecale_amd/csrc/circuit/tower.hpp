@@ -1,0 +1,198 @@
+// Extension towers of the BLS12-377 base field, generic over the DSL's field type F (dsl.hpp):
+//   Fq2  = Fq[u]  / (u^2 + 5)
+//   Fq12 = Fq[w]  / (w^12 + 5),  u = w^6       (direct degree-12 extension: -5 is neither a square nor a cube in
+//                                                Fq, q = 1 mod 12, and 5/4 is not a fourth power - checked in
+//                                                tests/test_circuit_host.py against big integers)
+// The direct representation makes the Frobenius maps coefficient-wise scalings by constants (free in a circuit)
+// and lets a full Fq12 multiplication cost 23 constraints: c(X) = a(X) b(X) has degree 22, so it is pinned by
+// a(x_k) b(x_k) = c(x_k) at 23 points, and the reduction modulo w^12 + 5 is linear.
+#pragma once
+#include "dsl.hpp"
+
+namespace zkhip {
+namespace circuit {
+
+template <class F>
+struct Fq2 {
+  F c0, c1;
+  Fq2() : c0(f_zero<F>()), c1(f_zero<F>()) {}
+  Fq2(const F& a, const F& b) : c0(a), c1(b) {}
+  static Fq2 zero() { return Fq2(); }
+  static Fq2 one() { return Fq2(f_one<F>(), f_zero<F>()); }
+  static Fq2 constant(const HFr& a, const HFr& b) { return Fq2(F::constant(a), F::constant(b)); }
+  static Fq2 witness(const HFr& a, const HFr& b) { return Fq2(F::witness(a), F::witness(b)); }
+  Fq2 operator+(const Fq2& o) const { return Fq2(c0 + o.c0, c1 + o.c1); }
+  Fq2 operator-(const Fq2& o) const { return Fq2(c0 - o.c0, c1 - o.c1); }
+  Fq2 neg() const { return Fq2(c0.neg(), c1.neg()); }
+  Fq2 dbl() const { return *this + *this; }
+  Fq2 mulc(const HFr& k) const { return Fq2(c0.mulc(k), c1.mulc(k)); }
+  Fq2 mul_base(const F& k) const { return Fq2(c0 * k, c1 * k); }     // by an element of Fq: 2 products
+  Fq2 operator*(const Fq2& o) const {                                // Karatsuba: 3 products
+    F v0 = c0 * o.c0, v1 = c1 * o.c1;
+    F m = (c0 + c1) * (o.c0 + o.c1);
+    return Fq2(v0 - v1.mulc(HFr::from_u64(5)), m - v0 - v1);
+  }
+  Fq2 sqr() const {                                                  // 2 products
+    F t = c0 * c1;
+    F s = (c0 + c1) * (c0 - c1.mulc(HFr::from_u64(5)));              // a0^2 - 5 a1^2 - 4 t
+    return Fq2(s + t.mulc(HFr::from_u64(4)), t + t);
+  }
+  static void assert_eq(const Fq2& a, const Fq2& b) { F::assert_eq(a.c0, b.c0); F::assert_eq(a.c1, b.c1); }
+};
+
+// native value helpers on Fq2 (for witnesses)
+struct V2 { HFr a, b; };
+inline V2 v2_mul(const V2& x, const V2& y) {
+  HFr v0 = x.a * y.a, v1 = x.b * y.b;
+  return V2{v0 - v1 * HFr::from_u64(5), (x.a + x.b) * (y.a + y.b) - v0 - v1};
+}
+inline V2 v2_inv(const V2& x) {
+  HFr n = x.a * x.a + x.b * x.b * HFr::from_u64(5);     // norm a^2 + 5 b^2
+  if (n.is_zero()) return V2{HFr::zero(), HFr::zero()};
+  HFr ni = n.inv();
+  return V2{x.a * ni, (x.b * ni).neg()};
+}
+template <class F> inline V2 v2_of(const Fq2<F>& x) { return V2{x.c0.value(), x.c1.value()}; }
+
+// a / b in Fq2: witness q, enforce q b = a   (3 products + 2 equalities)
+template <class F> inline Fq2<F> fq2_div(const Fq2<F>& a, const Fq2<F>& b) {
+  V2 q = v2_mul(v2_of(a), v2_inv(v2_of(b)));
+  if (f_is_const(a.c0) && f_is_const(a.c1) && f_is_const(b.c0) && f_is_const(b.c1)) return Fq2<F>::constant(q.a, q.b);
+  Fq2<F> w = Fq2<F>::witness(q.a, q.b);
+  Fq2<F>::assert_eq(w * b, a);
+  return w;
+}
+
+// ---- Fq12 -----------------------------------------------------------------------------------------
+struct Fq12Consts {
+  HFr pw[23][23];      // pw[k][m] = k^m : evaluation points 0..22
+  HFr frob[12];        // c1^i, c1 = (-5)^((q-1)/12): Frobenius scales coefficient i by frob[(k i) mod 12] for x -> x^(q^k)
+  Fq12Consts() {
+    for (int k = 0; k < 23; k++) {
+      HFr x = HFr::from_u64((uint64_t)k), p = HFr::one();
+      for (int m = 0; m < 23; m++) { pw[k][m] = p; p = p * x; }
+    }
+    // (q - 1) / 12 as limbs
+    uint64_t e[6];
+    memcpy(e, FrParams::P64, sizeof e);
+    e[0] -= 1;
+    uint64_t rem = 0;
+    for (int i = 5; i >= 0; i--) {
+      unsigned __int128 cur = ((unsigned __int128)rem << 64) | e[i];
+      e[i] = (uint64_t)(cur / 12); rem = (uint64_t)(cur % 12);
+    }
+    HFr c1 = HFr::from_u64(5).neg().pow_limbs(e, 6);
+    frob[0] = HFr::one();
+    for (int i = 1; i < 12; i++) frob[i] = frob[i - 1] * c1;
+  }
+};
+inline const Fq12Consts& fq12_consts() { static Fq12Consts c; return c; }
+
+template <class F> struct Fq12;
+template <class F> Fq12<F> fq12_mul_impl(const Fq12<F>& a, const Fq12<F>& b);
+
+template <class F>
+struct Fq12 {
+  F c[12];
+  Fq12() { for (auto& x : c) x = f_zero<F>(); }
+  static Fq12 one() { Fq12 r; r.c[0] = f_one<F>(); return r; }
+  Fq12 operator+(const Fq12& o) const { Fq12 r; for (int i = 0; i < 12; i++) r.c[i] = c[i] + o.c[i]; return r; }
+  Fq12 operator-(const Fq12& o) const { Fq12 r; for (int i = 0; i < 12; i++) r.c[i] = c[i] - o.c[i]; return r; }
+  Fq12 operator*(const Fq12& o) const { return fq12_mul_impl(*this, o); }
+  Fq12 sqr() const { return fq12_mul_impl(*this, *this); }
+  // x -> x^(q^k): coefficient-wise scaling (w^(q^k) = c1^k w)
+  Fq12 frobenius(int k) const {
+    Fq12 r;
+    for (int i = 0; i < 12; i++) r.c[i] = c[i].mulc(fq12_consts().frob[(k * i) % 12]);
+    return r;
+  }
+  Fq12 conjugate() const { return frobenius(6); }       // x^(q^6): odd coefficients negated
+  static void assert_eq(const Fq12& a, const Fq12& b) { for (int i = 0; i < 12; i++) F::assert_eq(a.c[i], b.c[i]); }
+};
+
+// native product of coefficient vectors: full 23-coefficient product
+inline void v12_full_product(const HFr* a, const HFr* b, HFr* c /*23*/) {
+  for (int i = 0; i < 23; i++) c[i] = HFr::zero();
+  for (int i = 0; i < 12; i++)
+    for (int j = 0; j < 12; j++) c[i + j] = c[i + j] + a[i] * b[j];
+}
+
+template <> inline Fq12<NF> fq12_mul_impl<NF>(const Fq12<NF>& a, const Fq12<NF>& b) {
+  HFr av[12], bv[12], cv[23];
+  for (int i = 0; i < 12; i++) { av[i] = a.c[i].v; bv[i] = b.c[i].v; }
+  v12_full_product(av, bv, cv);
+  Fq12<NF> r;
+  HFr five = HFr::from_u64(5);
+  for (int i = 0; i < 12; i++) r.c[i] = NF(i + 12 < 23 ? cv[i] - cv[i + 12] * five : cv[i]);
+  return r;
+}
+
+template <> inline Fq12<CV> fq12_mul_impl<CV>(const Fq12<CV>& a, const Fq12<CV>& b) {
+  const Fq12Consts& K = fq12_consts();
+  HFr av[12], bv[12], cv[23];
+  for (int i = 0; i < 12; i++) { av[i] = a.c[i].val; bv[i] = b.c[i].val; }
+  v12_full_product(av, bv, cv);
+  CV cc[23];
+  for (int m = 0; m < 23; m++) cc[m] = CV::witness(cv[m]);
+  for (int k = 0; k < 23; k++) {
+    CV ea, eb, ec;
+    for (int i = 0; i < 12; i++) { ea = ea + a.c[i].mulc(K.pw[k][i]); eb = eb + b.c[i].mulc(K.pw[k][i]); }
+    for (int m = 0; m < 23; m++) ec = ec + cc[m].mulc(K.pw[k][m]);
+    CV::assert_product(ea, eb, ec);
+  }
+  Fq12<CV> r;
+  HFr five = HFr::from_u64(5);
+  for (int i = 0; i < 12; i++) r.c[i] = (i + 12 < 23) ? cc[i] - cc[i + 12].mulc(five) : cc[i];
+  return r;
+}
+
+// 1 / a: witness + a * inv = 1
+template <class F> inline void v12_of(const Fq12<F>& a, HFr* out) { for (int i = 0; i < 12; i++) out[i] = a.c[i].value(); }
+
+// native inverse in Fq12 by solving with the norm chain is overkill here: use a^(q^12 - 2) ... too slow;
+// instead: inverse = conj-product trick over the quadratic tower Fq12 = Fq6[w] (w^2 = v, v = w^2 in our basis):
+// a = e + o (even part e, odd part o);  a^-1 = (e - o) / (e^2 - o^2),  and e^2 - o^2 lies in the even subalgebra
+// Fq6 = Fq[w^2]; repeat with Fq6 = Fq2[...]: simpler to do Gaussian elimination on the 12x12 multiplication matrix.
+inline bool v12_inverse(const HFr* a, HFr* out) {
+  // solve M x = e0 where column j of M is a * w^j reduced
+  HFr M[12][13];
+  HFr five = HFr::from_u64(5);
+  for (int j = 0; j < 12; j++) {
+    // a * w^j : shift coefficients by j with wrap  w^12 = -5
+    for (int i = 0; i < 12; i++) {
+      int d = i + j;
+      HFr v = a[i];
+      if (d >= 12) { d -= 12; v = (v * five).neg(); }
+      M[d][j] = v;
+    }
+  }
+  for (int i = 0; i < 12; i++) M[i][12] = (i == 0) ? HFr::one() : HFr::zero();
+  for (int col = 0; col < 12; col++) {
+    int piv = -1;
+    for (int r = col; r < 12; r++) if (!M[r][col].is_zero()) { piv = r; break; }
+    if (piv < 0) return false;
+    if (piv != col) for (int k = 0; k < 13; k++) std::swap(M[piv][k], M[col][k]);
+    HFr inv = M[col][col].inv();
+    for (int k = 0; k < 13; k++) M[col][k] = M[col][k] * inv;
+    for (int r = 0; r < 12; r++) {
+      if (r == col || M[r][col].is_zero()) continue;
+      HFr f = M[r][col];
+      for (int k = 0; k < 13; k++) M[r][k] = M[r][k] - f * M[col][k];
+    }
+  }
+  for (int i = 0; i < 12; i++) out[i] = M[i][12];
+  return true;
+}
+
+template <class F> inline Fq12<F> fq12_inverse(const Fq12<F>& a) {
+  HFr av[12], iv[12];
+  v12_of(a, av);
+  if (!v12_inverse(av, iv)) for (auto& x : iv) x = HFr::zero();
+  Fq12<F> w;
+  for (int i = 0; i < 12; i++) w.c[i] = F::witness(iv[i]);
+  Fq12<F>::assert_eq(w * a, Fq12<F>::one());
+  return w;
+}
+
+}  // namespace circuit
+}  // namespace zkhip
