@@ -134,6 +134,35 @@ int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_
                          const uint64_t* vk_abc, const uint64_t* inputs, size_t n_inputs, const uint64_t proof_affine[72],
                          int* ok);
 
+/* ---- the wrapping (aggregator) circuit: host code, no device needed ------------------------------- */
+/* Nested objects are over BLS12-377, whose base field is Fr of BW6-761: coordinates are 6-limb Montgomery
+ * elements.  G1 affine = x | y (12 limbs); G2 affine = x.c0 | x.c1 | y.c0 | y.c1 (24 limbs), Fq2 = Fq[u]/(u^2+5).
+ * nested_vk   = alpha (12) | beta (24) | delta (24) | ABC_0 .. ABC_k (12 each), k = inputs_per_proof
+ * nested_proofs = num_proofs x [ a (12) | b (24) | c (12) ];  nested_inputs = num_proofs x k x 6 limbs. */
+
+/* replaces: nsnark::verify for the nested curve (libzecale/tests/circuits/dummy_application_test.cpp:32-44):
+ * Groth16 over BLS12-377, Clearmatics variant without gamma. */
+int zkhip_bls12_377_groth16_verify(const uint64_t vk_alpha_g1[12], const uint64_t vk_beta_g2[24], const uint64_t vk_delta_g2[24],
+                                   const uint64_t* vk_abc, const uint64_t* inputs, size_t n_inputs,
+                                   const uint64_t proof_a[12], const uint64_t proof_b[24], const uint64_t proof_c[12], int* ok);
+
+/* replaces: libzecale::aggregator_circuit<wppT, wsnarkT, nverifierT, NumProofs>(inputs_per_nested_proof)
+ * (libzecale/circuits/aggregator_circuit.hpp:32-114; constructor .tcc:17-98): builds the constraint system. */
+typedef struct zkhip_aggregator zkhip_aggregator;
+int zkhip_aggregator_new(size_t num_proofs, size_t inputs_per_proof, zkhip_aggregator** out);
+void zkhip_aggregator_free(zkhip_aggregator* a);
+size_t zkhip_aggregator_num_constraints(const zkhip_aggregator* a);
+size_t zkhip_aggregator_num_variables(const zkhip_aggregator* a);      /* including the constant ONE */
+size_t zkhip_aggregator_num_primary_inputs(const zkhip_aggregator* a); /* aggregator_circuit::num_primary_inputs, .tcc:172-180 */
+/* replaces: get_constraint_system() (aggregator_circuit.hpp:99-101); pointers stay valid while `a` lives */
+int zkhip_aggregator_get_r1cs(const zkhip_aggregator* a, zkhip_r1cs_desc* out);
+/* replaces: the generate_r1cs_witness calls of aggregator_circuit::prove (.tcc:136-157): full assignment
+ * z = (1, primary, auxiliary), n_vars x 6 limbs; primary = [vk hash, packed results, nested inputs ...] */
+int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, const uint64_t* nested_proofs,
+                             const uint64_t* nested_inputs, uint64_t* z_out);
+/* replaces: verification_key_hash_gadget::compute_hash(vk, num_inputs) (verification_key_hash_gadget.tcc:42-59) */
+int zkhip_aggregator_vk_hash(const uint64_t* nested_vk, size_t inputs_per_proof, uint64_t out[6]);
+
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
 

@@ -129,6 +129,19 @@ def qap_h(A, B, C, z, n, n_primary):
     return h
 
 
+def r1cs_first_unsatisfied(A, B, C, z):
+    """Index of the first violated constraint of <A,z><B,z> = <C,z>, or -1."""
+    n = len(A[0]) - 1
+    args = []
+    for (rp, col, val) in (A, B, C):
+        args += [_p32(np.ascontiguousarray(rp, dtype=np.uint32)), _p32(np.ascontiguousarray(col, dtype=np.uint32)),
+                 _p(np.ascontiguousarray(val, dtype=np.uint64))]
+    zz = np.ascontiguousarray(z, dtype=np.uint64)
+    fn = load().oracle_r1cs_first_unsatisfied
+    fn.restype = ctypes.c_long
+    return int(fn(*args, _p(zz), ctypes.c_size_t(n)))
+
+
 def groth16_prove(pk, z, n_primary, h, r_m, s_m, chunks=None):
     zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(-1, 6)
     hh = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 6)

@@ -1,0 +1,85 @@
+"""The wrapping (aggregator) circuit on the host: structure, witness, public inputs.  Mirrors the checks of the
+reference's libzecale/tests/aggregator/aggregator_dummy_test.cpp:64-96 that do not need a proof:
+  input[0] == compute_hash(vk), input[1] == packed result bits ({1,1} valid / {1,0} when the 2nd nested input is
+  bumped, :162-186), inputs[2..] == nested inputs; plus: the assignment satisfies every constraint (CPU oracle), and
+  verification_key_hash_gadget_test.cpp:20-47 (hash non-zero, differs between keys).
+Nested proofs and key are the reference's own fixtures (testdata/dummy_app/vk.json, extproof1..6.json).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import pyref as R
+from tests.helpers import fr_int, fr_limbs
+from tests.test_oracle_pins import load_nested_fixtures
+
+
+def _fl(x):
+    return R.int_to_limbs(R.to_mont(x % R.BLS_Q, R.BLS_Q, 6), 6)
+
+
+def g1_limbs(p):
+    return _fl(p[0]) + _fl(p[1])
+
+
+def g2_limbs(p):
+    return _fl(p[0][0]) + _fl(p[0][1]) + _fl(p[1][0]) + _fl(p[1][1])
+
+
+def nested_vk_limbs(nvk):
+    return np.array(g1_limbs(nvk["alpha"]) + g2_limbs(nvk["beta"]) + g2_limbs(nvk["delta"]) + sum((g1_limbs(p) for p in nvk["ABC"]), []),
+                    dtype=np.uint64)
+
+
+def nested_proof_limbs(pr):
+    return np.array(g1_limbs(pr["a"]) + g2_limbs(pr["b"]) + g1_limbs(pr["c"]), dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def circuit():
+    from zecale_amd import zkhip
+    return zkhip.AggregatorCircuit(2, 1)
+
+
+def test_native_nested_verifier_on_reference_fixtures():
+    from zecale_amd import zkhip
+    nvk, proofs = load_nested_fixtures()
+    vk = nested_vk_limbs(nvk)
+    for pr, inputs in proofs:
+        assert zkhip.bls12_377_groth16_verify(vk, np.array([fr_limbs(inputs[0])]), nested_proof_limbs(pr))
+    pr, inputs = proofs[2]
+    assert not zkhip.bls12_377_groth16_verify(vk, np.array([fr_limbs(inputs[0] + 1)]), nested_proof_limbs(pr))
+
+
+def test_circuit_shape(circuit):
+    assert circuit.num_primary_inputs() == 4          # 1 + 1 + 2 * 1 (aggregator_circuit.tcc:172-180)
+    assert 20000 < circuit.num_constraints < 200000
+    A, B, C = circuit.get_constraint_system()
+    assert len(A[0]) == circuit.num_constraints + 1
+    assert int(max(A[1].max(), B[1].max(), C[1].max())) < circuit.num_variables
+
+
+@pytest.mark.parametrize("bump_second", [False, True])
+def test_witness_and_public_inputs(circuit, oracle_lib, bump_second):
+    from zecale_amd import zkhip
+    nvk, proofs = load_nested_fixtures()
+    vk = nested_vk_limbs(nvk)
+    (p1, in1), (p2, in2) = proofs[0], proofs[1]       # a = 7, 8 (fees 12, 11: the first batch, scripts/test-client:67-70)
+    x1, x2 = in1[0], in2[0] + (1 if bump_second else 0)
+    z = circuit.witness(vk, np.concatenate([nested_proof_limbs(p1), nested_proof_limbs(p2)]), np.array([fr_limbs(x1), fr_limbs(x2)]))
+    A, B, C = circuit.get_constraint_system()
+    assert oracle_lib.r1cs_first_unsatisfied(A, B, C, z) == -1
+    assert fr_int(z[0]) == 1
+    assert (z[1] == zkhip.aggregator_vk_hash(vk, 1)).all() and fr_int(z[1]) != 0
+    assert fr_int(z[2]) == (1 if bump_second else 3)     # results packed LSB-first: {1,1} -> 3, {1,0} -> 1
+    assert fr_int(z[3]) == x1 and fr_int(z[4]) == x2
+    # a corrupted assignment is rejected
+    zb = z.copy(); zb[2] = fr_limbs(fr_int(z[2]) ^ 2)
+    assert oracle_lib.r1cs_first_unsatisfied(A, B, C, zb) >= 0
+
+
+def test_vk_hash_differs_between_keys():
+    from zecale_amd import zkhip
+    nvk, _ = load_nested_fixtures()
+    h1 = zkhip.aggregator_vk_hash(nested_vk_limbs(nvk), 1)
+    nvk2 = dict(nvk); nvk2["alpha"] = nvk["ABC"][0]
+    h2 = zkhip.aggregator_vk_hash(nested_vk_limbs(nvk2), 1)
+    assert fr_int(h1) != 0 and fr_int(h2) != 0 and fr_int(h1) != fr_int(h2)

@@ -44,3 +44,181 @@ extern "C" int zkhip_bls12_377_groth16_verify(const uint64_t vk_alpha_g1[12], co
   }
   return ZKHIP_OK;
 }
+
+// ================================================================================================
+// The wrapping ("aggregator") circuit.  Mirrors libzecale::aggregator_circuit<wppT, wsnarkT, nverifierT, NumProofs>
+// (libzecale/circuits/aggregator_circuit.hpp:32-114, .tcc:17-180) and aggregator_gadget (.tcc:13-112):
+//   primary inputs, allocated first (aggregator_circuit.hpp:19-31, .tcc:172-180):
+//     [ hash of the nested verification key, packed verification results (LSB = proof 0),
+//       nested primary inputs of proof 0, ..., of proof NumProofs-1 ]
+//   auxiliary: the nested verification key, the nested proofs, 253 bits per nested input
+//     (aggregator_gadget.tcc:42), and every intermediate of the in-circuit Groth16 verifications.
+//   The result bits are NOT enforced to be 1: an invalid nested proof yields a valid wrapping proof whose
+//   result bit is 0 (aggregator_circuit.hpp:51-54; aggregator_dummy_test.cpp:162-186).
+// ================================================================================================
+#include "circuit/mimc.hpp"
+
+struct zkhip_aggregator {
+  size_t num_proofs, inputs_per_proof;
+  size_t n_vars = 0, n_primary = 0, n_constraints = 0;
+  std::vector<uint32_t> rp[3], col[3];
+  std::vector<uint64_t> val[3];
+  std::mutex mu;
+};
+
+namespace {
+
+constexpr int NESTED_INPUT_BITS = 253;   // Fr of BLS12-377 (aggregator_gadget.tcc:42)
+
+template <class F> std::vector<F> vk_all_vars(const NestedVk<F>& vk) {
+  std::vector<F> v = {vk.alpha.x, vk.alpha.y, vk.beta.x.c0, vk.beta.x.c1, vk.beta.y.c0, vk.beta.y.c1,
+                      vk.delta.x.c0, vk.delta.x.c1, vk.delta.y.c0, vk.delta.y.c1};
+  for (const auto& p : vk.abc) { v.push_back(p.x); v.push_back(p.y); }
+  return v;
+}
+
+struct NestedData {
+  const uint64_t* vk;        // alpha (12) | beta (24) | delta (24) | abc ((k+1) x 12)
+  const uint64_t* proofs;    // num_proofs x [a (12) | b (24) | c (12)]
+  const uint64_t* inputs;    // num_proofs x k x 6
+};
+
+// One pass over the circuit: emits constraints when b.record, always fills b.z.
+void synthesize(Builder& b, size_t num_proofs, size_t k, const NestedData* data) {
+  current_builder() = &b;
+  static const uint64_t zeros[48 * 8] = {0};
+  auto limbs = [&](const uint64_t* p, size_t off) { return data ? p + off : zeros; };
+  // --- primary inputs first
+  CV vk_hash = CV::witness(HFr::zero());                 // value patched below
+  CV packed = CV::witness(HFr::zero());
+  std::vector<std::vector<CV>> nin(num_proofs);
+  std::vector<std::vector<HFr>> nin_val(num_proofs);
+  for (size_t p = 0; p < num_proofs; p++)
+    for (size_t j = 0; j < k; j++) {
+      HFr v = HFr::from_limbs(limbs(data ? data->inputs : nullptr, (p * k + j) * 6));
+      nin_val[p].push_back(v);
+      nin[p].push_back(CV::witness(v));
+    }
+  // --- auxiliary: nested key and proofs
+  NestedVk<CV> vk;
+  const uint64_t* vkp = data ? data->vk : nullptr;
+  vk.alpha = g1_from<CV>(limbs(vkp, 0), true);
+  vk.beta = g2_from<CV>(limbs(vkp, 12), true);
+  vk.delta = g2_from<CV>(limbs(vkp, 36), true);
+  for (size_t i = 0; i <= k; i++) vk.abc.push_back(g1_from<CV>(limbs(vkp, 60 + i * 12), true));
+  std::vector<NestedProof<CV>> proofs;
+  for (size_t p = 0; p < num_proofs; p++) {
+    const uint64_t* pp = data ? data->proofs : nullptr;
+    proofs.push_back(NestedProof<CV>{g1_from<CV>(limbs(pp, p * 48), true), g2_from<CV>(limbs(pp, p * 48 + 12), true),
+                                     g1_from<CV>(limbs(pp, p * 48 + 36), true)});
+  }
+  // --- hash of the key = primary input 0
+  CV h = mimc_hash(vk_all_vars(vk));
+  CV::assert_eq(vk_hash, h);
+  b.z[vk_hash.lc[0].var] = h.val;
+  // --- per proof: input bits, accumulator, verification bit
+  CV packed_lc;
+  HFr pow2 = HFr::one();
+  for (size_t p = 0; p < num_proofs; p++) {
+    std::vector<std::vector<CV>> bits(k);
+    for (size_t j = 0; j < k; j++) {
+      uint64_t c[6];
+      nin_val[p][j].to_canonical(c);
+      CV sum;
+      HFr w = HFr::one();
+      for (int t = 0; t < NESTED_INPUT_BITS; t++) {
+        CV bit = CV::witness_bit((c[t / 64] >> (t % 64)) & 1);
+        bits[j].push_back(bit);
+        sum = sum + bit.mulc(w);
+        w = w + w;
+      }
+      CV::assert_eq(sum, nin[p][j]);                      // packing (multipacking_gadget in the reference)
+    }
+    G1<CV> acc = input_accumulator(vk, bits);
+    CV res = groth16_verify_bit(vk, proofs[p], acc);
+    packed_lc = packed_lc + res.mulc(pow2);
+    pow2 = pow2 + pow2;
+  }
+  CV::assert_eq(packed, packed_lc);                       // packing_gadget::generate_r1cs_witness_from_bits (.tcc:157)
+  b.z[packed.lc[0].var] = packed_lc.val;
+  current_builder() = nullptr;
+}
+
+void to_csr(const std::vector<LC>& M, std::vector<uint32_t>& rp, std::vector<uint32_t>& col, std::vector<uint64_t>& val) {
+  rp.assign(1, 0);
+  for (const LC& row : M) {
+    for (const Term& t : row) {
+      col.push_back(t.var);
+      uint64_t l[6];
+      t.coeff.to_limbs(l);
+      val.insert(val.end(), l, l + 6);
+    }
+    rp.push_back((uint32_t)col.size());
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkhip_aggregator_new(size_t num_proofs, size_t inputs_per_proof, zkhip_aggregator** out) {
+  if (!out || num_proofs == 0 || num_proofs > 16 || inputs_per_proof == 0 || inputs_per_proof > 8) return ZKHIP_ERR_ARG;
+  zkhip_aggregator* a = new zkhip_aggregator();
+  a->num_proofs = num_proofs; a->inputs_per_proof = inputs_per_proof;
+  Builder b;
+  b.record = true;
+  synthesize(b, num_proofs, inputs_per_proof, nullptr);
+  a->n_vars = b.z.size();
+  a->n_primary = 2 + num_proofs * inputs_per_proof;       // aggregator_circuit.tcc:172-180
+  a->n_constraints = b.num_constraints();
+  to_csr(b.A, a->rp[0], a->col[0], a->val[0]);
+  to_csr(b.B, a->rp[1], a->col[1], a->val[1]);
+  to_csr(b.C, a->rp[2], a->col[2], a->val[2]);
+  *out = a;
+  return ZKHIP_OK;
+}
+
+void zkhip_aggregator_free(zkhip_aggregator* a) { delete a; }
+size_t zkhip_aggregator_num_constraints(const zkhip_aggregator* a) { return a ? a->n_constraints : 0; }
+size_t zkhip_aggregator_num_variables(const zkhip_aggregator* a) { return a ? a->n_vars : 0; }
+size_t zkhip_aggregator_num_primary_inputs(const zkhip_aggregator* a) { return a ? a->n_primary : 0; }
+
+int zkhip_aggregator_get_r1cs(const zkhip_aggregator* a, zkhip_r1cs_desc* d) {
+  if (!a || !d) return ZKHIP_ERR_ARG;
+  d->n_constraints = a->n_constraints; d->n_vars = a->n_vars; d->n_primary = a->n_primary;
+  d->a_row_ptr = a->rp[0].data(); d->a_col = a->col[0].data(); d->a_val = a->val[0].data();
+  d->b_row_ptr = a->rp[1].data(); d->b_col = a->col[1].data(); d->b_val = a->val[1].data();
+  d->c_row_ptr = a->rp[2].data(); d->c_col = a->col[2].data(); d->c_val = a->val[2].data();
+  return ZKHIP_OK;
+}
+
+int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, const uint64_t* nested_proofs,
+                             const uint64_t* nested_inputs, uint64_t* z_out) {
+  if (!a || !nested_vk || !nested_proofs || !nested_inputs || !z_out) return ZKHIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(a->mu);
+  Builder b;
+  b.record = false;
+  NestedData d{nested_vk, nested_proofs, nested_inputs};
+  try {
+    synthesize(b, a->num_proofs, a->inputs_per_proof, &d);
+  } catch (const std::exception&) {
+    current_builder() = nullptr;
+    return ZKHIP_ERR_ARG;
+  }
+  if (b.z.size() != a->n_vars) return ZKHIP_ERR_STATE;
+  for (size_t i = 0; i < b.z.size(); i++) b.z[i].to_limbs(z_out + i * 6);
+  return ZKHIP_OK;
+}
+
+int zkhip_aggregator_vk_hash(const uint64_t* nested_vk, size_t inputs_per_proof, uint64_t out[6]) {
+  if (!nested_vk || !out) return ZKHIP_ERR_ARG;
+  NestedVk<NF> vk;
+  vk.alpha = g1_from<NF>(nested_vk, false);
+  vk.beta = g2_from<NF>(nested_vk + 12, false);
+  vk.delta = g2_from<NF>(nested_vk + 36, false);
+  for (size_t i = 0; i <= inputs_per_proof; i++) vk.abc.push_back(g1_from<NF>(nested_vk + 60 + i * 12, false));
+  mimc_hash(vk_all_vars(vk)).value().to_limbs(out);
+  return ZKHIP_OK;
+}
+
+}  // extern "C"

@@ -17,6 +17,9 @@ EXPORTS = [
     "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
     "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings", "zkhip_groth16_verify",
+    "zkhip_bls12_377_groth16_verify", "zkhip_aggregator_new", "zkhip_aggregator_free", "zkhip_aggregator_num_constraints",
+    "zkhip_aggregator_num_variables", "zkhip_aggregator_num_primary_inputs", "zkhip_aggregator_get_r1cs",
+    "zkhip_aggregator_witness", "zkhip_aggregator_vk_hash",
     "zkhip_jac_to_affine", "zkhip_jac_add",
 ]
 
@@ -263,6 +266,70 @@ def groth16_verify(vk, inputs, proof):
     _check(load().zkhip_groth16_verify(_p(c(vk["alpha"])), _p(c(vk["beta"])), _p(c(vk["delta"])), _p(abc), _p(inp), inp.shape[0],
                                        _p(c(proof)), ctypes.byref(ok)))
     return bool(ok.value)
+
+
+def bls12_377_groth16_verify(nested_vk, inputs, proof):
+    """Nested (BLS12-377) Groth16 verification on the host.  nested_vk: 60 + 12 (k+1) limbs (alpha | beta | delta | ABC);
+    inputs: k x 6 limbs; proof: 48 limbs (a | b | c)."""
+    c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+    vk, pr, inp = c(nested_vk), c(proof), c(inputs).reshape(-1, 6)
+    assert vk.size == 60 + 12 * (inp.shape[0] + 1) and pr.size == 48
+    ok = ctypes.c_int(0)
+    _check(load().zkhip_bls12_377_groth16_verify(_p(vk[:12]), _p(vk[12:36]), _p(vk[36:60]), _p(vk[60:]), _p(inp), inp.shape[0],
+                                                 _p(pr[:12]), _p(pr[12:36]), _p(pr[36:]), ctypes.byref(ok)))
+    return bool(ok.value)
+
+
+class AggregatorCircuit:
+    """Mirror of libzecale::aggregator_circuit<wpp, wsnark, nverifier, NumProofs> (aggregator_circuit.hpp:32-114):
+    builds the wrapping circuit on construction; `witness` performs the generate_r1cs_witness half of prove()."""
+
+    def __init__(self, num_proofs=2, inputs_per_nested_proof=1):
+        h = ctypes.c_void_p()
+        _check(load().zkhip_aggregator_new(num_proofs, inputs_per_nested_proof, ctypes.byref(h)))
+        self.handle = h
+        self.num_proofs, self.inputs_per_nested_proof = num_proofs, inputs_per_nested_proof
+        lib = load()
+        self.num_constraints = lib.zkhip_aggregator_num_constraints(h)
+        self.num_variables = lib.zkhip_aggregator_num_variables(h)
+
+    def num_primary_inputs(self):
+        return load().zkhip_aggregator_num_primary_inputs(self.handle)
+
+    def get_constraint_system(self):
+        """CSR triples (row_ptr, col, val) of A, B, C as numpy arrays (copies)."""
+        d = R1csDesc()
+        _check(load().zkhip_aggregator_get_r1cs(self.handle, ctypes.byref(d)))
+        out = []
+        for m in "abc":
+            n = d.n_constraints
+            rp = np.ctypeslib.as_array(ctypes.cast(getattr(d, m + "_row_ptr"), ctypes.POINTER(ctypes.c_uint32)), (n + 1,)).copy()
+            nnz = int(rp[-1])
+            col = np.ctypeslib.as_array(ctypes.cast(getattr(d, m + "_col"), ctypes.POINTER(ctypes.c_uint32)), (nnz,)).copy()
+            val = np.ctypeslib.as_array(ctypes.cast(getattr(d, m + "_val"), ctypes.POINTER(ctypes.c_uint64)), (nnz, 6)).copy()
+            out.append((rp, col, val))
+        return out
+
+    def witness(self, nested_vk, nested_proofs, nested_inputs):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+        vk, pr, inp = c(nested_vk), c(nested_proofs), c(nested_inputs)
+        k = self.inputs_per_nested_proof
+        assert vk.size == 60 + 12 * (k + 1) and pr.size == 48 * self.num_proofs and inp.size == 6 * k * self.num_proofs
+        z = np.zeros((self.num_variables, 6), dtype=np.uint64)
+        _check(load().zkhip_aggregator_witness(self.handle, _p(vk), _p(pr), _p(inp), _p(z)))
+        return z
+
+    def free(self):
+        if self.handle:
+            load().zkhip_aggregator_free(self.handle)
+            self.handle = None
+
+
+def aggregator_vk_hash(nested_vk, inputs_per_nested_proof=1):
+    vk = np.ascontiguousarray(nested_vk, dtype=np.uint64).reshape(-1)
+    out = np.zeros(6, dtype=np.uint64)
+    _check(load().zkhip_aggregator_vk_hash(_p(vk), inputs_per_nested_proof, _p(out)))
+    return out
 
 
 def last_prove_timings():
