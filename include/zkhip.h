@@ -163,6 +163,21 @@ int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, con
 /* replaces: verification_key_hash_gadget::compute_hash(vk, num_inputs) (verification_key_hash_gadget.tcc:42-59) */
 int zkhip_aggregator_vk_hash(const uint64_t* nested_vk, size_t inputs_per_proof, uint64_t out[6]);
 
+/* replaces: wsnarkT::generate_setup(pb) = libsnark::r1cs_gg_ppzksnark_generator, reached from
+ * aggregator_circuit::generate_trusted_setup (libzecale/circuits/aggregator_circuit.tcc:100-109).
+ * QAP evaluation at tau on the host, the batch exponentiations on the GPU (zkhip_fixed_base_mul).
+ * The toxic waste is an argument so that tests can reproduce keys; a deployment passes fresh randomness and
+ * forgets it.  All four scalars: 6 limbs, Montgomery form, non-zero. */
+typedef struct zkhip_keypair zkhip_keypair;
+int zkhip_groth16_setup(const zkhip_r1cs_desc* cs, const uint64_t tau[6], const uint64_t alpha[6], const uint64_t beta[6],
+                        const uint64_t delta[6], zkhip_keypair** out);
+/* proving half: pointers into the keypair (valid while it lives) */
+int zkhip_keypair_crs_desc(const zkhip_keypair* kp, zkhip_crs_desc* out);
+/* verification half: alpha (G1), beta, delta (G2), abc = (n_primary + 1) x 24 limbs; returns n_primary + 1 */
+size_t zkhip_keypair_vk(const zkhip_keypair* kp, uint64_t alpha_g1[24], uint64_t beta_g2[24], uint64_t delta_g2[24],
+                        const uint64_t** abc);
+void zkhip_keypair_free(zkhip_keypair* kp);
+
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
 

@@ -12,6 +12,7 @@
 #include "pairing_host.hpp"
 #include <chrono>
 #include <future>
+#include <vector>
 
 using namespace zkhip;
 
@@ -29,6 +30,11 @@ struct zkhip_crs {
   size_t n_vars, n_primary, domain_size;
   zkhip_bases *A, *B2, *B1, *H, *L;
   uint64_t alpha_g1[24], beta_g1[24], beta_g2[24], delta_g1[24], delta_g2[24];
+};
+
+struct zkhip_keypair {
+  size_t n_vars, n_primary, domain_size;
+  std::vector<uint64_t> alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, A, B2, B1, H, L, ABC;
 };
 
 namespace {
@@ -441,6 +447,100 @@ int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_
   *ok = pairing_product_is_one(p1, p2) ? 1 : 0;
   return ZKHIP_OK;
 }
+
+int zkhip_groth16_setup(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], const uint64_t alpha_m[6], const uint64_t beta_m[6],
+                        const uint64_t delta_m[6], zkhip_keypair** out) {
+  using namespace host;
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!cs || !tau_m || !alpha_m || !beta_m || !delta_m || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  const size_t n = cs->n_constraints, m = cs->n_vars, l = cs->n_primary;
+  if (m < l + 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
+  int lg = 0;
+  while (((size_t)1 << lg) < n + l + 1) lg++;
+  if (lg > 22) return fail(ZKHIP_ERR_ARG, "domain larger than 2^22");
+  const size_t d = (size_t)1 << lg;
+  HFr tau = HFr::from_limbs(tau_m), alpha = HFr::from_limbs(alpha_m), beta = HFr::from_limbs(beta_m), delta = HFr::from_limbs(delta_m);
+  if (delta.is_zero()) return fail(ZKHIP_ERR_ARG, "delta must be invertible");
+  // Lagrange basis at tau: L_j(tau) = Z(tau) w^j / (d (tau - w^j)), one batch inversion
+  HFr omega = HFr::from_limbs(FrParams::ROOT_2_46_64);
+  for (int i = 0; i < FrParams::TWO_ADICITY - lg; i++) omega = omega.sqr();
+  uint64_t e[1] = {(uint64_t)d};
+  HFr Zt = tau.pow_limbs(e, 1) - HFr::one();
+  std::vector<HFr> w(d), den(d), pref(d);
+  HFr acc = HFr::one(), wj = HFr::one();
+  for (size_t j = 0; j < d; j++) {
+    w[j] = wj; den[j] = tau - wj;
+    if (den[j].is_zero()) return fail(ZKHIP_ERR_ARG, "tau lies in the evaluation domain");
+    pref[j] = acc; acc = acc * den[j]; wj = wj * omega;
+  }
+  HFr inv_all = acc.inv(), dinv = HFr::from_u64((uint64_t)d).inv();
+  std::vector<HFr> Lg(d);
+  for (size_t j = d; j-- > 0;) {
+    HFr dj_inv = inv_all * pref[j];
+    inv_all = inv_all * den[j];
+    Lg[j] = Zt * w[j] * dinv * dj_inv;
+  }
+  std::vector<HFr> At(m, HFr::zero()), Bt(m, HFr::zero()), Ct(m, HFr::zero());
+  auto accumulate = [&](const uint32_t* rp, const uint32_t* col, const uint64_t* val, std::vector<HFr>& out_) {
+    for (size_t j = 0; j < n; j++)
+      for (uint32_t k = rp[j]; k < rp[j + 1]; k++) out_[col[k]] = out_[col[k]] + HFr::from_limbs(val + (size_t)k * 6) * Lg[j];
+  };
+  accumulate(cs->a_row_ptr, cs->a_col, cs->a_val, At);
+  accumulate(cs->b_row_ptr, cs->b_col, cs->b_val, Bt);
+  accumulate(cs->c_row_ptr, cs->c_col, cs->c_val, Ct);
+  for (size_t k = 0; k <= l; k++) At[k] = At[k] + Lg[n + k];          // input-consistency rows
+  HFr delta_inv = delta.inv();
+  // scalar vectors -> limbs
+  auto pack = [](const std::vector<HFr>& v) { std::vector<uint64_t> o(v.size() * 6); for (size_t i = 0; i < v.size(); i++) v[i].to_limbs(&o[i * 6]); return o; };
+  std::vector<HFr> hs(d - 1), ls(m - l - 1), abc(l + 1), single(3);
+  HFr t = Zt * delta_inv;
+  for (size_t j = 0; j + 1 < d; j++) { hs[j] = t; t = t * tau; }
+  for (size_t i = l + 1; i < m; i++) ls[i - l - 1] = (beta * At[i] + alpha * Bt[i] + Ct[i]) * delta_inv;
+  for (size_t i = 0; i <= l; i++) abc[i] = beta * At[i] + alpha * Bt[i] + Ct[i];
+  single[0] = alpha; single[1] = beta; single[2] = delta;
+  uint64_t g1[24], g2[24];
+  memcpy(g1, FqParams::G1_GEN_X64, 96); memcpy(g1 + 12, FqParams::G1_GEN_Y64, 96);
+  memcpy(g2, FqParams::G2_GEN_X64, 96); memcpy(g2 + 12, FqParams::G2_GEN_Y64, 96);
+  zkhip_keypair* kp = new zkhip_keypair();
+  kp->n_vars = m; kp->n_primary = l; kp->domain_size = d;
+  auto fb = [&](const uint64_t* base, const std::vector<HFr>& sc, std::vector<uint64_t>& dst) -> int {
+    dst.assign(sc.size() * 24, 0);
+    if (sc.empty()) return ZKHIP_OK;
+    std::vector<uint64_t> s = pack(sc);
+    return zkhip_fixed_base_mul(base, s.data(), sc.size(), 1, dst.data());
+  };
+  int rc;
+  std::vector<uint64_t> s1, s2;
+  if ((rc = fb(g1, single, s1)) != ZKHIP_OK || (rc = fb(g2, single, s2)) != ZKHIP_OK || (rc = fb(g1, At, kp->A)) != ZKHIP_OK ||
+      (rc = fb(g2, Bt, kp->B2)) != ZKHIP_OK || (rc = fb(g1, Bt, kp->B1)) != ZKHIP_OK || (rc = fb(g1, hs, kp->H)) != ZKHIP_OK ||
+      (rc = fb(g1, ls, kp->L)) != ZKHIP_OK || (rc = fb(g1, abc, kp->ABC)) != ZKHIP_OK) {
+    delete kp;
+    return rc;
+  }
+  kp->alpha_g1.assign(s1.begin(), s1.begin() + 24); kp->beta_g1.assign(s1.begin() + 24, s1.begin() + 48);
+  kp->delta_g1.assign(s1.begin() + 48, s1.begin() + 72);
+  kp->beta_g2.assign(s2.begin() + 24, s2.begin() + 48); kp->delta_g2.assign(s2.begin() + 48, s2.begin() + 72);
+  *out = kp;
+  return ZKHIP_OK;
+}
+
+int zkhip_keypair_crs_desc(const zkhip_keypair* kp, zkhip_crs_desc* o) {
+  if (!kp || !o) return ZKHIP_ERR_ARG;
+  o->n_vars = kp->n_vars; o->n_primary = kp->n_primary; o->domain_size = kp->domain_size;
+  o->alpha_g1 = kp->alpha_g1.data(); o->beta_g1 = kp->beta_g1.data(); o->beta_g2 = kp->beta_g2.data();
+  o->delta_g1 = kp->delta_g1.data(); o->delta_g2 = kp->delta_g2.data();
+  o->a_query = kp->A.data(); o->b_g2_query = kp->B2.data(); o->b_g1_query = kp->B1.data(); o->h_query = kp->H.data(); o->l_query = kp->L.data();
+  return ZKHIP_OK;
+}
+
+size_t zkhip_keypair_vk(const zkhip_keypair* kp, uint64_t alpha_g1[24], uint64_t beta_g2[24], uint64_t delta_g2[24], const uint64_t** abc) {
+  if (!kp || !alpha_g1 || !beta_g2 || !delta_g2 || !abc) return 0;
+  memcpy(alpha_g1, kp->alpha_g1.data(), 192); memcpy(beta_g2, kp->beta_g2.data(), 192); memcpy(delta_g2, kp->delta_g2.data(), 192);
+  *abc = kp->ABC.data();
+  return kp->n_primary + 1;
+}
+
+void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 
 float zkhip_last_accumulate_ms(void) { return g.msm_ready ? g.msm.last_accumulate_ms : 0.f; }
 

@@ -20,12 +20,16 @@ EXPORTS = [
     "zkhip_bls12_377_groth16_verify", "zkhip_aggregator_new", "zkhip_aggregator_free", "zkhip_aggregator_num_constraints",
     "zkhip_aggregator_num_variables", "zkhip_aggregator_num_primary_inputs", "zkhip_aggregator_get_r1cs",
     "zkhip_aggregator_witness", "zkhip_aggregator_vk_hash",
+    "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free",
     "zkhip_jac_to_affine", "zkhip_jac_add",
 ]
 
 
 class ZkhipError(RuntimeError):
     pass
+
+
+c_u64p_t = ctypes.POINTER(ctypes.c_uint64)
 
 
 class R1csDesc(ctypes.Structure):
@@ -323,6 +327,53 @@ class AggregatorCircuit:
         if self.handle:
             load().zkhip_aggregator_free(self.handle)
             self.handle = None
+
+
+class Keypair:
+    """Groth16 keypair from a trusted setup on the GPU (mirror of wsnark::generate_setup / keypair)."""
+
+    def __init__(self, r1cs_desc, tau, alpha, beta, delta):
+        h = ctypes.c_void_p()
+        c = lambda a: _p(np.ascontiguousarray(a, dtype=np.uint64))
+        _check(load().zkhip_groth16_setup(ctypes.byref(r1cs_desc), c(tau), c(alpha), c(beta), c(delta), ctypes.byref(h)))
+        self.handle = h
+
+    def upload_crs(self):
+        d = CrsDesc()
+        _check(load().zkhip_keypair_crs_desc(self.handle, ctypes.byref(d)))
+        crs = Crs.__new__(Crs)
+        h = ctypes.c_void_p()
+        _check(load().zkhip_crs_upload(ctypes.byref(d), ctypes.byref(h)))
+        crs.handle = h
+        return crs
+
+    def vk(self):
+        a, b, dl = (np.zeros(24, dtype=np.uint64) for _ in range(3))
+        abc = c_u64p_t()
+        n = load().zkhip_keypair_vk(self.handle, _p(a), _p(b), _p(dl), ctypes.byref(abc))
+        return dict(alpha=a, beta=b, delta=dl, ABC=np.ctypeslib.as_array(abc, (n, 24)).copy())
+
+    def free(self):
+        if self.handle:
+            load().zkhip_keypair_free(self.handle)
+            self.handle = None
+
+
+def r1cs_desc_from_aggregator(agg):
+    d = R1csDesc()
+    _check(load().zkhip_aggregator_get_r1cs(agg.handle, ctypes.byref(d)))
+    return d
+
+
+def r1cs_from_desc(desc):
+    """Upload a constraint system described by a zkhip_r1cs_desc (e.g. the aggregator circuit's)."""
+    r = R1cs.__new__(R1cs)
+    h = ctypes.c_void_p()
+    _check(load().zkhip_r1cs_upload(ctypes.byref(desc), ctypes.byref(h)))
+    r.handle, r._keep = h, []
+    r.n_vars, r.n_primary, r.n_constraints = desc.n_vars, desc.n_primary, desc.n_constraints
+    r.log_d = int(load().zkhip_r1cs_log_domain(h))
+    return r
 
 
 def aggregator_vk_hash(nested_vk, inputs_per_nested_proof=1):
