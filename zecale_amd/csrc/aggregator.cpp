@@ -83,64 +83,66 @@ struct NestedData {
   const uint64_t* inputs;    // num_proofs x k x 6
 };
 
-// One pass over the circuit: emits constraints when b.record, always fills b.z.
+// One pass over the circuit with V = CV (constraints + assignment) or V = WV (assignment only, native speed).
+// WV cannot name its variables, so the two deferred primary values are patched by index: variables 1 and 2.
+template <class V>
 void synthesize(Builder& b, size_t num_proofs, size_t k, const NestedData* data) {
   current_builder() = &b;
   static const uint64_t zeros[48 * 8] = {0};
   auto limbs = [&](const uint64_t* p, size_t off) { return data ? p + off : zeros; };
   // --- primary inputs first
-  CV vk_hash = CV::witness(HFr::zero());                 // value patched below
-  CV packed = CV::witness(HFr::zero());
-  std::vector<std::vector<CV>> nin(num_proofs);
+  V vk_hash = V::witness(HFr::zero());                   // variable 1, value patched below
+  V packed = V::witness(HFr::zero());                    // variable 2
+  std::vector<std::vector<V>> nin(num_proofs);
   std::vector<std::vector<HFr>> nin_val(num_proofs);
   for (size_t p = 0; p < num_proofs; p++)
     for (size_t j = 0; j < k; j++) {
       HFr v = HFr::from_limbs(limbs(data ? data->inputs : nullptr, (p * k + j) * 6));
       nin_val[p].push_back(v);
-      nin[p].push_back(CV::witness(v));
+      nin[p].push_back(V::witness(v));
     }
   // --- auxiliary: nested key and proofs
-  NestedVk<CV> vk;
+  NestedVk<V> vk;
   const uint64_t* vkp = data ? data->vk : nullptr;
-  vk.alpha = g1_from<CV>(limbs(vkp, 0), true);
-  vk.beta = g2_from<CV>(limbs(vkp, 12), true);
-  vk.delta = g2_from<CV>(limbs(vkp, 36), true);
-  for (size_t i = 0; i <= k; i++) vk.abc.push_back(g1_from<CV>(limbs(vkp, 60 + i * 12), true));
-  std::vector<NestedProof<CV>> proofs;
+  vk.alpha = g1_from<V>(limbs(vkp, 0), true);
+  vk.beta = g2_from<V>(limbs(vkp, 12), true);
+  vk.delta = g2_from<V>(limbs(vkp, 36), true);
+  for (size_t i = 0; i <= k; i++) vk.abc.push_back(g1_from<V>(limbs(vkp, 60 + i * 12), true));
+  std::vector<NestedProof<V>> proofs;
   for (size_t p = 0; p < num_proofs; p++) {
     const uint64_t* pp = data ? data->proofs : nullptr;
-    proofs.push_back(NestedProof<CV>{g1_from<CV>(limbs(pp, p * 48), true), g2_from<CV>(limbs(pp, p * 48 + 12), true),
-                                     g1_from<CV>(limbs(pp, p * 48 + 36), true)});
+    proofs.push_back(NestedProof<V>{g1_from<V>(limbs(pp, p * 48), true), g2_from<V>(limbs(pp, p * 48 + 12), true),
+                                    g1_from<V>(limbs(pp, p * 48 + 36), true)});
   }
   // --- hash of the key = primary input 0
-  CV h = mimc_hash(vk_all_vars(vk));
-  CV::assert_eq(vk_hash, h);
-  b.z[vk_hash.lc[0].var] = h.val;
+  V h = mimc_hash(vk_all_vars(vk));
+  V::assert_eq(vk_hash, h);
+  b.z[1] = h.value();
   // --- per proof: input bits, accumulator, verification bit
-  CV packed_lc;
+  V packed_lc;
   HFr pow2 = HFr::one();
   for (size_t p = 0; p < num_proofs; p++) {
-    std::vector<std::vector<CV>> bits(k);
+    std::vector<std::vector<V>> bits(k);
     for (size_t j = 0; j < k; j++) {
       uint64_t c[6];
       nin_val[p][j].to_canonical(c);
-      CV sum;
+      V sum;
       HFr w = HFr::one();
       for (int t = 0; t < NESTED_INPUT_BITS; t++) {
-        CV bit = CV::witness_bit((c[t / 64] >> (t % 64)) & 1);
+        V bit = V::witness_bit((c[t / 64] >> (t % 64)) & 1);
         bits[j].push_back(bit);
         sum = sum + bit.mulc(w);
         w = w + w;
       }
-      CV::assert_eq(sum, nin[p][j]);                      // packing (multipacking_gadget in the reference)
+      V::assert_eq(sum, nin[p][j]);                       // packing (multipacking_gadget in the reference)
     }
-    G1<CV> acc = input_accumulator(vk, bits);
-    CV res = groth16_verify_bit(vk, proofs[p], acc);
+    G1<V> acc = input_accumulator(vk, bits);
+    V res = groth16_verify_bit(vk, proofs[p], acc);
     packed_lc = packed_lc + res.mulc(pow2);
     pow2 = pow2 + pow2;
   }
-  CV::assert_eq(packed, packed_lc);                       // packing_gadget::generate_r1cs_witness_from_bits (.tcc:157)
-  b.z[packed.lc[0].var] = packed_lc.val;
+  V::assert_eq(packed, packed_lc);                        // packing_gadget::generate_r1cs_witness_from_bits (.tcc:157)
+  b.z[2] = packed_lc.value();
   current_builder() = nullptr;
 }
 
@@ -167,7 +169,7 @@ int zkhip_aggregator_new(size_t num_proofs, size_t inputs_per_proof, zkhip_aggre
   a->num_proofs = num_proofs; a->inputs_per_proof = inputs_per_proof;
   Builder b;
   b.record = true;
-  synthesize(b, num_proofs, inputs_per_proof, nullptr);
+  synthesize<CV>(b, num_proofs, inputs_per_proof, nullptr);
   a->n_vars = b.z.size();
   a->n_primary = 2 + num_proofs * inputs_per_proof;       // aggregator_circuit.tcc:172-180
   a->n_constraints = b.num_constraints();
@@ -200,7 +202,7 @@ int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, con
   b.record = false;
   NestedData d{nested_vk, nested_proofs, nested_inputs};
   try {
-    synthesize(b, a->num_proofs, a->inputs_per_proof, &d);
+    synthesize<WV>(b, a->num_proofs, a->inputs_per_proof, &d);
   } catch (const std::exception&) {
     current_builder() = nullptr;
     return ZKHIP_ERR_ARG;

@@ -89,9 +89,12 @@ struct NF {
 };
 
 // ---- circuit instantiation -------------------------------------------------------------------
+// "Constant" is a STRUCTURAL property (built from constants only), tracked by an explicit flag with the same
+// propagation rules in CV and WV, so that both allocate variables in exactly the same order.
 struct CV {
   LC lc;
   HFr val;
+  bool cst = true;
   CV() : val(HFr::zero()) {}
   static CV constant(const HFr& c) {
     CV r;
@@ -103,6 +106,7 @@ struct CV {
     CV r;
     r.lc.push_back({current_builder()->alloc(value), HFr::one()});
     r.val = value;
+    r.cst = false;
     return r;
   }
   static CV witness_bit(bool b) {
@@ -112,12 +116,13 @@ struct CV {
     return r;
   }
   const HFr& value() const { return val; }
-  bool is_const() const { return lc.empty() || (lc.size() == 1 && lc[0].var == 0); }
+  bool is_const() const { return cst; }
   void compact() { if (lc.size() > 48) lc_normalise(lc); }
   CV operator+(const CV& o) const {
     CV r = *this;
     r.lc.insert(r.lc.end(), o.lc.begin(), o.lc.end());
     r.val = val + o.val;
+    r.cst = cst && o.cst;
     r.compact();
     return r;
   }
@@ -130,6 +135,7 @@ struct CV {
   }
   CV mulc(const HFr& c) const {
     CV r;
+    r.cst = cst;
     if (c.is_zero()) return r;
     r = *this;
     for (auto& t : r.lc) t.coeff = t.coeff * c;
@@ -150,7 +156,33 @@ struct CV {
   static void assert_product(const CV& a, const CV& b, const CV& c) { current_builder()->enforce(a.lc, b.lc, c.lc); }
 };
 
-// helpers shared by both instantiations
+// ---- witness-only instantiation: values and the const flag, no linear combinations ---------------------------
+// Replays exactly the allocations of CV (same code, same flag rules) at native speed: this is the
+// generate_r1cs_witness half of the reference's gadgets.
+struct WV {
+  HFr val;
+  bool cst = true;
+  WV() : val(HFr::zero()) {}
+  static WV constant(const HFr& c) { WV r; r.val = c; return r; }
+  static WV witness(const HFr& value) { WV r; r.val = value; r.cst = false; current_builder()->alloc(value); return r; }
+  static WV witness_bit(bool b) { return witness(b ? HFr::one() : HFr::zero()); }
+  const HFr& value() const { return val; }
+  bool is_const() const { return cst; }
+  WV operator+(const WV& o) const { WV r; r.val = val + o.val; r.cst = cst && o.cst; return r; }
+  WV operator-(const WV& o) const { WV r; r.val = val - o.val; r.cst = cst && o.cst; return r; }
+  WV neg() const { WV r; r.val = val.neg(); r.cst = cst; return r; }
+  WV mulc(const HFr& c) const { WV r; r.val = val * c; r.cst = cst; return r; }
+  WV operator*(const WV& o) const {
+    if (cst) return o.mulc(val);
+    if (o.cst) return mulc(o.val);
+    return witness(val * o.val);
+  }
+  static void assert_eq(const WV&, const WV&) {}
+  static void assert_product(const WV&, const WV&, const WV&) {}
+};
+inline bool f_is_const(const WV& x) { return x.cst; }
+
+// helpers shared by the instantiations
 template <class F> inline F f_const_u64(uint64_t x) { return F::constant(HFr::from_u64(x)); }
 template <class F> inline F f_zero() { return F::constant(HFr::zero()); }
 template <class F> inline F f_one() { return F::constant(HFr::one()); }

@@ -146,6 +146,18 @@ template <> inline Fq12<CV> fq12_mul_impl<CV>(const Fq12<CV>& a, const Fq12<CV>&
   return r;
 }
 
+template <> inline Fq12<WV> fq12_mul_impl<WV>(const Fq12<WV>& a, const Fq12<WV>& b) {
+  HFr av[12], bv[12], cv[23];
+  for (int i = 0; i < 12; i++) { av[i] = a.c[i].val; bv[i] = b.c[i].val; }
+  v12_full_product(av, bv, cv);
+  WV cc[23];
+  for (int m = 0; m < 23; m++) cc[m] = WV::witness(cv[m]);       // same 23 allocations as the CV version
+  Fq12<WV> r;
+  HFr five = HFr::from_u64(5);
+  for (int i = 0; i < 12; i++) r.c[i] = (i + 12 < 23) ? cc[i] - cc[i + 12].mulc(five) : cc[i];
+  return r;
+}
+
 // 1 / a: witness + a * inv = 1
 template <class F> inline void v12_of(const Fq12<F>& a, HFr* out) { for (int i = 0; i < 12; i++) out[i] = a.c[i].value(); }
 
