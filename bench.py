@@ -12,6 +12,8 @@ N - 1 group additions on every rank (zecale_amd/dist.py).
 
 `--workload prover` times BASELINE configs[2] instead (full Groth16 prover: SpMV + 7 NTT + 5 MSM +
 tail at 2^log_n constraints, synthetic R1CS and proving key of that shape).
+`--workload aggregator` times the real wrapping circuit (batch of 2 nested BLS12-377 Groth16 proofs verified
+in-circuit, 51k constraints): witness generation on the host + proof on the GPU, end to end.
 
 Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` and `cpu_baseline`.
 """
@@ -73,7 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=LOG_N)
-    ap.add_argument("--workload", choices=["msm", "prover"], default="msm")
+    ap.add_argument("--workload", choices=["msm", "prover", "aggregator"], default="msm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log", type=int, default=17)
     args = ap.parse_args()
@@ -123,6 +125,29 @@ def main():
             part = bases.msm_dev(s.data_ptr(), n, montgomery=False)
             return zdist.combine_partial_sums(part, device=dev) if world > 1 else part
         units_per_step = n * world
+    elif args.workload == "aggregator":
+        # the real wrapping circuit on the committed nested fixtures (reference testdata/dummy_app: vk.json, extproof1/2.json)
+        from tests.test_aggregator_host import nested_proof_limbs, nested_vk_limbs
+        from tests.test_oracle_pins import load_nested_fixtures
+        from tests.helpers import fr_limbs
+        agg = zkhip.AggregatorCircuit(2, 1)
+        desc = zkhip.r1cs_desc_from_aggregator(agg)
+        kp = zkhip.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
+        crs, r1 = kp.upload_crs(), zkhip.r1cs_from_desc(desc)
+        nvk, proofs = load_nested_fixtures()
+        nvk_l = nested_vk_limbs(nvk)
+        npr = np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])])
+        nin = np.array([fr_limbs(proofs[0][1][0]), fr_limbs(proofs[1][1][0])])
+        rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
+        wit_ms = []
+
+        def step(i):
+            t = time.time()
+            z = agg.witness(nvk_l, npr, nin)
+            wit_ms.append((time.time() - t) * 1e3)
+            return zkhip.groth16_prove(crs, r1, z, rr, ss)
+        units_per_step = world
+        n = agg.num_constraints
     else:
         # synthetic R1CS of the wrapping circuit's shape: n constraints, n + 5 variables, 4 primary inputs, <= 3 terms per row
         rng = np.random.default_rng(1234 + rank)
@@ -161,7 +186,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
         kernel_ms.append(zkhip.last_accumulate_ms())
-        if args.workload == "prover":
+        if args.workload in ("prover", "aggregator"):
             phase.append(zkhip.last_prove_timings())
     barrier()
     dt = time.time() - t0
@@ -178,6 +203,14 @@ def main():
             metric = "G1-MSM Mscalar/s (BW6_761, 2^%d terms per GPU)" % args.log_n
             workload = "BASELINE configs[1]: single MI355X G1_BW6_761 Pippenger MSM, 2^%d random scalars/points" % args.log_n
             terms_in_kernel = n
+        elif args.workload == "aggregator":
+            value, unit = units_per_step * args.steps / dt, "proofs/s"
+            metric = "wrapping proofs/sec (batch-2 BLS12_377 -> BW6_761 aggregation, %d constraints)" % n
+            workload = ("BASELINE configs[0]/[2] shape: aggregator circuit batch=2 dummy_app proofs (reference fixtures), host witness "
+                        "generation + Groth16 BW6_761 prover on the GPU, end to end")
+            terms_in_kernel = agg.num_variables - 5
+            extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
+            extra["phase_ms"]["witness_host"] = round(float(np.mean(wit_ms)), 3)
         else:
             value, unit = units_per_step * args.steps / dt, "proofs/s"
             metric = "wrapping proofs/sec (Groth16 over BW6_761, 2^%d constraints)" % args.log_n
