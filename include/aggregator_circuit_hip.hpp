@@ -1,0 +1,172 @@
+// aggregator_circuit_hip.hpp - C++ mirror of libzecale::aggregator_circuit<wppT, wsnarkT, nverifierT, NumProofs>
+// (reference libzecale/circuits/aggregator_circuit.hpp:32-114) over the zkhip C ABI: same member names, argument
+// meaning and error behaviour, so that aggregator_server.cpp (:480-514, :318-319) and the reference's tests read the same.
+//   explicit aggregator_circuit(size_t inputs_per_nested_proof);          hpp:85      (copy deleted, hpp:95-97)
+//   keypair generate_trusted_setup() const;                               tcc:100-109
+//   size_t num_primary_inputs() const;                                    tcc:172-180
+//   const r1cs_constraint_system& get_constraint_system() const;          hpp:99-101
+//   extended_proof prove(nested_vk, nested_proofs, proving_key);          tcc:120-170  (throws std::runtime_error on a
+//                                                                         wrong nested input count, tcc:138-141)
+// Types are plain limb containers (the libff/libsnark types are not in this image); INTEGRATION.md shows the bridge.
+#pragma once
+#include <array>
+#include <cstdio>
+#include <memory>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "groth16_snark_hip.hpp"
+
+namespace zecale_amd {
+
+// Nested (BLS12-377) objects: coordinates are 6-limb Montgomery elements of Fr(BW6-761) = Fq(BLS12-377).
+struct nested_verification_key {           // libzeth groth16 verification_key<npp>: alpha, beta, delta, ABC (testdata/dummy_app/vk.json)
+  std::array<uint64_t, 12> alpha_g1;
+  std::array<uint64_t, 24> beta_g2, delta_g2;
+  std::vector<std::array<uint64_t, 12>> abc_g1;
+  std::vector<uint64_t> flat() const {
+    std::vector<uint64_t> v(alpha_g1.begin(), alpha_g1.end());
+    v.insert(v.end(), beta_g2.begin(), beta_g2.end());
+    v.insert(v.end(), delta_g2.begin(), delta_g2.end());
+    for (const auto& p : abc_g1) v.insert(v.end(), p.begin(), p.end());
+    return v;
+  }
+};
+struct nested_proof {
+  std::array<uint64_t, 12> a, c;
+  std::array<uint64_t, 24> b;
+};
+struct nested_extended_proof {             // libzeth::extended_proof<npp, nsnark>: get_proof(), get_primary_inputs()
+  nested_proof proof;
+  std::vector<std::array<uint64_t, 6>> primary_inputs;
+  const nested_proof& get_proof() const { return proof; }
+  const std::vector<std::array<uint64_t, 6>>& get_primary_inputs() const { return primary_inputs; }
+};
+
+// libzeth::extended_proof<wpp, wsnark> (used at aggregator_circuit.tcc:167-169; write_json at aggregator_server.cpp:322)
+struct extended_proof {
+  groth16_proof proof;
+  std::vector<std::array<uint64_t, 6>> primary_inputs;
+  const groth16_proof& get_proof() const { return proof; }
+  const std::vector<std::array<uint64_t, 6>>& get_primary_inputs() const { return primary_inputs; }
+
+  static std::string hex_be(int which, const uint64_t* mont) {     // "0x" + fixed-width big-endian hex of the canonical value
+    const int n = which == 0 ? 12 : 6;
+    uint64_t c[12];
+    zk_check(zkhip_to_canonical(which, mont, c), "zkhip_to_canonical");
+    std::string s = "0x";
+    char buf[17];
+    for (int i = n - 1; i >= 0; i--) { std::snprintf(buf, sizeof buf, "%016llx", (unsigned long long)c[i]); s += buf; }
+    return s;
+  }
+  // same shape as testdata/dummy_app/batch1.json "ext_proof" 
+  std::string to_json() const {
+    auto pt = [](const uint64_t* p) { return "[\"" + hex_be(0, p) + "\", \"" + hex_be(0, p + 12) + "\"]"; };
+    std::ostringstream o;
+    o << "{\"proof\": {\"a\": " << pt(proof.a.data()) << ", \"b\": " << pt(proof.b.data()) << ", \"c\": " << pt(proof.c.data())
+      << "}, \"inputs\": [";
+    for (size_t i = 0; i < primary_inputs.size(); i++) o << (i ? ", " : "") << "\"" << hex_be(1, primary_inputs[i].data()) << "\"";
+    o << "]}";
+    return o.str();
+  }
+};
+
+class keypair {                            // wsnarkT::keypair: pk (HBM-resident) + vk
+ public:
+  explicit keypair(zkhip_keypair* kp) : kp_(kp) {
+    zkhip_crs_desc d;
+    zk_check(zkhip_keypair_crs_desc(kp_, &d), "zkhip_keypair_crs_desc");
+    zk_check(zkhip_crs_upload(&d, &crs_), "zkhip_crs_upload");
+  }
+  keypair(const keypair&) = delete;
+  keypair& operator=(const keypair&) = delete;
+  ~keypair() { zkhip_crs_free(crs_); zkhip_keypair_free(kp_); }
+  const zkhip_crs* pk() const { return crs_; }
+  // vk: alpha (G1), beta, delta (G2), ABC; `vk_abc_size() == num_primary_inputs() + 1` is the server's sanity check (aggregator_server.cpp:490)
+  size_t vk_abc_size() const { uint64_t a[24], b[24], d[24]; const uint64_t* abc; return zkhip_keypair_vk(kp_, a, b, d, &abc); }
+  bool verify(const extended_proof& ep) const {      // wsnarkT::verify(inputs, proof, vk)
+    uint64_t a[24], b[24], d[24];
+    const uint64_t* abc;
+    size_t n = zkhip_keypair_vk(kp_, a, b, d, &abc);
+    if (ep.primary_inputs.size() + 1 != n) return false;
+    std::vector<uint64_t> in;
+    for (const auto& x : ep.primary_inputs) in.insert(in.end(), x.begin(), x.end());
+    uint64_t pr[72];
+    std::memcpy(pr, ep.proof.a.data(), 192); std::memcpy(pr + 24, ep.proof.b.data(), 192); std::memcpy(pr + 48, ep.proof.c.data(), 192);
+    int ok = 0;
+    zk_check(zkhip_groth16_verify(a, b, d, abc, in.data(), ep.primary_inputs.size(), pr, &ok), "zkhip_groth16_verify");
+    return ok != 0;
+  }
+ private:
+  zkhip_keypair* kp_;
+  zkhip_crs* crs_ = nullptr;
+};
+
+template <size_t NumProofs>
+class aggregator_circuit {
+ public:
+  explicit aggregator_circuit(size_t inputs_per_nested_proof) : inputs_per_nested_proof_(inputs_per_nested_proof) {
+    zk_check(zkhip_aggregator_new(NumProofs, inputs_per_nested_proof, &agg_), "zkhip_aggregator_new");
+    zk_check(zkhip_aggregator_get_r1cs(agg_, &cs_), "zkhip_aggregator_get_r1cs");
+  }
+  aggregator_circuit(const aggregator_circuit&) = delete;
+  aggregator_circuit& operator=(const aggregator_circuit&) = delete;
+  ~aggregator_circuit() { if (r1cs_) zkhip_r1cs_free(r1cs_); zkhip_aggregator_free(agg_); }
+
+  size_t num_primary_inputs() const { return zkhip_aggregator_num_primary_inputs(agg_); }
+  const zkhip_r1cs_desc& get_constraint_system() const { return cs_; }
+
+  // needs a device (the batch exponentiations run on the GPU); fresh toxic waste from the OS, discarded on return
+  std::unique_ptr<keypair> generate_trusted_setup() const {
+    std::random_device rd;
+    uint64_t t[4][6];
+    for (auto& s : t) { for (auto& l : s) l = ((uint64_t)rd() << 32) | rd(); s[5] &= (1ull << 56) - 1; }   // < 2^376 < r: valid residues
+    zkhip_keypair* kp = nullptr;
+    zk_check(zkhip_groth16_setup(&cs_, t[0], t[1], t[2], t[3], &kp), "zkhip_groth16_setup");
+    return std::unique_ptr<keypair>(new keypair(kp));
+  }
+
+  // Non-const like the reference (it fills its protoboard); not re-entrant.
+  extended_proof prove(const nested_verification_key& nested_vk,
+                       const std::array<const nested_extended_proof*, NumProofs>& nested_proofs, const keypair& kp) {
+    std::vector<uint64_t> proofs, inputs;
+    for (size_t i = 0; i < NumProofs; i++) {
+      const auto& in = nested_proofs[i]->get_primary_inputs();
+      if (in.size() != inputs_per_nested_proof_)
+        throw std::runtime_error("unexpected number of inputs in nested proof " + std::to_string(i));   // tcc:138-141
+      const nested_proof& p = nested_proofs[i]->get_proof();
+      proofs.insert(proofs.end(), p.a.begin(), p.a.end());
+      proofs.insert(proofs.end(), p.b.begin(), p.b.end());
+      proofs.insert(proofs.end(), p.c.begin(), p.c.end());
+      for (const auto& x : in) inputs.insert(inputs.end(), x.begin(), x.end());
+    }
+    if (nested_vk.abc_g1.size() != inputs_per_nested_proof_ + 1) throw std::runtime_error("nested verification key has the wrong size");
+    std::vector<uint64_t> vk = nested_vk.flat(), z(cs_.n_vars * 6);
+    zk_check(zkhip_aggregator_witness(agg_, vk.data(), proofs.data(), inputs.data(), z.data()), "zkhip_aggregator_witness");
+    if (!r1cs_) zk_check(zkhip_r1cs_upload(&cs_, &r1cs_), "zkhip_r1cs_upload");
+    std::random_device rd;
+    uint64_t r[6], s[6];
+    for (int i = 0; i < 6; i++) { r[i] = ((uint64_t)rd() << 32) | rd(); s[i] = ((uint64_t)rd() << 32) | rd(); }
+    r[5] &= (1ull << 56) - 1; s[5] &= (1ull << 56) - 1;
+    uint64_t out[72];
+    zk_check(zkhip_groth16_prove(kp.pk(), r1cs_, z.data(), r, s, out), "zkhip_groth16_prove");
+    extended_proof ep;
+    std::memcpy(ep.proof.a.data(), out, 192); std::memcpy(ep.proof.b.data(), out + 24, 192); std::memcpy(ep.proof.c.data(), out + 48, 192);
+    for (size_t i = 0; i < num_primary_inputs(); i++) {
+      std::array<uint64_t, 6> x;
+      std::memcpy(x.data(), &z[(i + 1) * 6], 48);
+      ep.primary_inputs.push_back(x);
+    }
+    return ep;
+  }
+
+ private:
+  size_t inputs_per_nested_proof_;
+  zkhip_aggregator* agg_ = nullptr;
+  zkhip_r1cs_desc cs_;
+  zkhip_r1cs* r1cs_ = nullptr;
+};
+
+}  // namespace zecale_amd

@@ -181,6 +181,10 @@ void zkhip_keypair_free(zkhip_keypair* kp);
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
 
+/* Montgomery limbs -> canonical integer limbs (little-endian), for the JSON / EVM encodings of the reference
+ * (SURVEY App. A.2, A.3): which = 0 for Fq (12 limbs), 1 for Fr (6 limbs).  Host code. */
+int zkhip_to_canonical(int which, const uint64_t* in, uint64_t* out);
+
 /* host helpers on results (tiny, serial): Jacobian -> affine (infinity -> all zero), a + b */
 int zkhip_jac_to_affine(const uint64_t jac[36], uint64_t aff[24]);
 int zkhip_jac_add(const uint64_t a[36], const uint64_t b[36], uint64_t out[36]);

@@ -37,3 +37,38 @@ def test_header_compiles_and_links(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GROTH16" in out.stdout and "probe: bad argument" in out.stdout
+
+
+def test_aggregator_circuit_mirror_compiles_and_runs_host_part(tmp_path):
+    """include/aggregator_circuit_hip.hpp: construct the circuit, query it, and hit the reference's error path
+    (wrong nested input count -> std::runtime_error, aggregator_circuit.tcc:138-141).  No device needed for these."""
+    src = tmp_path / "a.cpp"
+    src.write_text(textwrap.dedent(r'''
+        #include "aggregator_circuit_hip.hpp"
+        #include <cstdio>
+        using namespace zecale_amd;
+        int main() {
+          aggregator_circuit<2> agg(1);
+          std::printf("primary=%zu constraints=%zu vars=%zu\n", agg.num_primary_inputs(), agg.get_constraint_system().n_constraints,
+                      agg.get_constraint_system().n_vars);
+          nested_verification_key vk{};
+          vk.abc_g1.resize(2);
+          nested_extended_proof p{};            // zero inputs: wrong count
+          std::array<const nested_extended_proof*, 2> ps = {&p, &p};
+          try {
+            agg.prove(vk, ps, *(const keypair*)nullptr);
+          } catch (const std::runtime_error& e) { std::printf("caught: %s\n", e.what()); }
+          try { agg.generate_trusted_setup(); } catch (const std::runtime_error& e) { std::printf("setup: %s\n", e.what()); }
+          extended_proof ep{};
+          ep.primary_inputs.resize(1);
+          std::printf("%s\n", ep.to_json().substr(0, 40).c_str());
+          return 0;
+        }
+    '''))
+    exe = tmp_path / "a"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "zecale_amd"), "-lzkhip", "-Wl,-rpath," + os.path.join(ROOT, "zecale_amd")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "primary=4" in out.stdout and "caught: unexpected number of inputs in nested proof 0" in out.stdout
+    assert '{"proof": {"a": ["0x' in out.stdout

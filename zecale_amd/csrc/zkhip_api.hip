@@ -544,6 +544,15 @@ void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 
 float zkhip_last_accumulate_ms(void) { return g.msm_ready ? g.msm.last_accumulate_ms : 0.f; }
 
+int zkhip_to_canonical(int which, const uint64_t* in, uint64_t* out) {
+  using namespace host;
+  if (!in || !out) return ZKHIP_ERR_ARG;
+  if (which == 0) HFq::from_limbs(in).to_canonical(out);
+  else if (which == 1) HFr::from_limbs(in).to_canonical(out);
+  else return ZKHIP_ERR_ARG;
+  return ZKHIP_OK;
+}
+
 int zkhip_jac_to_affine(const uint64_t jac[36], uint64_t aff[24]) {
   using namespace host;
   if (!jac || !aff) return ZKHIP_ERR_ARG;

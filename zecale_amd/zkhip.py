@@ -21,7 +21,7 @@ EXPORTS = [
     "zkhip_aggregator_num_variables", "zkhip_aggregator_num_primary_inputs", "zkhip_aggregator_get_r1cs",
     "zkhip_aggregator_witness", "zkhip_aggregator_vk_hash",
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free",
-    "zkhip_jac_to_affine", "zkhip_jac_add",
+    "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
 ]
 
 
