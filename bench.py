@@ -140,11 +140,21 @@ def main():
         nin = np.array([fr_limbs(proofs[0][1][0]), fr_limbs(proofs[1][1][0])])
         rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
         wit_ms = []
+        # two-stage pipeline over successive batches: a host thread generates the witness of batch i+1 (ctypes
+        # releases the GIL) while the GPU proves batch i.  Every step still performs one witness + one proof.
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
 
-        def step(i):
+        def make_witness():
             t = time.time()
             z = agg.witness(nvk_l, npr, nin)
             wit_ms.append((time.time() - t) * 1e3)
+            return z
+        pending = [pool.submit(make_witness)]
+
+        def step(i):
+            z = pending.pop().result()
+            pending.append(pool.submit(make_witness))
             return zkhip.groth16_prove(crs, r1, z, rr, ss)
         units_per_step = world
         n = agg.num_constraints

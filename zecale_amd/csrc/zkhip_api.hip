@@ -45,8 +45,8 @@ struct Lib {
   int forced_c = 0;
   MsmCtx msm;
   bool msm_ready = false;
-  MsmCtx msm2;              // second context: the prover keeps two MSMs in flight
-  bool msm2_ready = false;
+  MsmCtx msmx[4];           // further contexts: the prover keeps 2 (large) or 5 (small circuits) MSMs in flight
+  bool msmx_ready[4] = {false, false, false, false};
   char err[512] = {0};
   std::mutex mu;
 } g;
@@ -73,13 +73,13 @@ int auto_window(size_t n) {
   return 16;
 }
 
-int ensure_msm2(size_t n) {
+int ensure_msmx(int k, size_t n) {
   int c = auto_window(n);
-  if (g.msm2_ready && g.msm2.max_n >= n && g.msm2.c == c) return ZKHIP_OK;
-  if (g.msm2_ready) { msm_plan_free(&g.msm2); g.msm2_ready = false; }
-  int rc = msm_plan_init(&g.msm2, n, c);
-  if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "msm_plan_init: %s", g.msm2.errbuf); return rc; }
-  g.msm2_ready = true;
+  if (g.msmx_ready[k] && g.msmx[k].max_n >= n && g.msmx[k].c == c) return ZKHIP_OK;
+  if (g.msmx_ready[k]) { msm_plan_free(&g.msmx[k]); g.msmx_ready[k] = false; }
+  int rc = msm_plan_init(&g.msmx[k], n, c);
+  if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "msm_plan_init: %s", g.msmx[k].errbuf); return rc; }
+  g.msmx_ready[k] = true;
   return ZKHIP_OK;
 }
 
@@ -117,7 +117,7 @@ int zkhip_init(int device) {
 void zkhip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g.mu);
   if (g.msm_ready) { msm_plan_free(&g.msm); g.msm_ready = false; }
-  if (g.msm2_ready) { msm_plan_free(&g.msm2); g.msm2_ready = false; }
+  for (int k = 0; k < 4; k++) if (g.msmx_ready[k]) { msm_plan_free(&g.msmx[k]); g.msmx_ready[k] = false; }
   g.inited = false;
 }
 
@@ -370,25 +370,31 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
   struct { const zkhip_bases* b; const uint64_t* sc; size_t len; int mode; uint64_t* out; } jobs[5] = {
       {crs->A, dz, m, 1, evA}, {crs->B2, dz, m, 1, evB2}, {crs->B1, dz, m, 1, evB1},
       {crs->H, (const uint64_t*)rd->bufA, d - 1, 2, evH}, {crs->L, dz + (l + 1) * 6, m - l - 1, 1, evL}};
-  if ((rc = ensure_msm2(maxlen)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
-  // two MSMs in flight: while MSM j reduces its buckets (latency-bound, few lanes), MSM j+1 accumulates
-  MsmCtx* ctxs[2] = {&g.msm, &g.msm2};
+  // MSMs in flight: while MSM j reduces its buckets (latency-bound, few lanes), MSM j+1 accumulates.  Large
+  // circuits keep two contexts (each holds ~1.3 GB of work space at 2^20); small ones (every phase is
+  // latency-bound and the chip is mostly idle) run all five MSMs side by side.
+  const int nctx = (maxlen <= ((size_t)1 << 18)) ? 5 : 2;
+  MsmCtx* ctxs[5] = {&g.msm, nullptr, nullptr, nullptr, nullptr};
+  for (int k = 1; k < nctx; k++) {
+    if ((rc = ensure_msmx(k - 1, maxlen)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
+    ctxs[k] = &g.msmx[k - 1];
+  }
   clk::time_point tl[5];
   for (int j = 0; j < 5; j++) {
-    MsmCtx* cx = ctxs[j & 1];
-    if (j >= 2) {
-      rc = msm_finish(cx, jobs[j - 2].out);
-      g_prove_ms[2 + j - 2] = ms_since(tl[j - 2]);
+    MsmCtx* cx = ctxs[j % nctx];
+    if (j >= nctx) {
+      rc = msm_finish(cx, jobs[j - nctx].out);
+      g_prove_ms[2 + j - nctx] = ms_since(tl[j - nctx]);
       if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", cx->errbuf); (void)hipFree(dz); return rc; }
     }
     tl[j] = clk::now();
     rc = msm_launch(cx, jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode);
     if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", cx->errbuf); (void)hipFree(dz); return rc; }
   }
-  for (int j = 3; j < 5; j++) {
-    rc = msm_finish(ctxs[j & 1], jobs[j].out);
+  for (int j = 5 - nctx; j < 5; j++) {
+    rc = msm_finish(ctxs[j % nctx], jobs[j].out);
     g_prove_ms[2 + j] = ms_since(tl[j]);
-    if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", ctxs[j & 1]->errbuf); (void)hipFree(dz); return rc; }
+    if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", ctxs[j % nctx]->errbuf); (void)hipFree(dz); return rc; }
   }
   (void)hipFree(dz);
   // tail: A = alpha + evA + r delta1;  B = beta + evB + s delta;  C = evH + evL + s A + r B1 - rs delta1
