@@ -1,6 +1,8 @@
 // Host side of the wrapping circuit: native BLS12-377 Groth16 verification and (below) the aggregator circuit.
 #include <string.h>
 #include <mutex>
+#include <thread>
+#include <exception>
 
 #include "../../include/zkhip.h"
 #include "circuit/bls12_377.hpp"
@@ -83,67 +85,123 @@ struct NestedData {
   const uint64_t* inputs;    // num_proofs x k x 6
 };
 
-// One pass over the circuit with V = CV (constraints + assignment) or V = WV (assignment only, native speed).
-// WV cannot name its variables, so the two deferred primary values are patched by index: variables 1 and 2.
+// The circuit in three kinds of sections, allocated in this order:
+//   inputs:   primary inputs (vk hash, packed results, nested inputs), then the nested key and proofs
+//   hash:     MiMC of the key's variables                          -> value of primary input 0
+//   proof p:  253 bits per nested input, accumulator, verification -> result bit p
+// With V = CV one pass emits constraints and the assignment.  With V = WV (assignment only) the hash section and
+// the proof sections only READ the input section's values, so they run on separate host threads, each filling its
+// own slice of the assignment; concatenated in section order they reproduce the circuit's variable numbering.
 template <class V>
-void synthesize(Builder& b, size_t num_proofs, size_t k, const NestedData* data) {
-  current_builder() = &b;
+struct Inputs {
+  V vk_hash, packed;
+  std::vector<std::vector<V>> nin;
+  std::vector<std::vector<HFr>> nin_val;
+  NestedVk<V> vk;
+  std::vector<NestedProof<V>> proofs;
+};
+
+template <class V>
+void alloc_inputs(Inputs<V>& in, size_t num_proofs, size_t k, const NestedData* data) {
   static const uint64_t zeros[48 * 8] = {0};
   auto limbs = [&](const uint64_t* p, size_t off) { return data ? p + off : zeros; };
-  // --- primary inputs first
-  V vk_hash = V::witness(HFr::zero());                   // variable 1, value patched below
-  V packed = V::witness(HFr::zero());                    // variable 2
-  std::vector<std::vector<V>> nin(num_proofs);
-  std::vector<std::vector<HFr>> nin_val(num_proofs);
+  in.vk_hash = V::witness(HFr::zero());                  // variable 1, value patched by the caller
+  in.packed = V::witness(HFr::zero());                   // variable 2
+  in.nin.resize(num_proofs); in.nin_val.resize(num_proofs);
   for (size_t p = 0; p < num_proofs; p++)
     for (size_t j = 0; j < k; j++) {
       HFr v = HFr::from_limbs(limbs(data ? data->inputs : nullptr, (p * k + j) * 6));
-      nin_val[p].push_back(v);
-      nin[p].push_back(V::witness(v));
+      in.nin_val[p].push_back(v);
+      in.nin[p].push_back(V::witness(v));
     }
-  // --- auxiliary: nested key and proofs
-  NestedVk<V> vk;
   const uint64_t* vkp = data ? data->vk : nullptr;
-  vk.alpha = g1_from<V>(limbs(vkp, 0), true);
-  vk.beta = g2_from<V>(limbs(vkp, 12), true);
-  vk.delta = g2_from<V>(limbs(vkp, 36), true);
-  for (size_t i = 0; i <= k; i++) vk.abc.push_back(g1_from<V>(limbs(vkp, 60 + i * 12), true));
-  std::vector<NestedProof<V>> proofs;
+  in.vk.alpha = g1_from<V>(limbs(vkp, 0), true);
+  in.vk.beta = g2_from<V>(limbs(vkp, 12), true);
+  in.vk.delta = g2_from<V>(limbs(vkp, 36), true);
+  for (size_t i = 0; i <= k; i++) in.vk.abc.push_back(g1_from<V>(limbs(vkp, 60 + i * 12), true));
   for (size_t p = 0; p < num_proofs; p++) {
     const uint64_t* pp = data ? data->proofs : nullptr;
-    proofs.push_back(NestedProof<V>{g1_from<V>(limbs(pp, p * 48), true), g2_from<V>(limbs(pp, p * 48 + 12), true),
-                                    g1_from<V>(limbs(pp, p * 48 + 36), true)});
+    in.proofs.push_back(NestedProof<V>{g1_from<V>(limbs(pp, p * 48), true), g2_from<V>(limbs(pp, p * 48 + 12), true),
+                                       g1_from<V>(limbs(pp, p * 48 + 36), true)});
   }
-  // --- hash of the key = primary input 0
-  V h = mimc_hash(vk_all_vars(vk));
-  V::assert_eq(vk_hash, h);
+}
+
+template <class V> V section_hash(const Inputs<V>& in) {
+  V h = mimc_hash(vk_all_vars(in.vk));
+  V::assert_eq(in.vk_hash, h);
+  return h;
+}
+
+template <class V> V section_proof(const Inputs<V>& in, size_t p, size_t k) {
+  std::vector<std::vector<V>> bits(k);
+  for (size_t j = 0; j < k; j++) {
+    uint64_t c[6];
+    in.nin_val[p][j].to_canonical(c);
+    V sum;
+    HFr w = HFr::one();
+    for (int t = 0; t < NESTED_INPUT_BITS; t++) {
+      V bit = V::witness_bit((c[t / 64] >> (t % 64)) & 1);
+      bits[j].push_back(bit);
+      sum = sum + bit.mulc(w);
+      w = w + w;
+    }
+    V::assert_eq(sum, in.nin[p][j]);                      // packing (multipacking_gadget in the reference)
+  }
+  G1<V> acc = input_accumulator(in.vk, bits);
+  return groth16_verify_bit(in.vk, in.proofs[p], acc);
+}
+
+// structure pass (and single-threaded assignment)
+template <class V>
+void synthesize(Builder& b, size_t num_proofs, size_t k, const NestedData* data) {
+  current_builder() = &b;
+  Inputs<V> in;
+  alloc_inputs(in, num_proofs, k, data);
+  V h = section_hash(in);
   b.z[1] = h.value();
-  // --- per proof: input bits, accumulator, verification bit
   V packed_lc;
   HFr pow2 = HFr::one();
   for (size_t p = 0; p < num_proofs; p++) {
-    std::vector<std::vector<V>> bits(k);
-    for (size_t j = 0; j < k; j++) {
-      uint64_t c[6];
-      nin_val[p][j].to_canonical(c);
-      V sum;
-      HFr w = HFr::one();
-      for (int t = 0; t < NESTED_INPUT_BITS; t++) {
-        V bit = V::witness_bit((c[t / 64] >> (t % 64)) & 1);
-        bits[j].push_back(bit);
-        sum = sum + bit.mulc(w);
-        w = w + w;
-      }
-      V::assert_eq(sum, nin[p][j]);                       // packing (multipacking_gadget in the reference)
-    }
-    G1<V> acc = input_accumulator(vk, bits);
-    V res = groth16_verify_bit(vk, proofs[p], acc);
+    V res = section_proof(in, p, k);
     packed_lc = packed_lc + res.mulc(pow2);
     pow2 = pow2 + pow2;
   }
-  V::assert_eq(packed, packed_lc);                        // packing_gadget::generate_r1cs_witness_from_bits (.tcc:157)
+  V::assert_eq(in.packed, packed_lc);                     // packing_gadget::generate_r1cs_witness_from_bits (.tcc:157)
   b.z[2] = packed_lc.value();
   current_builder() = nullptr;
+}
+
+// assignment only, sections on separate threads
+void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const NestedData* data) {
+  Builder b0;
+  current_builder() = &b0;
+  Inputs<WV> in;
+  alloc_inputs(in, num_proofs, k, data);
+  current_builder() = nullptr;
+  std::vector<std::vector<HFr>> parts(num_proofs + 1);
+  std::vector<HFr> results(num_proofs + 1);
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> errs(num_proofs + 1);
+  for (size_t s = 0; s <= num_proofs; s++) {
+    th.emplace_back([&, s]() {
+      try {
+        Builder bs;
+        bs.z.clear();                                     // a section holds no constant ONE of its own
+        current_builder() = &bs;
+        results[s] = (s == 0) ? section_hash(in).value() : section_proof(in, s - 1, k).value();
+        current_builder() = nullptr;
+        parts[s] = std::move(bs.z);
+      } catch (...) { errs[s] = std::current_exception(); current_builder() = nullptr; }
+    });
+  }
+  for (auto& t : th) t.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+  z = std::move(b0.z);
+  for (auto& p : parts) z.insert(z.end(), p.begin(), p.end());
+  z[1] = results[0];
+  HFr packed = HFr::zero(), pow2 = HFr::one();
+  for (size_t p = 0; p < num_proofs; p++) { packed = packed + results[p + 1] * pow2; pow2 = pow2 + pow2; }
+  z[2] = packed;
 }
 
 void to_csr(const std::vector<LC>& M, std::vector<uint32_t>& rp, std::vector<uint32_t>& col, std::vector<uint64_t>& val) {
@@ -198,17 +256,16 @@ int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, con
                              const uint64_t* nested_inputs, uint64_t* z_out) {
   if (!a || !nested_vk || !nested_proofs || !nested_inputs || !z_out) return ZKHIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(a->mu);
-  Builder b;
-  b.record = false;
+  std::vector<HFr> z;
   NestedData d{nested_vk, nested_proofs, nested_inputs};
   try {
-    synthesize<WV>(b, a->num_proofs, a->inputs_per_proof, &d);
+    witness_parallel(z, a->num_proofs, a->inputs_per_proof, &d);
   } catch (const std::exception&) {
     current_builder() = nullptr;
     return ZKHIP_ERR_ARG;
   }
-  if (b.z.size() != a->n_vars) return ZKHIP_ERR_STATE;
-  for (size_t i = 0; i < b.z.size(); i++) b.z[i].to_limbs(z_out + i * 6);
+  if (z.size() != a->n_vars) return ZKHIP_ERR_STATE;
+  for (size_t i = 0; i < z.size(); i++) z[i].to_limbs(z_out + i * 6);
   return ZKHIP_OK;
 }
 

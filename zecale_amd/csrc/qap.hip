@@ -35,27 +35,41 @@ __device__ __forceinline__ void q_store12(uint32_t* p, const FrD& v) {
 }
 
 // out[i] = <M_i, z> for i < n ; for the A matrix also out[n + k] = z_k, k <= n_primary ; zero up to d.
-// One lane per row; products are accumulated lazily (each < 2r) and folded every 32 terms.
+// SIXTEEN lanes per row: lane j takes the row's terms j, j+16, ...; the partial sums are folded with DPP row
+// shifts.  (One lane per row is latency-bound by the longest rows - a packing constraint has 253 terms, an Fq12
+// multiplication constraint 47 - and a wrapping circuit has fewer rows than the chip has lanes.)
+// Products are accumulated lazily (each < 2r) and folded every 32 terms.
+__device__ __forceinline__ FrD fr_shfl_down16(const FrD& v, int delta) {
+  FrD r;
+#pragma unroll
+  for (int i = 0; i < 14; i++) r.l[i] = (uint32_t)__shfl_down((int)v.l[i], delta, 16);
+  return r;
+}
+
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                const uint32_t* __restrict__ val, const uint32_t* __restrict__ z,
                                                uint32_t n, uint32_t extra /* n_primary + 1 for A, else 0 */, uint32_t d,
                                                uint32_t* __restrict__ out) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d) return;
+  uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t i = gt >> 4, sub = gt & 15u;
+  if (i >= d) return;                       // whole 16-lane groups leave together
   FrD acc = fp_zero<FrParams>();
   if (i < n) {
     uint32_t k0 = row_ptr[i], k1 = row_ptr[i + 1];
     uint32_t cnt = 0;
-    for (uint32_t k = k0; k < k1; k++) {
+    for (uint32_t k = k0 + sub; k < k1; k += 16) {
       FrD p = fp_mul(q_load12(val + (size_t)k * 12), q_load12(z + (size_t)col[k] * 12));
       acc = fp_add(acc, p);
       if ((++cnt & 31u) == 0) acc = fp_mul(acc, fp_one<FrParams>());   // back to < 2r
     }
-    if (cnt > 1) acc = fp_mul(acc, fp_one<FrParams>());                 // stored values are always < 2r
+    if (cnt > 1) acc = fp_mul(acc, fp_one<FrParams>());                 // every partial sum < 2r
+    // fold the 16 partial sums (each < 2r; the total < 32r fits the lazy bound; one final fold below)
+    for (int delta = 8; delta >= 1; delta >>= 1) acc = fp_add(acc, fr_shfl_down16(acc, delta));
+    if (sub == 0) acc = fp_mul(acc, fp_one<FrParams>());                // stored values are always < 2r
   } else if (i < n + extra) {
     acc = q_load12(z + (size_t)(i - n) * 12);
   }
-  q_store12(out + (size_t)i * 12, acc);
+  if (sub == 0) q_store12(out + (size_t)i * 12, acc);
 }
 
 // H[i] = (A[i] B[i] - C[i]) * zinv   (in place into A)
@@ -158,7 +172,7 @@ void r1cs_free(R1csDev* r) {
 
 static void spmv3(R1csDev* r, hipStream_t st) {
   uint32_t n = (uint32_t)r->n_constraints, d = 1u << r->log_d;
-  unsigned nb = (d + 255) / 256;
+  unsigned nb = (unsigned)(((size_t)d * 16 + 255) / 256);
   hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->A.row_ptr, r->A.col, r->A.val, r->z, n, (uint32_t)r->n_primary + 1, d, r->bufA);
   hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->B.row_ptr, r->B.col, r->B.val, r->z, n, 0u, d, r->bufB);
   hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->C.row_ptr, r->C.col, r->C.val, r->z, n, 0u, d, r->bufC);
