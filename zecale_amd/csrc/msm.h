@@ -20,7 +20,7 @@ struct MsmCtx {
   hipEvent_t ev, ev2, ev_acc0, ev_acc1;
   int32_t* digits;
   uint32_t *counts, *offsets, *cursor, *block_tot, *entries;
-  uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels;
+  uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels, *colS[2], *hilo;
   uint64_t *win_abi, *win_host;
   float last_accumulate_ms;
   bool pending;       // an MSM has been enqueued by msm_launch and not yet collected by msm_finish

@@ -344,35 +344,70 @@ __global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_
   }
 }
 
-// out[t] = sum_u in[tL + u]
+// out[t] = sum_u in[i(t) + u * row_len],  i(t) = (t / row_len) * (L * row_len) + (t % row_len).
+// row_len = 1: sums of L consecutive items (row sums);  row_len = R: for items laid out [g][h][R] it sums L
+// consecutive h for every (g, h / L, lo) (column sums).  in: n_in items with row stride in_stride words.
 template <bool QUAD>
-__global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_t n_in, int L, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_t n_in, uint32_t in_stride, int L, uint32_t row_len,
+                                                 uint32_t* __restrict__ out) {
   size_t n_out = n_in / L;
   size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt;    // one lane / quad per output
   const uint32_t q = (uint32_t)(gt & 3);
   if (t >= n_out) return;
+  const size_t i0 = (t / row_len) * ((size_t)L * row_len) + (t % row_len);
   XyzzRef acc = make_ref(out, (uint32_t)n_out, (uint32_t)t);
-  pt_copy<QUAD>(acc, make_ref(in, (uint32_t)n_in, (uint32_t)(t * L)), q);
-  for (int u = 1; u < L; u++) pt_add<QUAD>(acc, make_ref(in, (uint32_t)n_in, (uint32_t)(t * L + u)), q);
+  pt_copy<QUAD>(acc, make_ref(in, in_stride, (uint32_t)i0), q);
+  for (int u = 1; u < L; u++) pt_add<QUAD>(acc, make_ref(in, in_stride, (uint32_t)(i0 + (size_t)u * row_len)), q);
+}
+
+// Two-level split of the bucket index j = hi * R + lo (R = 2^lo_bits, H = 2^hi_bits rows):
+//   sum_j (j+1) B_j = R * sum_hi hi * Row[hi] + sum_lo (lo+1) * Col[lo].
+// k_place_hilo lays both small weighted sums out as 2W groups of N = max(R, H) items with weights index+1:
+//   group w      : item i = Row[w][i+1]  (i < H-1), infinity beyond      (weight i+1 = hi)
+//   group W + w  : item i = Col[w][i]    (i < R),   infinity beyond      (weight i+1 = lo+1)
+__global__ void __launch_bounds__(256, 2) k_place_hilo(uint32_t* __restrict__ rows /* W*H */, uint32_t* __restrict__ cols /* W*R */,
+                                                        uint32_t W, uint32_t H, uint32_t R, uint32_t N, uint32_t* __restrict__ out /* 2W*N */) {
+  uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, t = gt >> 2, q = gt & 3u;
+  if (t >= 2 * W * N) return;
+  uint32_t g = t / N, i = t % N;
+  XyzzRef dst = make_ref(out, 2 * W * N, t);
+  if (g < W) {
+    if (i + 1 < H) mem_st_lane(dst, q, mem_ld_lane(make_ref(rows, W * H, g * H + i + 1), q));
+    else mem_st_lane(dst, q, fp_zero<FqParams>());
+  } else {
+    if (i < R) mem_st_lane(dst, q, mem_ld_lane(make_ref(cols, W * R, (g - W) * R + i), q));
+    else mem_st_lane(dst, q, fp_zero<FqParams>());
+  }
 }
 
 // per window w: out[w] = R[0][w] + L_0 (R[1][w] + L_1 (R[2][w] + ...)).
 // R_all: `levels` arrays of W XYZZ points each, limb-major with stride W, consecutive (108*W words apart);
 // `work`: scratch for W accumulators.
 struct LevelShifts { uint8_t log_l[32]; };
-__global__ void __launch_bounds__(64, 2) k_window_combine(uint32_t* __restrict__ R_all, int levels, int W, LevelShifts ls,
-                                                           uint32_t* __restrict__ work, uint64_t* __restrict__ out_abi /* W x 4 x 12 u64 */) {
-  int gt = blockIdx.x * blockDim.x + threadIdx.x, w = gt >> 2;   // one quad per window
+__global__ void __launch_bounds__(64, 2) k_window_combine(uint32_t* __restrict__ R_all, int levels, int G, LevelShifts ls,
+                                                           uint32_t* __restrict__ work /* G accumulators, result left here */) {
+  int gt = blockIdx.x * blockDim.x + threadIdx.x, w = gt >> 2;   // one quad per group
   const uint32_t q = (uint32_t)(gt & 3);
-  if (w >= W) return;
-  XyzzRef acc = make_ref(work, (uint32_t)W, (uint32_t)w);
-  mem_st_lane(acc, q, mem_ld_lane(make_ref(R_all + (size_t)(levels - 1) * 108 * W, (uint32_t)W, (uint32_t)w), q));
+  if (w >= G) return;
+  XyzzRef acc = make_ref(work, (uint32_t)G, (uint32_t)w);
+  mem_st_lane(acc, q, mem_ld_lane(make_ref(R_all + (size_t)(levels - 1) * 108 * G, (uint32_t)G, (uint32_t)w), q));
   for (int k = levels - 2; k >= 0; k--) {
     for (int d = 0; d < ls.log_l[k]; d++) dbl_mem_quad(acc, q);
-    add_mem_quad(acc, make_ref(R_all + (size_t)k * 108 * W, (uint32_t)W, (uint32_t)w), q);
+    add_mem_quad(acc, make_ref(R_all + (size_t)k * 108 * G, (uint32_t)G, (uint32_t)w), q);
   }
+}
+
+// per window: R * (hi part) + (lo part), converted to ABI limbs
+__global__ void __launch_bounds__(64, 2) k_hilo_combine(uint32_t* __restrict__ work /* 2W */, int W, int lo_bits,
+                                                         uint64_t* __restrict__ out_abi /* W x 4 x 12 u64 */) {
+  int gt = blockIdx.x * blockDim.x + threadIdx.x, w = gt >> 2;
+  const uint32_t q = (uint32_t)(gt & 3);
+  if (w >= W) return;
+  XyzzRef hi = make_ref(work, (uint32_t)(2 * W), (uint32_t)w), lo = make_ref(work, (uint32_t)(2 * W), (uint32_t)(W + w));
+  for (int d = 0; d < lo_bits; d++) dbl_mem_quad(hi, q);
+  add_mem_quad(hi, lo, q);
   uint64_t* o = out_abi + (size_t)w * 48;
-  fp_to_abi<FqParams>(mem_ld_lane(acc, q), o + 12 * q);            // lane q converts coordinate q
+  fp_to_abi<FqParams>(mem_ld_lane(hi, q), o + 12 * q);            // lane q converts coordinate q
 }
 
 // ---- batch fixed-base scalar multiplication: out[i] = k_i * G (the inner loop of Groth16 setup:
@@ -518,12 +553,15 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c) {
   }
   HIP_TRY(hipMalloc(&ctx->buckets, (size_t)ctx->slot_stride * 108 * 4));
   // reduction scratch: S ping-pong (<= nb/L each) and R arrays (sum over levels <= nb/L * L/(L-1)), R sums
-  HIP_TRY(hipMalloc(&ctx->segS[0], (nb / ctx->L + 1) * 108 * 4));
-  HIP_TRY(hipMalloc(&ctx->segS[1], (nb / ctx->L + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->segS[0], (nb / 2 + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->segS[1], (nb / 2 + 1) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->segR, (nb / 2 + 64 * (size_t)ctx->W) * 108 * 4));   // one R array per level, back to back (sum < nb/3 at L = 4)
-  HIP_TRY(hipMalloc(&ctx->sumR[0], (nb / ctx->L / ctx->L + ctx->W + 1) * 108 * 4));
-  HIP_TRY(hipMalloc(&ctx->sumR[1], (nb / ctx->L / ctx->L + ctx->W + 1) * 108 * 4));
-  HIP_TRY(hipMalloc(&ctx->Rlevels, (size_t)32 * ctx->W * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->sumR[0], (nb / ctx->L / ctx->L + 4 * ctx->W + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->sumR[1], (nb / ctx->L / ctx->L + 4 * ctx->W + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->Rlevels, (size_t)32 * 2 * ctx->W * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->colS[0], (nb / 2 + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->colS[1], (nb / 2 + 1) * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->hilo, ((size_t)2 * ctx->W * ((size_t)1 << ((c - 1 + 1) / 2)) + 8) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->win_abi, (size_t)ctx->W * 48 * 8));
   HIP_TRY(hipHostMalloc(&ctx->win_host, (size_t)ctx->W * 48 * 8));
   return ZKHIP_OK;
@@ -531,7 +569,8 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c) {
 
 void msm_plan_free(MsmCtx* ctx) {
   void* ptrs[] = {ctx->digits, ctx->counts, ctx->offsets, ctx->cursor, ctx->block_tot, ctx->entries, ctx->buckets,
-                  ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi};
+                  ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi,
+                  ctx->colS[0], ctx->colS[1], ctx->hilo};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->win_host) (void)hipHostFree(ctx->win_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -613,56 +652,92 @@ int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags
                      ctx->buckets, ctx->slot_stride);
   HIP_TRY(hipGetLastError());
 
-  // bucket reduction: F(items) = sum_t R_t + L * F0(S), recursively; levels until one item per window.
-  // The k_seg chain (stream 1) produces one R array per level; reducing each R array to one point per
-  // window (k_sum chain) is independent of the later levels and runs on stream 2 behind an event.
-  uint32_t* cur = ctx->buckets;
-  size_t n_cur = nb;   // W groups of n_cur / W
+  // ---- bucket reduction -------------------------------------------------------------------------------
+  // (1) two-level split of the bucket index (row sums on stream 1, column sums on stream 2: plain trees),
+  // (2) the two small weighted sums per window by recursive 4-ary running sums:
+  //     F(items) = sum_t R_t + L * F0(S); the k_seg chain (stream 1) produces one R array per level, reducing
+  //     each R array to one point per group (k_sum chain) is independent of the later levels: stream 2,
+  // (3) per group Horner over the levels, then per window R * hi + lo.
+  const size_t QUAD_BELOW = 65536;   // fewer additions than half the chip's lanes: latency-bound, use quads
+  hipStream_t st2 = ctx->stream2;
+  const int lo_bits = (c - 1 + 1) / 2, hi_bits = (c - 1) - lo_bits;
+  const uint32_t Rr = 1u << lo_bits, Hh = 1u << hi_bits, Nn = Rr > Hh ? Rr : Hh;
+  auto launch_sum = [&](hipStream_t s_, uint32_t* in, size_t n_in, uint32_t in_stride, int L, uint32_t row_len, uint32_t* out) {
+    size_t n_out = n_in / L;
+    if (n_out >= QUAD_BELOW) hipLaunchKernelGGL(k_sum<false>, dim3(nblk(n_out, 256)), dim3(256), 0, s_, in, n_in, in_stride, L, row_len, out);
+    else hipLaunchKernelGGL(k_sum<true>, dim3(nblk(n_out * 4, 256)), dim3(256), 0, s_, in, n_in, in_stride, L, row_len, out);
+  };
+  HIP_TRY(hipEventRecord(ctx->ev, st));
+  HIP_TRY(hipStreamWaitEvent(st2, ctx->ev, 0));
+  uint32_t *rows = nullptr, *cols = nullptr;
+  {
+    // row tree: [W][H][R] -> [W][H]  (sum over lo, contiguous)
+    uint32_t* in = ctx->buckets; uint32_t in_stride = ctx->slot_stride; size_t n_in = nb; uint32_t left = Rr; int pp = 0;
+    if (left == 1) rows = in;   // (c <= 2 never happens: c >= 4)
+    while (left > 1) {
+      int L = ctx->L; while ((uint32_t)L > left) L >>= 1;
+      uint32_t* out = ctx->segS[pp];
+      launch_sum(st, in, n_in, in_stride, L, 1, out);
+      n_in /= L; left /= L; in = out; in_stride = (uint32_t)n_in; pp ^= 1; rows = out;
+    }
+    // column tree: [W][H][R] -> [W][R]  (sum over hi, stride R)
+    in = ctx->buckets; in_stride = ctx->slot_stride; n_in = nb; left = Hh; pp = 0;
+    if (left == 1) { cols = ctx->colS[0]; launch_sum(st2, in, n_in, in_stride, 1, Rr, cols); }
+    while (left > 1) {
+      int L = ctx->L; while ((uint32_t)L > left) L >>= 1;
+      uint32_t* out = ctx->colS[pp];
+      launch_sum(st2, in, n_in, in_stride, L, Rr, out);
+      n_in /= L; left /= L; in = out; in_stride = (uint32_t)n_in; pp ^= 1; cols = out;
+    }
+  }
+  HIP_TRY(hipEventRecord(ctx->ev2, st2));
+  HIP_TRY(hipStreamWaitEvent(st, ctx->ev2, 0));
+  const int G = 2 * W;
+  hipLaunchKernelGGL(k_place_hilo, dim3(nblk((size_t)G * Nn * 4, 256)), dim3(256), 0, st, rows, cols, (uint32_t)W, Hh, Rr, Nn, ctx->hilo);
+
+  uint32_t* cur = ctx->hilo;
+  size_t n_cur = (size_t)G * Nn;   // G groups of Nn items, weights index + 1
   int level = 0;
   LevelShifts ls;
   memset(&ls, 0, sizeof ls);
-  const size_t QUAD_BELOW = 65536;   // fewer additions than half the chip's lanes: latency-bound, use quads
   size_t r_off = 0;                  // this level's R array starts here inside segR (in points)
-  hipStream_t st2 = ctx->stream2;
-  while (n_cur > (size_t)W) {
+  while (n_cur > (size_t)G) {
     int L = ctx->L;
-    while ((size_t)L > n_cur / W) L >>= 1;      // last level: fewer items per window than L
+    while ((size_t)L > n_cur / G) L >>= 1;      // last level: fewer items per group than L
     int lg = 0; while ((1 << lg) < L) lg++;
     ls.log_l[level] = (uint8_t)lg;
     size_t n_out = n_cur / L;
     uint32_t* S = ctx->segS[level & 1];
     uint32_t* Rk = ctx->segR + r_off * 108;
     if (n_out >= QUAD_BELOW)
-      hipLaunchKernelGGL(k_seg<false>, dim3(nblk(n_out, 256)), dim3(256), 0, st, cur, n_cur, level == 0 ? ctx->slot_stride : (uint32_t)n_cur, L,
-                         level == 0 ? 1 : 0, S, Rk);
+      hipLaunchKernelGGL(k_seg<false>, dim3(nblk(n_out, 256)), dim3(256), 0, st, cur, n_cur, (uint32_t)n_cur, L, level == 0 ? 1 : 0, S, Rk);
     else
-      hipLaunchKernelGGL(k_seg<true>, dim3(nblk(n_out * 4, 256)), dim3(256), 0, st, cur, n_cur, level == 0 ? ctx->slot_stride : (uint32_t)n_cur, L,
-                         level == 0 ? 1 : 0, S, Rk);
+      hipLaunchKernelGGL(k_seg<true>, dim3(nblk(n_out * 4, 256)), dim3(256), 0, st, cur, n_cur, (uint32_t)n_cur, L, level == 0 ? 1 : 0, S, Rk);
     HIP_TRY(hipEventRecord(ctx->ev, st));
     HIP_TRY(hipStreamWaitEvent(st2, ctx->ev, 0));
-    // reduce R (n_out items, W groups) to W items: Rlevels[level]
+    // reduce R (n_out items, G groups) to G items: Rlevels[level]
     uint32_t* rc = Rk;
     size_t rn = n_out;
     int pp = 0;
-    while (rn > (size_t)W) {
+    while (rn > (size_t)G) {
       int Ls = ctx->L;
-      while ((size_t)Ls > rn / W) Ls >>= 1;
+      while ((size_t)Ls > rn / G) Ls >>= 1;
       size_t ro = rn / Ls;
-      uint32_t* dst = (ro == (size_t)W) ? ctx->Rlevels + (size_t)level * 108 * W : ctx->sumR[pp];
-      if (ro >= QUAD_BELOW) hipLaunchKernelGGL(k_sum<false>, dim3(nblk(ro, 256)), dim3(256), 0, st2, rc, rn, Ls, dst);
-      else hipLaunchKernelGGL(k_sum<true>, dim3(nblk(ro * 4, 256)), dim3(256), 0, st2, rc, rn, Ls, dst);
+      uint32_t* dst = (ro == (size_t)G) ? ctx->Rlevels + (size_t)level * 108 * G : ctx->sumR[pp];
+      launch_sum(st2, rc, rn, (uint32_t)rn, Ls, 1, dst);
       rc = dst; rn = ro; pp ^= 1;
     }
-    if (n_out == (size_t)W) {   // R already one per window
-      HIP_TRY(hipMemcpyAsync(ctx->Rlevels + (size_t)level * 108 * W, Rk, (size_t)108 * W * 4, hipMemcpyDeviceToDevice, st2));
+    if (n_out == (size_t)G) {   // R already one per group
+      HIP_TRY(hipMemcpyAsync(ctx->Rlevels + (size_t)level * 108 * G, Rk, (size_t)108 * G * 4, hipMemcpyDeviceToDevice, st2));
     }
     r_off += n_out;
     cur = S; n_cur = n_out; level++;
   }
   HIP_TRY(hipEventRecord(ctx->ev2, st2));
   HIP_TRY(hipStreamWaitEvent(st, ctx->ev2, 0));
-  // the last S (one item per window) has weight 0 at its level (o = 0 for level >= 1) and is dropped.
-  hipLaunchKernelGGL(k_window_combine, dim3(nblk((size_t)W * 4, 64)), dim3(64), 0, st, ctx->Rlevels, level, W, ls, ctx->sumR[0], ctx->win_abi);
+  // the last S (one item per group) has weight 0 at its level (o = 0 for level >= 1) and is dropped.
+  hipLaunchKernelGGL(k_window_combine, dim3(nblk((size_t)G * 4, 64)), dim3(64), 0, st, ctx->Rlevels, level, G, ls, ctx->sumR[0]);
+  hipLaunchKernelGGL(k_hilo_combine, dim3(nblk((size_t)W * 4, 64)), dim3(64), 0, st, ctx->sumR[0], W, lo_bits, ctx->win_abi);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ctx->win_host, ctx->win_abi, (size_t)W * 48 * 8, hipMemcpyDeviceToHost, st));
   return ZKHIP_OK;
