@@ -228,20 +228,23 @@ def main():
                         "4 primary inputs, random proving key of that shape" % args.log_n)
             terms_in_kernel = n - 5       # the last MSM of a proof is L
             extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
-        achieved = ALG_BYTES_PER_TERM * terms_in_kernel / (k_ms * 1e-3) / 1e9
+        timed = k_ms > 0        # the prover replays captured hipGraphs: no per-kernel events there (profiles/ has the kernel traces)
+        if not timed:
+            k_ms = float("nan")
+        achieved = ALG_BYTES_PER_TERM * terms_in_kernel / (k_ms * 1e-3) / 1e9 if timed else None
         out = {
             "metric": metric, "value": round(value, 4), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (27 x 29-bit limbs: 761-bit Montgomery integers)", "data": "synthetic",
             "config": {"workload": workload, "terms_per_gpu": n, "bases": "resident in HBM (proving key)",
                        "parallelism": "point-partitioned x%d, RCCL all-gather of 288-byte partial sums" % world},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": measured_traffic(),
-                         "kernel": "zkhip::k_accumulate", "kernel_ms": round(k_ms, 3),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3) if timed else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6) if timed else None, "traffic": measured_traffic() if timed else None,
+                         "kernel": "zkhip::k_accumulate", "kernel_ms": round(k_ms, 3) if timed else None,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_TERM * terms_in_kernel,
                          "note": "this path is integer-multiply bound, not HBM bound (SURVEY 0.5): fq_mul_frac = Fq "
                                  "multiplications per second in the kernel / measured chip peak of the multiplier",
-                         "fq_mul_frac": round(terms_in_kernel * 24 * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4)},
+                         "fq_mul_frac": round(terms_in_kernel * 24 * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4) if timed else None},
         }
         out.update(extra)
         if not args.no_cpu_baseline:
