@@ -121,6 +121,21 @@ void zkhip_crs_free(zkhip_crs* c);
  * results can be compared bit for bit.  z: n_vars x 6 limbs.  proof_affine: A (G1), B (G2), C (G1). */
 int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, const uint64_t r[6], const uint64_t s[6],
                         uint64_t proof_affine[72]);
+/* Multi-GPU form (the proving key is partitioned across the GPUs of a node, one process per GPU):
+ *   zkhip_crs_upload_slice   uploads this rank's slice of every query vector: [a_lo, a_lo+a_len) of the A / B queries,
+ *                            [h_lo, ..) of H, [l_lo, ..) of L (full-key descriptor + ranges)
+ *   zkhip_groth16_prove_partial  QAP map (replicated) + the five MSMs over the slice -> 5 Jacobian partial sums
+ *                            (A, B-G2, B-G1, H, L: 5 x 36 limbs)
+ *   ... the ranks exchange and add the partial sums (RCCL all-gather of 1440 bytes, zecale_amd/dist.py) ...
+ *   zkhip_groth16_finish     host tail on the summed values.
+ * zkhip_groth16_prove is exactly prove_partial over the whole key followed by finish. */
+int zkhip_crs_upload_slice(const zkhip_crs_desc* full_key, size_t a_lo, size_t a_len, size_t h_lo, size_t h_len, size_t l_lo, size_t l_len,
+                           zkhip_crs** out);
+int zkhip_groth16_prove_partial(const zkhip_crs* crs_slice, zkhip_r1cs* r1cs, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
+                                uint64_t sums_jac[180]);
+int zkhip_groth16_finish(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
+                         const uint64_t delta_g2[24], const uint64_t sums_jac[180], const uint64_t r[6], const uint64_t s[6],
+                         uint64_t proof_affine[72]);
 /* phase timings of the last zkhip_groth16_prove, milliseconds: [0] upload z, [1] QAP (SpMV + 7 NTT),
  * [2..6] the five MSMs A, B2, B1, H, L, [7] host tail */
 int zkhip_last_prove_timings(double out_ms[8]);

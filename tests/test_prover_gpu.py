@@ -95,3 +95,32 @@ def test_bad_arguments(zk):
         r2 = zk.R1cs(A, B, C, len(g["z"]), g["n_primary"] + 1)
         zk.groth16_prove(crs, r2, fr_array([h2i(x) for x in g["z"]]), fr_limbs(1), fr_limbs(1))
     r1.free()
+
+
+def test_key_partitioned_prover_matches_whole_key(zk):
+    """SURVEY 8e on one device: the proving key cut into 3 uneven slices (as 3 ranks would hold it), partial sums
+    added, tail run once == the single-GPU proof, limb for limb."""
+    from zecale_amd import dist as zdist
+    n, n_primary = 2500, 4
+    A, B, C, z = make_r1cs(77, n, n_primary, n, 0.5)
+    m = len(z)
+    rng = random.Random(9)
+    tau, alpha, beta, delta, r, s = (rng.randrange(1, R.R_MOD) for _ in range(6))
+    pk, log_d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta)
+    d = 1 << log_d
+    r1 = zk.R1cs(csr_from_rows(A), csr_from_rows(B), csr_from_rows(C), m, n_primary)
+    zl = fr_array(z)
+    whole = zk.Crs(pk, m, n_primary, d)
+    expect = zk.groth16_prove(whole, r1, zl, fr_limbs(r), fr_limbs(s))
+    world = 3
+    total = None
+    for rank in range(world):
+        a_rng, h_rng, l_rng = zdist.key_slices(m, n_primary, d, world, rank)
+        sl = zk.Crs.upload_slice(pk, m, n_primary, d, a_rng, h_rng, l_rng)
+        part = zk.groth16_prove_partial(sl, r1, zl)
+        total = part if total is None else np.array([zk.jac_add(total[k], part[k]) for k in range(5)])
+        sl.free()
+    got = zk.groth16_finish(pk, total, fr_limbs(r), fr_limbs(s))
+    assert (got == expect).all()
+    assert zk.groth16_verify(pk["vk"], zl[1:1 + n_primary], got)
+    whole.free(); r1.free()

@@ -330,6 +330,26 @@ int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) {
   return ZKHIP_OK;
 }
 
+int zkhip_crs_upload_slice(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, size_t h_lo, size_t h_len, size_t l_lo, size_t l_len,
+                           zkhip_crs** out) {
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!d || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (a_lo + a_len > d->n_vars || h_lo + h_len > d->domain_size - 1 || l_lo + l_len > d->n_vars - d->n_primary - 1)
+    return fail(ZKHIP_ERR_ARG, "slice out of range");
+  zkhip_crs* c = new zkhip_crs();
+  c->n_vars = d->n_vars; c->n_primary = d->n_primary; c->domain_size = d->domain_size;
+  memcpy(c->alpha_g1, d->alpha_g1, 192); memcpy(c->beta_g1, d->beta_g1, 192); memcpy(c->beta_g2, d->beta_g2, 192);
+  memcpy(c->delta_g1, d->delta_g1, 192); memcpy(c->delta_g2, d->delta_g2, 192);
+  int rc;
+  if ((rc = zkhip_bases_upload(d->a_query + a_lo * 24, a_len, &c->A)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->b_g2_query + a_lo * 24, a_len, &c->B2)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->b_g1_query + a_lo * 24, a_len, &c->B1)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->h_query + h_lo * 24, h_len, &c->H)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->l_query + l_lo * 24, l_len, &c->L)) != ZKHIP_OK) return rc;
+  *out = c;
+  return ZKHIP_OK;
+}
+
 void zkhip_crs_free(zkhip_crs* c) {
   if (!c) return;
   zkhip_bases_free(c->A); zkhip_bases_free(c->B2); zkhip_bases_free(c->B1); zkhip_bases_free(c->H); zkhip_bases_free(c->L);
@@ -342,18 +362,20 @@ int zkhip_last_prove_timings(double out_ms[8]) {
   return ZKHIP_OK;
 }
 
-int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6],
-                        uint64_t proof_affine[72]) {
-  using namespace host;
+// The five MSMs of a proof over THIS process's slice of the proving key (the key is partitioned across the
+// GPUs of a node; each rank computes partial sums, the ranks exchange 5 x 288 bytes).  Slice = [a_lo, a_lo + a_len) of
+// the A / B queries (indices into z), [h_lo, h_lo + h_len) of the H query (indices into h), [l_lo, l_lo + l_len) of the
+// L query (indices into z[n_primary+1 ..]).  The whole key is the slice (0, n_vars), (0, d - 1), (0, n_vars - l - 1).
+static int prove_partial_locked(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
+                                uint64_t sums[5 * 36]) {
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
-  if (!crs || !r1cs || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
   R1csDev* rd = r1cs->dev;
-  const size_t m = crs->n_vars, l = crs->n_primary, d = (size_t)1 << rd->log_d;
-  if (rd->n_vars != m || rd->n_primary != l || crs->domain_size != d)
-    return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+  const size_t m = rd->n_vars, l = rd->n_primary, d = (size_t)1 << rd->log_d;
+  const size_t a_len = crs->A->len, h_len = crs->H->len, l_len = crs->L->len;
+  if (crs->n_vars != m || crs->n_primary != l || crs->domain_size != d) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+  if (crs->B2->len != a_len || crs->B1->len != a_len || a_lo + a_len > m || h_lo + h_len > d - 1 || l_lo + l_len > m - l - 1)
+    return fail(ZKHIP_ERR_ARG, "key slice out of range");
   auto t0 = clk::now();
   uint64_t* dz = nullptr;
   API_HIP(hipMalloc(&dz, m * 48));
@@ -364,12 +386,12 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
   if (rc != ZKHIP_OK) { (void)hipFree(dz); return rc; }
   API_HIP(hipDeviceSynchronize());
   g_prove_ms[1] = ms_since(t0);
-  size_t maxlen = m > d ? m : d;
+  size_t maxlen = a_len > h_len ? a_len : h_len;
+  if (maxlen < 1) maxlen = 1;
   if ((rc = ensure_msm(maxlen)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
-  uint64_t evA[36], evB2[36], evB1[36], evH[36], evL[36];
   struct { const zkhip_bases* b; const uint64_t* sc; size_t len; int mode; uint64_t* out; } jobs[5] = {
-      {crs->A, dz, m, 1, evA}, {crs->B2, dz, m, 1, evB2}, {crs->B1, dz, m, 1, evB1},
-      {crs->H, (const uint64_t*)rd->bufA, d - 1, 2, evH}, {crs->L, dz + (l + 1) * 6, m - l - 1, 1, evL}};
+      {crs->A, dz + a_lo * 6, a_len, 1, sums}, {crs->B2, dz + a_lo * 6, a_len, 1, sums + 36}, {crs->B1, dz + a_lo * 6, a_len, 1, sums + 72},
+      {crs->H, (const uint64_t*)rd->bufA + h_lo * 6, h_len, 2, sums + 108}, {crs->L, dz + (l + 1 + l_lo) * 6, l_len, 1, sums + 144}};
   // MSMs in flight: while MSM j reduces its buckets (latency-bound, few lanes), MSM j+1 accumulates.  Large
   // circuits keep two contexts (each holds ~1.3 GB of work space at 2^20); small ones (every phase is
   // latency-bound and the chip is mostly idle) run all five MSMs side by side.
@@ -397,29 +419,62 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
     if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", ctxs[j % nctx]->errbuf); (void)hipFree(dz); return rc; }
   }
   (void)hipFree(dz);
-  // tail: A = alpha + evA + r delta1;  B = beta + evB + s delta;  C = evH + evL + s A + r B1 - rs delta1
-  t0 = clk::now();
+  return ZKHIP_OK;
+}
+
+int zkhip_groth16_prove_partial(const zkhip_crs* crs_slice, zkhip_r1cs* r1cs, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
+                                uint64_t sums_jac[180]) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!crs_slice || !r1cs || !z || !sums_jac) return fail(ZKHIP_ERR_ARG, "null pointer");
+  return prove_partial_locked(crs_slice, r1cs, z, a_lo, h_lo, l_lo, sums_jac);
+}
+
+// tail: A = alpha + evA + r delta1;  B = beta + evB + s delta;  C = evH + evL + s A + r B1 - rs delta1
+int zkhip_groth16_finish(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
+                         const uint64_t delta_g2[24], const uint64_t sums_jac[180], const uint64_t r_m[6], const uint64_t s_m[6],
+                         uint64_t proof_affine[72]) {
+  using namespace host;
+  using clk = std::chrono::steady_clock;
+  if (!alpha_g1 || !beta_g1 || !beta_g2 || !delta_g1 || !delta_g2 || !sums_jac || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+  auto t0 = clk::now();
+  const uint64_t *evA = sums_jac, *evB2 = sums_jac + 36, *evB1 = sums_jac + 72, *evH = sums_jac + 108, *evL = sums_jac + 144;
   auto jac = [](const uint64_t* p) { HJac q; q.X = HFq::from_limbs(p); q.Y = HFq::from_limbs(p + 12); q.Z = HFq::from_limbs(p + 24); return q; };
   auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
   HFr r = HFr::from_limbs(r_m), s = HFr::from_limbs(s_m), rs = r * s;
   uint64_t rc_[6], sc_[6], rsc_[6];
   r.to_canonical(rc_); s.to_canonical(sc_); rs.to_canonical(rsc_);
-  HJac d1 = aff(crs->delta_g1), d2 = aff(crs->delta_g2);
+  HJac d1 = aff(delta_g1), d2 = aff(delta_g2);
   // six independent 377-bit scalar multiplications of single points: serial chains, one host thread each
   auto smul = [](HJac p, const uint64_t* k) { return std::async(std::launch::async, [p, k]() { return p.mul_canonical(k, 6); }); };
   auto f_rd1 = smul(d1, rc_), f_sd2 = smul(d2, sc_), f_sd1 = smul(d1, sc_), f_rsd1 = smul(d1, rsc_);
-  HJac gA = jac(evA).add(aff(crs->alpha_g1)).add(f_rd1.get());
+  HJac gA = jac(evA).add(aff(alpha_g1)).add(f_rd1.get());
   auto f_sA = smul(gA, sc_);
-  HJac gB1 = jac(evB1).add(aff(crs->beta_g1)).add(f_sd1.get());
+  HJac gB1 = jac(evB1).add(aff(beta_g1)).add(f_sd1.get());
   auto f_rB1 = smul(gB1, rc_);
-  HJac gB2 = jac(evB2).add(aff(crs->beta_g2)).add(f_sd2.get());
+  HJac gB2 = jac(evB2).add(aff(beta_g2)).add(f_sd2.get());
   HJac gC = jac(evH).add(jac(evL)).add(f_sA.get()).add(f_rB1.get()).add(f_rsd1.get().neg());
   HFq x, y;
   gA.to_affine(x, y); x.to_limbs(proof_affine); y.to_limbs(proof_affine + 12);
   gB2.to_affine(x, y); x.to_limbs(proof_affine + 24); y.to_limbs(proof_affine + 36);
   gC.to_affine(x, y); x.to_limbs(proof_affine + 48); y.to_limbs(proof_affine + 60);
-  g_prove_ms[7] = ms_since(t0);
+  g_prove_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
   return ZKHIP_OK;
+}
+
+int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6],
+                        uint64_t proof_affine[72]) {
+  uint64_t sums[180];
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+    if (!crs || !r1cs || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+    const size_t m = r1cs->dev->n_vars, l = r1cs->dev->n_primary, d = (size_t)1 << r1cs->dev->log_d;
+    if (crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+    int rc = prove_partial_locked(crs, r1cs, z, 0, 0, 0, sums);
+    if (rc != ZKHIP_OK) return rc;
+  }
+  return zkhip_groth16_finish(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine);
 }
 
 int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_g2[24], const uint64_t vk_delta_g2[24],

@@ -38,3 +38,17 @@ def combine_partial_sums(part_jac, group=None, device=None):
         for k in range(out.shape[0]):
             out[k] = zkhip.jac_add(out[k], q[k])
     return out.reshape(shape)
+
+
+def key_slices(n_vars, n_primary, domain_size, world, rank):
+    """Ranges of the A/B, H and L queries owned by `rank` (contiguous, sizes differ by at most one)."""
+    return (partition(n_vars, world, rank), partition(domain_size - 1, world, rank), partition(n_vars - n_primary - 1, world, rank))
+
+
+def prove_distributed(crs_slice, r1cs, pk_consts, z, r, s, group=None, device=None):
+    """One Groth16 proof with the proving key partitioned over the ranks of `group`: every rank runs the (cheap, replicated)
+    QAP map and the five MSMs over its slice, the 5 x 288-byte partial sums are all-gathered and added in rank order on
+    every rank, and every rank finishes the same proof.  Collective."""
+    sums = zkhip.groth16_prove_partial(crs_slice, r1cs, z)
+    total = combine_partial_sums(sums, group=group, device=device)
+    return zkhip.groth16_finish(pk_consts, total, r, s)

@@ -17,6 +17,7 @@ EXPORTS = [
     "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
     "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings", "zkhip_groth16_verify",
+    "zkhip_crs_upload_slice", "zkhip_groth16_prove_partial", "zkhip_groth16_finish",
     "zkhip_bls12_377_groth16_verify", "zkhip_aggregator_new", "zkhip_aggregator_free", "zkhip_aggregator_num_constraints",
     "zkhip_aggregator_num_variables", "zkhip_aggregator_num_primary_inputs", "zkhip_aggregator_get_r1cs",
     "zkhip_aggregator_witness", "zkhip_aggregator_vk_hash",
@@ -82,6 +83,9 @@ def load():
     lib.zkhip_crs_free.argtypes = [ctypes.c_void_p]
     lib.zkhip_groth16_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
     lib.zkhip_last_prove_timings.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    lib.zkhip_crs_upload_slice.argtypes = [ctypes.POINTER(CrsDesc)] + [ctypes.c_size_t] * 6 + [ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_groth16_prove_partial.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, c_u64p]
+    lib.zkhip_groth16_finish.argtypes = [c_u64p] * 9
     lib.zkhip_groth16_verify.argtypes = [c_u64p, c_u64p, c_u64p, c_u64p, c_u64p, ctypes.c_size_t, c_u64p, ctypes.POINTER(ctypes.c_int)]
     lib.zkhip_last_accumulate_ms.restype = ctypes.c_float
     lib.zkhip_jac_to_affine.argtypes = [c_u64p, c_u64p]
@@ -248,6 +252,43 @@ class Crs:
         if self.handle:
             load().zkhip_crs_free(self.handle)
             self.handle = None
+
+    @classmethod
+    def upload_slice(cls, pk, n_vars, n_primary, domain_size, a_range, h_range, l_range):
+        """This rank's slice of the proving key: ranges are (lo, hi) into the A/B queries, the H query and the L query."""
+        d = CrsDesc()
+        d.n_vars, d.n_primary, d.domain_size = n_vars, n_primary, domain_size
+        keep = []
+        for field, key in (("alpha_g1", "alpha_g1"), ("beta_g1", "beta_g1"), ("beta_g2", "beta_g2"), ("delta_g1", "delta_g1"),
+                           ("delta_g2", "delta_g2"), ("a_query", "A"), ("b_g2_query", "B2"), ("b_g1_query", "B1"), ("h_query", "H"),
+                           ("l_query", "L")):
+            a = np.ascontiguousarray(pk[key], dtype=np.uint64).reshape(-1, 24)
+            keep.append(a)
+            setattr(d, field, a.ctypes.data if a.size else None)
+        self = cls.__new__(cls)
+        h = ctypes.c_void_p()
+        _check(load().zkhip_crs_upload_slice(ctypes.byref(d), a_range[0], a_range[1] - a_range[0], h_range[0], h_range[1] - h_range[0],
+                                             l_range[0], l_range[1] - l_range[0], ctypes.byref(h)))
+        self.handle = h
+        self.ranges = (a_range, h_range, l_range)
+        return self
+
+
+def groth16_prove_partial(crs_slice, r1cs, z):
+    """The five partial sums (5 x 36 limbs) of this rank's key slice."""
+    zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(r1cs.n_vars, 6)
+    out = np.zeros((5, 36), dtype=np.uint64)
+    (a0, _), (h0, _), (l0, _) = crs_slice.ranges
+    _check(load().zkhip_groth16_prove_partial(crs_slice.handle, r1cs.handle, _p(zz), a0, h0, l0, _p(out)))
+    return out
+
+
+def groth16_finish(pk, sums, r, s):
+    c = lambda a: _p(np.ascontiguousarray(a, dtype=np.uint64))
+    out = np.zeros(72, dtype=np.uint64)
+    _check(load().zkhip_groth16_finish(c(pk["alpha_g1"]), c(pk["beta_g1"]), c(pk["beta_g2"]), c(pk["delta_g1"]), c(pk["delta_g2"]),
+                                       c(np.ascontiguousarray(sums, dtype=np.uint64).reshape(-1)), c(r), c(s), _p(out)))
+    return out
 
 
 def groth16_prove(crs, r1cs, z, r, s):
