@@ -89,8 +89,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP kernels are the only compute path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("ZKHIP_BENCH_FORCE_DIST") == "1"      # exercise the RCCL plumbing with a single rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from zecale_amd import dist as zdist
@@ -108,7 +110,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -123,7 +125,7 @@ def main():
         def step(i):
             s = scal_dev[i % len(scal_dev)]
             part = bases.msm_dev(s.data_ptr(), n, montgomery=False)
-            return zdist.combine_partial_sums(part, device=dev) if world > 1 else part
+            return zdist.combine_partial_sums(part, device=dev) if (world > 1 or force_dist) else part
         units_per_step = n * world
     elif args.workload == "aggregator":
         # the real wrapping circuit on the committed nested fixtures (reference testdata/dummy_app: vk.json, extproof1/2.json)
@@ -160,7 +162,7 @@ def main():
         n = agg.num_constraints
     else:
         # synthetic R1CS of the wrapping circuit's shape: n constraints, n + 5 variables, 4 primary inputs, <= 3 terms per row
-        rng = np.random.default_rng(1234 + rank)
+        rng = np.random.default_rng(1234)               # the circuit and the witness are the same on every rank
         n = n - 8                    # n + l + 1 <= 2^log_n: the QAP domain (and the H query) has exactly 2^log_n points
         m, l = n + 5, 4
         def rand_csr(terms):
@@ -170,13 +172,17 @@ def main():
             return rp, cols, vals
         r1 = zkhip.R1cs(rand_csr(2), rand_csr(2), rand_csr(2), m, l)
         d = 1 << r1.log_d
-        pk = dict(alpha_g1=g1, beta_g1=g1, beta_g2=g1, delta_g1=g1, delta_g2=g1)
-        for key, cnt, seed in (("A", m, 1), ("B2", m, 2), ("B1", m, 3), ("H", d - 1, 4), ("L", m - l - 1, 5)):
-            pk[key] = gen_bases(seed * 7919 + rank, cnt).cpu().numpy().view(np.uint64)
-        crs = zkhip.Crs(pk, m, l, d)
+        consts = dict(alpha_g1=g1, beta_g1=g1, beta_g2=g1, delta_g1=g1, delta_g2=g1)
+        # N > 1: ONE proof per step, the proving key partitioned over the ranks (strong scaling, BASELINE configs[3]):
+        # every rank holds a 1/N slice of each query vector and the ranks exchange 5 x 288 bytes per proof.
+        a_rng, h_rng, l_rng = zdist.key_slices(m, l, d, world, rank)
+        pk = {}
+        for key, (lo, hi), seed in (("A", a_rng, 1), ("B2", a_rng, 2), ("B1", a_rng, 3), ("H", h_rng, 4), ("L", l_rng, 5)):
+            pk[key] = gen_bases(seed * 7919 + rank, hi - lo).cpu().numpy().view(np.uint64)
+        crs = zkhip.crs_from_slice_arrays(consts, pk, m, l, d, a_rng, h_rng, l_rng)
         del pk
         # boolean-heavy witness: 60 % of the variables in {0, 1} (Montgomery form), the rest uniform
-        z = random_fr_canonical(99 + rank, m)
+        z = random_fr_canonical(99, m)
         sel = rng.random(m)
         one_m = np.array(zkhip_fr_one(), dtype=np.uint64)
         z[sel < 0.3] = 0
@@ -185,8 +191,11 @@ def main():
         rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
 
         def step(i):
-            return zkhip.groth16_prove(crs, r1, z, rr, ss)
-        units_per_step = world
+            if world > 1 or force_dist:
+                return zdist.prove_distributed(crs, r1, consts, z, rr, ss, device=dev)
+            return zkhip.groth16_finish(consts, zkhip.groth16_prove_partial(crs, r1, z), rr, ss)
+        units_per_step = 1
+        extra["scaling_override"] = "strong"
 
     for i in range(args.warmup):
         step(i)
@@ -200,7 +209,7 @@ def main():
             phase.append(zkhip.last_prove_timings())
     barrier()
     dt = time.time() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -246,6 +255,9 @@ def main():
                                  "multiplications per second in the kernel / measured chip peak of the multiplier",
                          "fq_mul_frac": round(terms_in_kernel * 24 * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4) if timed else None},
         }
+        if "scaling_override" in extra:
+            out["scaling"] = extra.pop("scaling_override")
+            out["config"]["parallelism"] = "proving key partitioned x%d, RCCL all-gather of 5 x 288-byte partial sums per proof" % world
         out.update(extra)
         if not args.no_cpu_baseline:
             from oracle import oracle as O
@@ -269,7 +281,7 @@ def main():
                              "" if args.workload == "msm" else "; proofs/s extrapolated as 5 MSMs of 2^%d terms per proof" % args.log_n),
                 "parity_with_gpu_on_sample": parity}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -274,6 +274,33 @@ class Crs:
         return self
 
 
+def crs_from_slice_arrays(consts, slices, n_vars, n_primary, domain_size, a_range, h_range, l_range):
+    """Like Crs.upload_slice, but from arrays that hold ONLY this rank's slices (A, B2, B1: a_hi - a_lo points; H; L):
+    what a rank of a multi-GPU job keeps in host memory.  consts: alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2."""
+    d = CrsDesc()
+    d.n_vars, d.n_primary, d.domain_size = n_vars, n_primary, domain_size
+    keep = []
+    for field in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2"):
+        a = np.ascontiguousarray(consts[field], dtype=np.uint64).reshape(24)
+        keep.append(a)
+        setattr(d, field, a.ctypes.data)
+    for field, key, lo, n in (("a_query", "A", a_range[0], a_range[1] - a_range[0]), ("b_g2_query", "B2", a_range[0], a_range[1] - a_range[0]),
+                              ("b_g1_query", "B1", a_range[0], a_range[1] - a_range[0]), ("h_query", "H", h_range[0], h_range[1] - h_range[0]),
+                              ("l_query", "L", l_range[0], l_range[1] - l_range[0])):
+        a = np.ascontiguousarray(slices[key], dtype=np.uint64).reshape(-1, 24)
+        assert a.shape[0] == n, (key, a.shape, n)
+        keep.append(a)
+        # the descriptor addresses the FULL vector: element `lo` of it is the first element of this slice
+        setattr(d, field, (a.ctypes.data - lo * 192) if n else None)
+    c = Crs.__new__(Crs)
+    h = ctypes.c_void_p()
+    _check(load().zkhip_crs_upload_slice(ctypes.byref(d), a_range[0], a_range[1] - a_range[0], h_range[0], h_range[1] - h_range[0],
+                                         l_range[0], l_range[1] - l_range[0], ctypes.byref(h)))
+    c.handle = h
+    c.ranges = (a_range, h_range, l_range)
+    return c
+
+
 def groth16_prove_partial(crs_slice, r1cs, z):
     """The five partial sums (5 x 36 limbs) of this rank's key slice."""
     zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(r1cs.n_vars, 6)
