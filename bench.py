@@ -244,8 +244,9 @@ def main():
         out = {
             "metric": metric, "value": round(value, 4), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (27 x 29-bit limbs: 761-bit Montgomery integers)", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "terms_per_gpu": n, "bases": "resident in HBM (proving key)",
+                       "arithmetic": "761-bit Montgomery integers as 27 x 29-bit limbs in u32, products via v_mad_u64_u32",
                        "parallelism": "point-partitioned x%d, RCCL all-gather of 288-byte partial sums" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3) if timed else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6) if timed else None, "traffic": measured_traffic() if timed else None,
