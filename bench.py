@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--workload", choices=["msm", "prover", "aggregator"], default="msm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-table", action="store_true", help="plain base sets: no precomputed window tables")
     ap.add_argument("--cpu-sample-log", type=int, default=17)
     args = ap.parse_args()
 
@@ -98,6 +99,7 @@ def main():
     from zecale_amd import dist as zdist
     from zecale_amd import zkhip
     zkhip.init(local)
+    zkhip.set_crs_precompute(not args.no_table)
     n = 1 << args.log_n
     g1 = g1_generator_limbs()
 
@@ -118,6 +120,9 @@ def main():
     if args.workload == "msm":
         bases_dev = gen_bases(0x5EED + 1000 * rank, n)
         bases = zkhip.Bases.upload_dev(bases_dev.data_ptr(), n)
+        if not args.no_table:
+            bases.precompute()          # setup-time, like loading the proving key: not part of a step
+        extra["table_window"] = bases.table_window
         scal_dev = [torch.from_numpy(random_fr_canonical(0xABC0 + 17 * i + 1000 * rank, n).view(np.int64)).to(dev)
                     for i in range(min(args.steps + args.warmup, 4))]
         torch.cuda.synchronize()
@@ -197,6 +202,8 @@ def main():
         units_per_step = 1
         extra["scaling_override"] = "strong"
 
+    if args.workload in ("prover", "aggregator"):
+        extra["table_window"] = crs.table_window
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -237,6 +244,8 @@ def main():
                         "4 primary inputs, random proving key of that shape" % args.log_n)
             terms_in_kernel = n - 5       # the last MSM of a proof is L
             extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
+        tw = extra.pop("table_window", None)
+        digits = -(-378 // tw) if tw else 24 if terms_in_kernel > (1 << 18) else None
         timed = k_ms > 0        # the prover replays captured hipGraphs: no per-kernel events there (profiles/ has the kernel traces)
         if not timed:
             k_ms = float("nan")
@@ -245,7 +254,9 @@ def main():
             "metric": metric, "value": round(value, 4), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": workload, "terms_per_gpu": n, "bases": "resident in HBM (proving key)",
+            "config": {"workload": workload, "terms_per_gpu": n,
+                       "bases": ("resident in HBM (proving key) with window tables: 2^(%d w) P_i for the %d window positions, built at "
+                                 "key-load time, %d x the key's memory" % (tw, digits, digits)) if tw else "resident in HBM (proving key)",
                        "arithmetic": "761-bit Montgomery integers as 27 x 29-bit limbs in u32, products via v_mad_u64_u32",
                        "parallelism": "point-partitioned x%d, RCCL all-gather of 288-byte partial sums" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3) if timed else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -254,7 +265,8 @@ def main():
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_TERM * terms_in_kernel,
                          "note": "this path is integer-multiply bound, not HBM bound (SURVEY 0.5): fq_mul_frac = Fq "
                                  "multiplications per second in the kernel / measured chip peak of the multiplier",
-                         "fq_mul_frac": round(terms_in_kernel * 24 * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4) if timed else None},
+                         "fq_mul_frac": round(terms_in_kernel * digits * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4) if (timed and digits) else None,
+                         "mixed_additions_per_term": digits},
         }
         if "scaling_override" in extra:
             out["scaling"] = extra.pop("scaling_override")

@@ -52,6 +52,14 @@ int zkhip_bases_upload(const uint64_t* bases_affine, size_t len, zkhip_bases** o
 int zkhip_bases_upload_dev(const void* d_bases_affine, size_t len, zkhip_bases** out);
 size_t zkhip_bases_len(const zkhip_bases* b);
 void zkhip_bases_free(zkhip_bases* b);
+/* Window table for a resident base set (a proving key stays in HBM for the life of the server, the reference keeps it
+ * in RAM: aggregator_server.cpp:483-514): stores 2^(c w) P_i for every window position w, so that all digit positions
+ * of a scalar share one bucket window.  Costs ceil(378/c) x the memory of the base set, once; results of zkhip_msm are
+ * unchanged (same group element).  c = 0 chooses the window from the length.  zkhip_crs_upload builds the tables of a
+ * key by default; zkhip_set_crs_precompute(0) turns that off. */
+int zkhip_bases_precompute(zkhip_bases* b, int c);
+int zkhip_bases_table_window(const zkhip_bases* b);      /* 0: no table */
+int zkhip_set_crs_precompute(int on);
 
 /* replaces: libff::multi_exp<G, Fr, multi_exp_method_BDLO12>(bases, scalars, chunks)
  * as called five times by r1cs_gg_ppzksnark_prover (reached from aggregator_circuit.tcc:168).
@@ -115,6 +123,7 @@ typedef struct {
 typedef struct zkhip_crs zkhip_crs;
 int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out);
 void zkhip_crs_free(zkhip_crs* c);
+int zkhip_crs_table_window(const zkhip_crs* c);          /* window of the key's tables, 0: none */
 
 /* replaces: wsnarkT::generate_proof(pk, pb) = libsnark::r1cs_gg_ppzksnark_prover (called at
  * libzecale/circuits/aggregator_circuit.tcc:168), with the randomisers (r, s) injected so that

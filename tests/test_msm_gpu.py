@@ -140,3 +140,79 @@ def test_heavy_buckets_are_stitched(zk, oracle_lib):
         scal_m = np.array([O.f_op("from_canonical", 1, s) for s in scal])
         assert (got == O.jac_to_affine(O.msm(bases, scal_m))).all()
     zk.set_msm_window(0)
+
+
+# ---- window tables (zkhip_bases_precompute): same group element as the plain path and as the oracle ----
+
+@pytest.mark.parametrize("window", [0, 5, 9, 13])
+def test_table_golden_vectors(zk, window):
+    """Every golden MSM vector through a table-backed base set (includes infinity bases, P + (-P), r - 1)."""
+    for case in golden("msm_vectors.json"):
+        bases = np.array([aff_limbs(pt_from_json(p)) for p in case["bases"]])
+        scal = fr_array([h2i(s) for s in case["scalars"]])
+        b = zk.Bases.upload(bases).precompute(window)
+        assert b.table_window == (window or b.table_window) and b.table_window > 0
+        got = aff_point(zk.jac_to_affine(b.msm(scal)))
+        b.free()
+        assert got == pt_from_json(case["result"]), case["name"]
+
+
+@pytest.mark.parametrize("n,window", [(1 << 10, 0), (5000, 11), (1 << 14, 0), (1 << 14, 17), (3001, 20)])
+def test_table_random_vs_oracle(zk, oracle_lib, n, window):
+    O = oracle_lib
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(300 + n, n), montgomery=False)
+    bases[7] = 0                                     # a base at infinity
+    scal = random_fr_canonical(400 + n, n)
+    scal[3] = 0
+    scal[4, :] = 0; scal[4, 0] = 1
+    b = zk.Bases.upload(bases).precompute(window)
+    exp = O.jac_to_affine(O.msm(bases, scal))
+    assert (zk.jac_to_affine(b.msm(scal)) == exp).all()
+    # sub-range of a table-backed set
+    off, ln = 17, n - 100
+    assert (zk.jac_to_affine(b.msm(scal[:ln], offset=off)) == O.jac_to_affine(O.msm(bases[off:off + ln], scal[:ln]))).all()
+    with pytest.raises(zk.ZkhipError):
+        b.precompute(window)                         # only once
+    b.free()
+
+
+def test_table_g2_and_witness_like(zk, oracle_lib):
+    O = oracle_lib
+    n = 4096
+    bases = zk.fixed_base_mul(aff_limbs(R.G2_GEN), random_fr_canonical(501, n), montgomery=False)
+    rng = np.random.default_rng(6)
+    sel = rng.random(n)
+    scal = fr_array([0 if s < 0.35 else 1 if s < 0.7 else int(x) for s, x in zip(sel, rng.integers(2, 1 << 62, n))])
+    big = random_fr_canonical(502, n)
+    scal[sel > 0.85] = big[sel > 0.85]
+    b = zk.Bases.upload(bases).precompute()
+    assert (zk.jac_to_affine(b.msm(scal)) == O.jac_to_affine(O.msm(bases, scal))).all()
+    b.free()
+
+
+def test_table_point_of_order_two(zk, oracle_lib):
+    """(1, 0) lies on G1's curve y^2 = x^3 - 1 and has order 2: every table level above 0 is the point at infinity.
+    Not a proving-key element, but zkhip_msm is a general group operation."""
+    O = oracle_lib
+    n = 64
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(601, n), montgomery=False)
+    bases[5] = aff_limbs((1, 0))
+    assert O.on_curve(bases[5])
+    scal = random_fr_canonical(602, n)
+    b = zk.Bases.upload(bases).precompute(6)
+    assert (zk.jac_to_affine(b.msm(scal)) == O.jac_to_affine(O.msm(bases, scal))).all()
+    b.free()
+
+
+def test_table_full_size_2_20_matches_plain_path(zk):
+    """BASELINE config 2 size: the table-backed MSM returns the same point as the plain path (itself pinned against the
+    oracle by test_full_size_2_20_closed_form)."""
+    n = 1 << 20
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(61, n), montgomery=False)
+    s = random_fr_canonical(62, n)
+    b = zk.Bases.upload(bases)
+    zk.set_msm_window(0)
+    plain = zk.jac_to_affine(b.msm(s, montgomery=False))
+    b.precompute()
+    assert (zk.jac_to_affine(b.msm(s, montgomery=False)) == plain).all()
+    b.free()

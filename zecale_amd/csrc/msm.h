@@ -11,7 +11,9 @@ namespace zkhip {
 struct AffPacked;
 
 struct MsmCtx {
-  int c, W, L, logL;
+  int c, W, L, logL;   // W: bucket windows (each owns 2^(c-1) buckets)
+  int Wd;              // digits per scalar: W without a table; with a precomputed table all Wd digit positions share ONE bucket window
+  int merged;          // 1: bases are a table  table[w * stride + i] = 2^(c w) P_i  (msm_table_build)
   uint16_t win_off[96];
   uint8_t win_bits[96];
   size_t B, max_n;
@@ -28,14 +30,20 @@ struct MsmCtx {
   char errbuf[256];
 };
 
-int msm_plan_init(MsmCtx* ctx, size_t max_n, int c);
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged);
 void msm_plan_free(MsmCtx* ctx);
-int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags);
+int msm_bases_convert(const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags, char* errbuf, size_t errlen);
+// table_stride: distance (in points) between the levels of a precomputed table (merged plans only)
 int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
-               int scalars_montgomery);
+               int scalars_montgomery, size_t table_stride);
 int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]);
 int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
-            int scalars_montgomery, uint64_t out_jac[36]);
+            int scalars_montgomery, size_t table_stride, uint64_t out_jac[36]);
+// levels of a window table for window size c
+static inline int msm_table_levels(int c) { return (378 + c - 1) / c; }
+// d_table: levels x n points, level 0 (= the n base points) already in place; d_tinf: levels x n flags, level 0 in place.
+// Fills levels 1 .. levels-1:  table[w * n + i] = 2^(c w) P_i  in affine packed form.
+int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, char* errbuf, size_t errlen);
 
 int fixed_base_mul(const uint64_t base_aff[24], const uint64_t* d_scalars, size_t n, int montgomery, uint64_t* d_out,
                    char* errbuf, size_t errlen);

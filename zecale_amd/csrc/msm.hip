@@ -63,13 +63,16 @@ struct WindowPlan {
 
 // one thread per scalar.  digits[w*n + i] = signed digit of window w (|d| <= 2^(bits_w - 1));
 // counts[w*B + |d|-1] += 1 for d != 0   (B = 2^(c-1) bucket slots per window).
+// merged != 0 (precomputed table): every digit position uses the SAME bucket window (bucket = |d| - 1) because the
+// entry will point at 2^(c w) P_i instead of P_i; inf_flags then has one row of `tab_stride` flags per level.
 __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restrict__ scalars, size_t n, int c, int W,
                                                         WindowPlan plan, int montgomery, const uint8_t* __restrict__ inf_flags,
+                                                        int merged, size_t tab_stride,
                                                         int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   if (!live) i = n - 1;                    // keep whole waves in the loop: the hot-bucket atomics are wave-aggregated
-  const bool skip = !live || (inf_flags && inf_flags[i]);   // a base at infinity contributes nothing: drop it here
+  const bool skip0 = !live || (inf_flags && inf_flags[i]);   // a base at infinity contributes nothing: drop it here
   uint64_t s[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) s[k] = scalars[i * 6 + k];
@@ -97,6 +100,7 @@ __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restric
     int32_t sd;
     if (d > (1u << (cw - 1))) { sd = (int32_t)d - (int32_t)(1u << cw); carry = 1; }
     else { sd = (int32_t)d; carry = 0; }
+    const bool skip = skip0 || (merged && w > 0 && inf_flags && inf_flags[(size_t)w * tab_stride + i]);   // 2^(c w) P_i = O
     if (skip) sd = 0;
     if (live) digits[(size_t)w * n + i] = sd;
     // "scalar == 1" (boolean-heavy witnesses) puts a third of all points into bucket (window 0, digit 1):
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restric
     }
     if (sd != 0 && !hot) {
       uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
-      atomicAdd(&counts[(size_t)w * B + (mag - 1)], 1u);
+      atomicAdd(&counts[(merged ? (size_t)0 : (size_t)w * B) + (mag - 1)], 1u);
     }
   }
 }
@@ -167,6 +171,7 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ out, co
 }
 
 __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, size_t n, int c, int W,
+                                                  int merged, size_t tab_stride,
                                                   const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                                                   uint32_t* __restrict__ entries) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,9 +192,9 @@ __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ dig
     }
     if (sd == 0 || hot) continue;
     uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
-    size_t b = (size_t)w * B + (mag - 1);
+    size_t b = (merged ? (size_t)0 : (size_t)w * B) + (mag - 1);
     uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
-    entries[pos] = (uint32_t)i | (sd < 0 ? 0x80000000u : 0u);
+    entries[pos] = (uint32_t)(merged ? (size_t)w * tab_stride + i : i) | (sd < 0 ? 0x80000000u : 0u);
   }
 }
 
@@ -495,6 +500,88 @@ __global__ void __launch_bounds__(256, 2) k_fixed_base_mul(const AffPacked* __re
   fp_to_abi<FqParams>(mem_ld(acc, CY), o + 12);
 }
 
+// ---- window tables: table[w * n + i] = 2^(c w) P_i, affine, for w = 1 .. levels-1 (level 0 is the base set itself).
+// With the table every digit position of a scalar addresses the same bucket window (the entry points at the
+// pre-shifted base), so one MSM has 2^(c-1) buckets instead of W * 2^(c-1): the bucket reduction shrinks W-fold and c
+// can grow until the accumulation (n * ceil(378/c) mixed additions) stops shrinking.  Built once per base set (a
+// proving key lives in HBM for the life of the server; 288 GB hold a 2^22 key 19 times over).
+// One lane per point: a chain of c doublings per level on a memory-resident XYZZ accumulator, every level kept;
+// then ONE inversion per point normalises all levels (Montgomery's trick over the levels: prefix products in a fifth
+// coordinate row of the work array).  Setup-time code: the multiplications outside dbl_mem are out-of-line calls.
+__device__ __noinline__ Fq fq_mul_ool(const Fq& a, const Fq& b) { return fp_mul(a, b); }
+
+// XyzzRef over 5 coordinate rows (X, Y, ZZ, ZZZ, scratch)
+__device__ __forceinline__ XyzzRef make_ref5(uint32_t* base, uint32_t stride, uint32_t idx) {
+  XyzzRef r;
+  r.rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(135u * stride * 4u), 0x00020000);
+  r.stride_b = stride * 4u;
+  r.voff = idx * 4u;
+  return r;
+}
+
+__global__ void __launch_bounds__(256, 2) k_table_build(AffPacked* __restrict__ table, uint8_t* __restrict__ tinf, size_t n, size_t i0,
+                                                         uint32_t cn, int c, int levels, uint32_t* __restrict__ work, uint32_t stride) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cn) return;
+  const size_t i = i0 + t;
+  const AffPacked* p = &table[i];
+  if (tinf[i]) {
+    for (int w = 1; w < levels; w++) {
+      AffPacked z;
+#pragma unroll
+      for (int k = 0; k < 24; k++) { z.x[k] = 0; z.y[k] = 0; }
+      table[(size_t)w * n + i] = z;
+      tinf[(size_t)w * n + i] = 1;
+    }
+    return;
+  }
+  const int CQ = 4;   // fifth row: prefix products
+  // doubling chain
+  for (int w = 1; w < levels; w++) {
+    XyzzRef r = make_ref5(work, stride, (uint32_t)(w - 1) * cn + t);
+    if (w == 1) {
+      mem_st(r, CX, aff_ld_x(p)); mem_st(r, CY, aff_ld_y(p, false));
+      mem_st(r, CZZ, fp_one<FqParams>()); mem_st(r, CZZZ, fp_one<FqParams>());
+    } else {
+      mem_copy(r, make_ref5(work, stride, (uint32_t)(w - 2) * cn + t));
+    }
+#pragma unroll 1
+    for (int d = 0; d < c; d++) dbl_mem(r);
+  }
+  // prefix products of ZZ * ZZZ over the finite levels
+  Fq q = fp_one<FqParams>();
+  for (int w = 1; w < levels; w++) {
+    XyzzRef r = make_ref5(work, stride, (uint32_t)(w - 1) * cn + t);
+    Fq zz = mem_ld(r, CZZ);
+    if (!fp_is_zero_2p(zz)) q = fq_mul_ool(q, fq_mul_ool(zz, mem_ld(r, CZZZ)));
+    mem_st(r, CQ, q);
+  }
+  Fq inv = fq_inv_fermat(q);      // q != 0: a product of non-zero field elements
+  for (int w = levels - 1; w >= 1; w--) {
+    XyzzRef r = make_ref5(work, stride, (uint32_t)(w - 1) * cn + t);
+    Fq zz = mem_ld(r, CZZ);
+    AffPacked o;
+    uint8_t is_inf = 0;
+    if (fp_is_zero_2p(zz)) {       // 2^(c w) P_i = O (a base outside the odd-order subgroup)
+#pragma unroll
+      for (int k = 0; k < 24; k++) { o.x[k] = 0; o.y[k] = 0; }
+      is_inf = 1;
+    } else {
+      Fq zzz = mem_ld(r, CZZZ);
+      Fq qprev = fp_one<FqParams>();
+      if (w > 1) qprev = mem_ld(make_ref5(work, stride, (uint32_t)(w - 2) * cn + t), CQ);
+      Fq tinv = fq_mul_ool(inv, qprev);                 // 1 / (ZZ ZZZ) of this level
+      inv = fq_mul_ool(inv, fq_mul_ool(zz, zzz));       // inverse of the prefix below
+      Fq x = fq_mul_ool(mem_ld(r, CX), fq_mul_ool(tinv, zzz));   // X / ZZ
+      Fq y = fq_mul_ool(mem_ld(r, CY), fq_mul_ool(tinv, zz));    // Y / ZZZ
+      fp_pack32<FqParams>(fp_cond_sub_p(x), o.x);
+      fp_pack32<FqParams>(fp_cond_sub_p(y), o.y);
+    }
+    table[(size_t)w * n + i] = o;
+    tinf[(size_t)w * n + i] = is_inf;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
@@ -509,17 +596,27 @@ __global__ void __launch_bounds__(256, 2) k_fixed_base_mul(const AffPacked* __re
 
 static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
-int msm_plan_init(MsmCtx* ctx, size_t max_n, int c) {
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged) {
   memset(ctx, 0, sizeof *ctx);
-  if (c < 4 || c > 18) return ZKHIP_ERR_ARG;   // 108 * W * 2^(c-1) * 4 bytes must stay below 4 GiB (buffer descriptor)
+  // 108 * (W * 2^(c-1) + 2T) * 4 bytes must stay below 4 GiB (buffer descriptor); checked below
+  if (c < 4 || c > (merged ? 22 : 18)) return ZKHIP_ERR_ARG;
   ctx->c = c;
-  ctx->W = (378 + c - 1) / c;   // scalars < 2^377, +1 bit for the signed-digit carry
-  {
-    int n_small = ctx->W * c - 378, bit = 0;   // that many windows get c-1 bits (the top ones)
-    for (int w = 0; w < ctx->W; w++) {
-      int cw = (w >= ctx->W - n_small) ? c - 1 : c;
+  ctx->merged = merged ? 1 : 0;
+  ctx->Wd = (378 + c - 1) / c;   // scalars < 2^377, +1 bit for the signed-digit carry
+  ctx->W = merged ? 1 : ctx->Wd;
+  if (!merged) {
+    int n_small = ctx->Wd * c - 378, bit = 0;   // that many windows get c-1 bits (the top ones)
+    for (int w = 0; w < ctx->Wd; w++) {
+      int cw = (w >= ctx->Wd - n_small) ? c - 1 : c;
       ctx->win_off[w] = (uint16_t)bit; ctx->win_bits[w] = (uint8_t)cw;
       bit += cw;
+    }
+  } else {
+    // table levels are 2^(c w) P: uniform windows, the top one takes what is left of the 378 bits (all digit
+    // positions share one bucket window, so a short top window costs nothing)
+    for (int w = 0; w < ctx->Wd; w++) {
+      int cw = 378 - w * c < c ? 378 - w * c : c;
+      ctx->win_off[w] = (uint16_t)(w * c); ctx->win_bits[w] = (uint8_t)cw;
     }
   }
   ctx->B = (size_t)1 << (c - 1);
@@ -532,16 +629,17 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c) {
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&ctx->ev_acc0));
   HIP_TRY(hipEventCreate(&ctx->ev_acc1));
-  HIP_TRY(hipMalloc(&ctx->digits, (size_t)ctx->W * max_n * sizeof(int32_t)));
+  if ((size_t)ctx->Wd * max_n >= ((size_t)1 << 31)) return ZKHIP_ERR_ARG;   // entry = 31-bit point index + sign
+  HIP_TRY(hipMalloc(&ctx->digits, (size_t)ctx->Wd * max_n * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&ctx->counts, nb * 4));
   HIP_TRY(hipMalloc(&ctx->offsets, nb * 4));
   HIP_TRY(hipMalloc(&ctx->cursor, nb * 4));
   HIP_TRY(hipMalloc(&ctx->block_tot, (nb / 1024 + 2) * 4));
-  HIP_TRY(hipMalloc(&ctx->entries, (size_t)ctx->W * max_n * 4));
+  HIP_TRY(hipMalloc(&ctx->entries, (size_t)ctx->Wd * max_n * 4));
   // slice length: every lane gets the same number of point operations; aim at a whole number of
   // machine fills (256 CUs x 8 waves x 64 lanes at two waves per SIMD)
   {
-    const size_t lanes = 131072, m_max = (size_t)ctx->W * max_n;
+    const size_t lanes = 131072, m_max = (size_t)ctx->Wd * max_n;
     size_t fills = (m_max + lanes * 48 - 1) / (lanes * 48);     // ~48 entries per lane and fill
     if (fills < 1) fills = 1;
     size_t S = (m_max + lanes * fills - 1) / (lanes * fills);
@@ -582,17 +680,21 @@ void msm_plan_free(MsmCtx* ctx) {
   memset(ctx, 0, sizeof *ctx);
 }
 
-int msm_bases_convert(MsmCtx* ctx, const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags) {
-  hipLaunchKernelGGL(k_bases_to_dev, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_bases_abi, d_out, d_inf_flags, n);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+int msm_bases_convert(const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags, char* errbuf, size_t errlen) {
+  hipLaunchKernelGGL(k_bases_to_dev, dim3(nblk(n, 256)), dim3(256), 0, 0, d_bases_abi, d_out, d_inf_flags, n);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    if (errbuf) snprintf(errbuf, errlen, "msm_bases_convert: %s", hipGetErrorString(e));
+    return ZKHIP_ERR_HIP;
+  }
   return ZKHIP_OK;
 }
 
 // d_bases: packed device-form points; d_scalars: n x 6 u64 (device memory).  Result: Jacobian, ABI form (host).
 int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
-            int scalars_montgomery, uint64_t out_jac[36]) {
-  int rc = msm_launch(ctx, d_bases, d_inf_flags, d_scalars, n, scalars_montgomery);
+            int scalars_montgomery, size_t table_stride, uint64_t out_jac[36]) {
+  int rc = msm_launch(ctx, d_bases, d_inf_flags, d_scalars, n, scalars_montgomery, table_stride);
   if (rc != ZKHIP_OK) return rc;
   return msm_finish(ctx, out_jac);
 }
@@ -600,9 +702,10 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, c
 // Enqueue one MSM on the context's streams and return without waiting (the prover keeps two contexts
 // in flight so that the latency-bound reduction of one MSM overlaps the accumulation of the next).
 int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
-               int scalars_montgomery) {
+               int scalars_montgomery, size_t table_stride) {
   if (n > ctx->max_n) return ZKHIP_ERR_ARG;
-  const int c = ctx->c, W = ctx->W;
+  const int c = ctx->c, W = ctx->W, Wd = ctx->Wd, merged = ctx->merged;
+  if (merged && (table_stride < n || (size_t)Wd * table_stride >= ((size_t)1 << 31))) return ZKHIP_ERR_ARG;
   const size_t B = ctx->B, nb = B * W;
   hipStream_t st = ctx->stream;
   ctx->pending_n = n;
@@ -612,20 +715,20 @@ int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags
   HIP_TRY(hipMemsetAsync(ctx->cursor, 0, nb * 4, st));
   WindowPlan plan;
   memset(&plan, 0, sizeof plan);
-  for (int w = 0; w < W; w++) { plan.off[w] = ctx->win_off[w]; plan.bits[w] = ctx->win_bits[w]; }
-  hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(n, 256)), dim3(256), 0, st, d_scalars, n, c, W, plan, scalars_montgomery,
-                     d_inf_flags, ctx->digits, ctx->counts);
+  for (int w = 0; w < Wd; w++) { plan.off[w] = ctx->win_off[w]; plan.bits[w] = ctx->win_bits[w]; }
+  hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(n, 256)), dim3(256), 0, st, d_scalars, n, c, Wd, plan, scalars_montgomery,
+                     d_inf_flags, merged, table_stride, ctx->digits, ctx->counts);
   unsigned sb = nblk(nb, 1024);
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->counts, ctx->offsets, ctx->block_tot, nb);
   hipLaunchKernelGGL(k_scan_tot, dim3(1), dim3(1024), 0, st, ctx->block_tot, (size_t)sb);
   hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, ctx->offsets, ctx->block_tot, nb);
-  hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->digits, n, c, W, ctx->offsets, ctx->cursor,
-                     ctx->entries);
+  hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->digits, n, c, Wd, merged, table_stride, ctx->offsets,
+                     ctx->cursor, ctx->entries);
   HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 4, st));   // block_tot[0] is reused as the max-span cell (scan is done)
   // slice length for THIS n (the plan's slot array is sized for max_n)
   uint32_t S_run, T_run;
   {
-    const size_t lanes = 131072, m = (size_t)W * n;
+    const size_t lanes = 131072, m = (size_t)Wd * n;
     size_t fills = (m + lanes * 48 - 1) / (lanes * 48);
     if (fills < 1) fills = 1;
     size_t S = (m + lanes * fills - 1) / (lanes * fills);
@@ -775,6 +878,30 @@ int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]) {
     acc = acc.add(q);
   }
   acc.X.to_limbs(out_jac); acc.Y.to_limbs(out_jac + 12); acc.Z.to_limbs(out_jac + 24);
+  return ZKHIP_OK;
+}
+
+int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, char* errbuf, size_t errlen) {
+  const int levels = msm_table_levels(c);
+  if (n == 0 || levels < 2) return ZKHIP_OK;
+  // points per launch: (levels - 1) * chunk slots of 135 words, at most 4M slots (2.2 GB of work space)
+  size_t chunk = ((size_t)1 << 22) / (size_t)(levels - 1);
+  chunk &= ~(size_t)255;
+  if (chunk > n) chunk = n;
+  const uint32_t stride = (uint32_t)(chunk * (size_t)(levels - 1));
+  uint32_t* work = nullptr;
+  hipError_t e = hipMalloc(&work, (size_t)stride * 135 * 4);
+  for (size_t i0 = 0; e == hipSuccess && i0 < n; i0 += chunk) {
+    uint32_t cn = (uint32_t)((n - i0 < chunk) ? n - i0 : chunk);
+    hipLaunchKernelGGL(k_table_build, dim3(nblk(cn, 256)), dim3(256), 0, 0, d_table, d_tinf, n, i0, cn, c, levels, work, stride);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (work) (void)hipFree(work);
+  if (e != hipSuccess) {
+    if (errbuf) snprintf(errbuf, errlen, "msm_table_build: %s", hipGetErrorString(e));
+    return ZKHIP_ERR_HIP;
+  }
   return ZKHIP_OK;
 }
 

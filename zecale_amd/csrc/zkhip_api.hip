@@ -17,9 +17,10 @@
 using namespace zkhip;
 
 struct zkhip_bases {
-  AffPacked* d_pts;
-  uint8_t* d_inf;    // 1 where the base is the point at infinity
+  AffPacked* d_pts;  // len points; after zkhip_bases_precompute: table_c > 0 and levels x len points (level w = 2^(table_c w) P)
+  uint8_t* d_inf;    // 1 where the base (or its table level) is the point at infinity; same shape as d_pts
   size_t len;
+  int table_c;       // 0: plain base set
 };
 
 struct zkhip_r1cs {
@@ -43,6 +44,7 @@ struct Lib {
   bool inited = false;
   int device = -1;
   int forced_c = 0;
+  int crs_tables = 1;       // zkhip_crs_upload builds window tables (zkhip_set_crs_precompute)
   MsmCtx msm;
   bool msm_ready = false;
   MsmCtx msmx[4];           // further contexts: the prover keeps 2 (large) or 5 (small circuits) MSMs in flight
@@ -73,25 +75,28 @@ int auto_window(size_t n) {
   return 16;
 }
 
-int ensure_msmx(int k, size_t n) {
-  int c = auto_window(n);
-  if (g.msmx_ready[k] && g.msmx[k].max_n >= n && g.msmx[k].c == c) return ZKHIP_OK;
-  if (g.msmx_ready[k]) { msm_plan_free(&g.msmx[k]); g.msmx_ready[k] = false; }
-  int rc = msm_plan_init(&g.msmx[k], n, c);
-  if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "msm_plan_init: %s", g.msmx[k].errbuf); return rc; }
-  g.msmx_ready[k] = true;
-  return ZKHIP_OK;
+// window size of a table (one shared bucket window: the reduction is W times cheaper, so c is larger than auto_window's)
+int auto_table_window(size_t n) {
+  if (n <= (1u << 10)) return 9;
+  if (n <= (1u << 13)) return 12;
+  if (n <= (1u << 15)) return 14;
+  if (n <= (1u << 17)) return 16;
+  if (n <= (1u << 19)) return 18;
+  return 20;
 }
 
-int ensure_msm(size_t n) {
-  int c = auto_window(n);
-  if (g.msm_ready && g.msm.max_n >= n && g.msm.c == c) return ZKHIP_OK;
-  if (g.msm_ready) { msm_plan_free(&g.msm); g.msm_ready = false; }
-  int rc = msm_plan_init(&g.msm, n, c);
-  if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "msm_plan_init: %s", g.msm.errbuf); return rc; }
-  g.msm_ready = true;
+// table_c = 0: plain plan with the automatic window;  > 0: merged plan (bases are a window table built for table_c)
+int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c) {
+  const int c = table_c ? table_c : auto_window(n), merged = table_c ? 1 : 0;
+  if (*ready && cx->max_n >= n && cx->c == c && cx->merged == merged) return ZKHIP_OK;
+  if (*ready) { msm_plan_free(cx); *ready = false; }
+  int rc = msm_plan_init(cx, n, c, merged);
+  if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "msm_plan_init: %s", cx->errbuf); return rc; }
+  *ready = true;
   return ZKHIP_OK;
 }
+int ensure_msmx(int k, size_t n, int table_c = 0) { return ensure_ctx(&g.msmx[k], &g.msmx_ready[k], n, table_c); }
+int ensure_msm(size_t n, int table_c = 0) { return ensure_ctx(&g.msm, &g.msm_ready, n, table_c); }
 }  // namespace
 
 extern "C" {
@@ -134,7 +139,7 @@ const char* zkhip_strerror(int code) {
 const char* zkhip_last_error(void) { return g.err; }
 
 int zkhip_set_msm_window(int c) {
-  if (c != 0 && (c < 4 || c > 18)) return fail(ZKHIP_ERR_ARG, "window must be 0 or in [4, 18]");
+  if (c != 0 && (c < 4 || c > 18)) return fail(ZKHIP_ERR_ARG, "window must be 0 or in [4, 18]");   // (tables: zkhip_bases_precompute takes up to 22)
   g.forced_c = c;
   return ZKHIP_OK;
 }
@@ -143,14 +148,12 @@ int zkhip_bases_upload_dev(const void* d_bases_affine, size_t len, zkhip_bases**
   std::lock_guard<std::mutex> lk(g.mu);
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!out || (len && !d_bases_affine)) return fail(ZKHIP_ERR_ARG, "null pointer");
-  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len};
+  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len, 0};
   if (len) {
     API_HIP(hipMalloc(&b->d_pts, len * sizeof(AffPacked)));
     API_HIP(hipMalloc(&b->d_inf, len));
-    int rc = ensure_msm(len);
+    int rc = msm_bases_convert((const uint64_t*)d_bases_affine, len, b->d_pts, b->d_inf, g.err, sizeof g.err);
     if (rc != ZKHIP_OK) return rc;
-    rc = msm_bases_convert(&g.msm, (const uint64_t*)d_bases_affine, len, b->d_pts, b->d_inf);
-    if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", g.msm.errbuf); return rc; }
   }
   *out = b;
   return ZKHIP_OK;
@@ -171,6 +174,32 @@ int zkhip_bases_upload(const uint64_t* bases_affine, size_t len, zkhip_bases** o
 
 size_t zkhip_bases_len(const zkhip_bases* b) { return b ? b->len : 0; }
 
+int zkhip_set_crs_precompute(int on) { g.crs_tables = on ? 1 : 0; return ZKHIP_OK; }
+
+int zkhip_bases_precompute(zkhip_bases* b, int c) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!b) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (b->table_c) return fail(ZKHIP_ERR_STATE, "base set already has a window table");
+  if (c == 0) c = auto_table_window(b->len);
+  if (c < 4 || c > 22) return fail(ZKHIP_ERR_ARG, "table window must be 0 (automatic) or in [4, 22]");
+  if (b->len == 0) { b->table_c = c; return ZKHIP_OK; }
+  const size_t levels = (size_t)msm_table_levels(c);
+  if (levels * b->len >= ((size_t)1 << 31)) return fail(ZKHIP_ERR_ARG, "table too large (levels * len must stay below 2^31)");
+  AffPacked* tab = nullptr;
+  uint8_t* tinf = nullptr;
+  API_HIP(hipMalloc(&tab, levels * b->len * sizeof(AffPacked)));
+  API_HIP(hipMalloc(&tinf, levels * b->len));
+  API_HIP(hipMemcpy(tab, b->d_pts, b->len * sizeof(AffPacked), hipMemcpyDeviceToDevice));
+  API_HIP(hipMemcpy(tinf, b->d_inf, b->len, hipMemcpyDeviceToDevice));
+  int rc = msm_table_build(tab, tinf, b->len, c, g.err, sizeof g.err);
+  if (rc != ZKHIP_OK) { (void)hipFree(tab); (void)hipFree(tinf); return rc; }
+  (void)hipFree(b->d_pts); (void)hipFree(b->d_inf);
+  b->d_pts = tab; b->d_inf = tinf; b->table_c = c;
+  return ZKHIP_OK;
+}
+int zkhip_bases_table_window(const zkhip_bases* b) { return b ? b->table_c : 0; }
+
 void zkhip_bases_free(zkhip_bases* b) {
   if (!b) return;
   if (b->d_pts) (void)hipFree(b->d_pts);
@@ -184,10 +213,10 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!bases || !out_jac || (len && !d_scalars)) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
-  int rc = ensure_msm(len ? len : 1);
+  int rc = ensure_msm(len ? len : 1, bases->table_c);
   if (rc != ZKHIP_OK) return rc;
   rc = msm_run(&g.msm, bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
-               scalars_montgomery, out_jac);
+               scalars_montgomery, bases->len, out_jac);
   if (rc != ZKHIP_OK) snprintf(g.err, sizeof g.err, "%s", g.msm.errbuf);
   return rc;
 }
@@ -311,6 +340,19 @@ int zkhip_qap_h(zkhip_r1cs* r, const uint64_t* z, uint64_t* h_out) {
   return rc;
 }
 
+// one window size for the whole key (the prover's MSM contexts are shared by the five query vectors)
+static int crs_build_tables(zkhip_crs* c) {
+  if (!g.crs_tables) return ZKHIP_OK;
+  size_t maxlen = c->A->len > c->H->len ? c->A->len : c->H->len;
+  const int tc = g.forced_c ? g.forced_c : auto_table_window(maxlen);
+  zkhip_bases* all[5] = {c->A, c->B2, c->B1, c->H, c->L};
+  for (zkhip_bases* b : all) {
+    int rc = zkhip_bases_precompute(b, tc);
+    if (rc != ZKHIP_OK) return rc;
+  }
+  return ZKHIP_OK;
+}
+
 int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) {
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!d || !out || !d->alpha_g1 || !d->beta_g1 || !d->beta_g2 || !d->delta_g1 || !d->delta_g2)
@@ -326,6 +368,7 @@ int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) {
   if ((rc = zkhip_bases_upload(d->b_g1_query, d->n_vars, &c->B1)) != ZKHIP_OK) return rc;
   if ((rc = zkhip_bases_upload(d->h_query, d->domain_size - 1, &c->H)) != ZKHIP_OK) return rc;
   if ((rc = zkhip_bases_upload(d->l_query, d->n_vars - d->n_primary - 1, &c->L)) != ZKHIP_OK) return rc;
+  if ((rc = crs_build_tables(c)) != ZKHIP_OK) return rc;
   *out = c;
   return ZKHIP_OK;
 }
@@ -346,9 +389,12 @@ int zkhip_crs_upload_slice(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, s
   if ((rc = zkhip_bases_upload(d->b_g1_query + a_lo * 24, a_len, &c->B1)) != ZKHIP_OK) return rc;
   if ((rc = zkhip_bases_upload(d->h_query + h_lo * 24, h_len, &c->H)) != ZKHIP_OK) return rc;
   if ((rc = zkhip_bases_upload(d->l_query + l_lo * 24, l_len, &c->L)) != ZKHIP_OK) return rc;
+  if ((rc = crs_build_tables(c)) != ZKHIP_OK) return rc;
   *out = c;
   return ZKHIP_OK;
 }
+
+int zkhip_crs_table_window(const zkhip_crs* c) { return (c && c->A) ? c->A->table_c : 0; }
 
 void zkhip_crs_free(zkhip_crs* c) {
   if (!c) return;
@@ -388,7 +434,12 @@ static int prove_partial_locked(const zkhip_crs* crs, zkhip_r1cs* r1cs, const ui
   g_prove_ms[1] = ms_since(t0);
   size_t maxlen = a_len > h_len ? a_len : h_len;
   if (maxlen < 1) maxlen = 1;
-  if ((rc = ensure_msm(maxlen)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
+  const int tc = crs->A->table_c;
+  if (crs->B2->table_c != tc || crs->B1->table_c != tc || crs->H->table_c != tc || crs->L->table_c != tc) {
+    (void)hipFree(dz);
+    return fail(ZKHIP_ERR_ARG, "the five query vectors of a proving key must share one table window");
+  }
+  if ((rc = ensure_msm(maxlen, tc)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
   struct { const zkhip_bases* b; const uint64_t* sc; size_t len; int mode; uint64_t* out; } jobs[5] = {
       {crs->A, dz + a_lo * 6, a_len, 1, sums}, {crs->B2, dz + a_lo * 6, a_len, 1, sums + 36}, {crs->B1, dz + a_lo * 6, a_len, 1, sums + 72},
       {crs->H, (const uint64_t*)rd->bufA + h_lo * 6, h_len, 2, sums + 108}, {crs->L, dz + (l + 1 + l_lo) * 6, l_len, 1, sums + 144}};
@@ -398,7 +449,7 @@ static int prove_partial_locked(const zkhip_crs* crs, zkhip_r1cs* r1cs, const ui
   const int nctx = (maxlen <= ((size_t)1 << 18)) ? 5 : 2;
   MsmCtx* ctxs[5] = {&g.msm, nullptr, nullptr, nullptr, nullptr};
   for (int k = 1; k < nctx; k++) {
-    if ((rc = ensure_msmx(k - 1, maxlen)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
+    if ((rc = ensure_msmx(k - 1, maxlen, tc)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
     ctxs[k] = &g.msmx[k - 1];
   }
   clk::time_point tl[5];
@@ -410,7 +461,7 @@ static int prove_partial_locked(const zkhip_crs* crs, zkhip_r1cs* r1cs, const ui
       if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", cx->errbuf); (void)hipFree(dz); return rc; }
     }
     tl[j] = clk::now();
-    rc = msm_launch(cx, jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode);
+    rc = msm_launch(cx, jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].b->len);
     if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", cx->errbuf); (void)hipFree(dz); return rc; }
   }
   for (int j = 5 - nctx; j < 5; j++) {

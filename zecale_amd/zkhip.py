@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libzkhip.so")
 EXPORTS = [
     "zkhip_init", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window",
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
+    "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_last_accumulate_ms",
     "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
@@ -66,6 +67,10 @@ def load():
     lib.zkhip_bases_len.restype = ctypes.c_size_t
     lib.zkhip_bases_len.argtypes = [ctypes.c_void_p]
     lib.zkhip_bases_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_bases_precompute.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.zkhip_bases_table_window.argtypes = [ctypes.c_void_p]
+    lib.zkhip_set_crs_precompute.argtypes = [ctypes.c_int]
+    lib.zkhip_crs_table_window.argtypes = [ctypes.c_void_p]
     lib.zkhip_msm.argtypes = [ctypes.c_void_p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
     lib.zkhip_msm_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, c_u64p]
     lib.zkhip_msm_raw.argtypes = [c_u64p, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
@@ -112,6 +117,11 @@ def set_msm_window(c):
     _check(load().zkhip_set_msm_window(c))
 
 
+def set_crs_precompute(on):
+    """Whether Crs uploads build window tables for the five query vectors (default: on)."""
+    _check(load().zkhip_set_crs_precompute(int(bool(on))))
+
+
 class Bases:
     """A base-point set resident in HBM (the proving key's query vectors)."""
 
@@ -133,6 +143,15 @@ class Bases:
 
     def __len__(self):
         return load().zkhip_bases_len(self.handle)
+
+    def precompute(self, c=0):
+        """Build the window table (2^(c w) P_i for every window position): all later msm calls use it."""
+        _check(load().zkhip_bases_precompute(self.handle, c))
+        return self
+
+    @property
+    def table_window(self):
+        return load().zkhip_bases_table_window(self.handle)
 
     def free(self):
         if self.handle:
@@ -247,6 +266,11 @@ class Crs:
         h = ctypes.c_void_p()
         _check(load().zkhip_crs_upload(ctypes.byref(d), ctypes.byref(h)))
         self.handle = h
+
+    @property
+    def table_window(self):
+        """Window size of the key's precomputed tables (0: plain key)."""
+        return load().zkhip_crs_table_window(self.handle)
 
     def free(self):
         if self.handle:
