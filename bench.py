@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--workload", choices=["msm", "prover", "aggregator"], default="msm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-table", action="store_true", help="plain base sets: no precomputed window tables")
+    ap.add_argument("--no-batch-msms", action="store_true", help="one launch sequence per MSM instead of one per proof")
+    ap.add_argument("--serial", action="store_true", help="aggregator workload: one proof in flight (per-phase timings) instead of the pipeline")
+    ap.add_argument("--gpu-slots", type=int, default=3, help="aggregator pipeline: proofs in flight on the GPU")
+    ap.add_argument("--witness-workers", type=int, default=4, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
     ap.add_argument("--cpu-sample-log", type=int, default=17)
     args = ap.parse_args()
 
@@ -100,6 +104,7 @@ def main():
     from zecale_amd import zkhip
     zkhip.init(local)
     zkhip.set_crs_precompute(not args.no_table)
+    zkhip.set_batch_msms(not args.no_batch_msms)
     n = 1 << args.log_n
     g1 = g1_generator_limbs()
 
@@ -147,22 +152,41 @@ def main():
         nin = np.array([fr_limbs(proofs[0][1][0]), fr_limbs(proofs[1][1][0])])
         rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
         wit_ms = []
-        # two-stage pipeline over successive batches: a host thread generates the witness of batch i+1 (ctypes
-        # releases the GIL) while the GPU proves batch i.  Every step still performs one witness + one proof.
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=1)
+        if args.serial:
+            # two-stage overlap only: a host thread generates the witness of batch i+1 (ctypes releases the GIL) while
+            # the GPU proves batch i; one proof in flight, so the per-phase timings are meaningful.
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=1)
 
-        def make_witness():
-            t = time.time()
-            z = agg.witness(nvk_l, npr, nin)
-            wit_ms.append((time.time() - t) * 1e3)
-            return z
-        pending = [pool.submit(make_witness)]
+            def make_witness():
+                t = time.time()
+                z = agg.witness(nvk_l, npr, nin)
+                wit_ms.append((time.time() - t) * 1e3)
+                return z
+            pending = [pool.submit(make_witness)]
 
-        def step(i):
-            z = pending.pop().result()
-            pending.append(pool.submit(make_witness))
-            return zkhip.groth16_prove(crs, r1, z, rr, ss)
+            def step(i):
+                z = pending.pop().result()
+                pending.append(pool.submit(make_witness))
+                return zkhip.groth16_prove(crs, r1, z, rr, ss)
+        else:
+            # the streaming prover (zkhip_aggregator_pipeline_*): every step submits one batch (witness generation +
+            # proof, nothing cached) and collects the oldest outstanding one; drain() inside the timed region collects
+            # the rest, so exactly `steps` wrapping proofs are produced between the two barriers.
+            pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers)
+            tickets, depth = [], args.gpu_slots + args.witness_workers + 2
+
+            def step(i):
+                tickets.append(pipe.submit(nvk_l, npr, nin, rr, ss))
+                if len(tickets) > depth:
+                    return pipe.wait(tickets.pop(0))
+
+            def drain():
+                out = None
+                while tickets:
+                    out = pipe.wait(tickets.pop(0))
+                return out
+            extra["drain"] = drain
         units_per_step = world
         n = agg.num_constraints
     else:
@@ -186,12 +210,13 @@ def main():
             pk[key] = gen_bases(seed * 7919 + rank, hi - lo).cpu().numpy().view(np.uint64)
         crs = zkhip.crs_from_slice_arrays(consts, pk, m, l, d, a_rng, h_rng, l_rng)
         del pk
-        # boolean-heavy witness: 60 % of the variables in {0, 1} (Montgomery form), the rest uniform
+        # witness shaped like the wrapping circuit's: 5.3 % of its 51,046 variables are 0 or 1 (measured on the real
+        # batch-2 witness: 2,694 zeros, 27 ones - the variables are Fq elements of the in-circuit pairing), the rest uniform
         z = random_fr_canonical(99, m)
         sel = rng.random(m)
         one_m = np.array(zkhip_fr_one(), dtype=np.uint64)
-        z[sel < 0.3] = 0
-        z[(sel >= 0.3) & (sel < 0.6)] = one_m
+        z[sel < 0.052] = 0
+        z[(sel >= 0.052) & (sel < 0.053)] = one_m
         z[0] = one_m
         rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
 
@@ -204,16 +229,19 @@ def main():
 
     if args.workload in ("prover", "aggregator"):
         extra["table_window"] = crs.table_window
+    drain = extra.pop("drain", lambda: None)
     for i in range(args.warmup):
         step(i)
+    drain()
     barrier()
     kernel_ms, phase = [], []
     t0 = time.time()
     for i in range(args.steps):
         step(args.warmup + i)
         kernel_ms.append(zkhip.last_accumulate_ms())
-        if args.workload in ("prover", "aggregator"):
+        if args.workload == "prover" or (args.workload == "aggregator" and args.serial):
             phase.append(zkhip.last_prove_timings())
+    drain()
     barrier()
     dt = time.time() - t0
     if world > 1 or force_dist:
@@ -234,15 +262,22 @@ def main():
             metric = "wrapping proofs/sec (batch-2 BLS12_377 -> BW6_761 aggregation, %d constraints)" % n
             workload = ("BASELINE configs[0]/[2] shape: aggregator circuit batch=2 dummy_app proofs (reference fixtures), host witness "
                         "generation + Groth16 BW6_761 prover on the GPU, end to end")
-            terms_in_kernel = agg.num_variables - 5
-            extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
-            extra["phase_ms"]["witness_host"] = round(float(np.mean(wit_ms)), 3)
+            m_, l_, d_ = agg.num_variables, agg.num_primary_inputs(), 1 << r1.log_d
+            terms_in_kernel = (3 * m_ + (d_ - 1) + (m_ - l_ - 1)) if (tw_batched(extra, args)) else m_ - l_ - 1
+            if args.serial:
+                extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
+                extra["phase_ms"]["witness_host"] = round(float(np.mean(wit_ms)), 3)
+            else:
+                extra["pipeline"] = {"gpu_slots": args.gpu_slots, "witness_workers": args.witness_workers,
+                                     "note": "proofs in flight overlap; --serial gives the per-phase timings of one proof"}
         else:
             value, unit = units_per_step * args.steps / dt, "proofs/s"
             metric = "wrapping proofs/sec (Groth16 over BW6_761, 2^%d constraints)" % args.log_n
             workload = ("BASELINE configs[2]: full Groth16 BW6_761 prover (SpMV + 7 NTT + 5 MSM), synthetic R1CS 2^%d constraints, "
                         "4 primary inputs, random proving key of that shape" % args.log_n)
-            terms_in_kernel = n - 5       # the last MSM of a proof is L
+            # one accumulation launch serves all five MSMs of a proof (table-backed key), else the last MSM of a proof is L
+            al, hl, ll = a_rng[1] - a_rng[0], h_rng[1] - h_rng[0], l_rng[1] - l_rng[0]      # this rank's slice of the key
+            terms_in_kernel = (3 * al + hl + ll) if tw_batched(extra, args) else ll
             extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
         tw = extra.pop("table_window", None)
         digits = -(-378 // tw) if tw else 24 if terms_in_kernel > (1 << 18) else None
@@ -265,7 +300,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_TERM * terms_in_kernel,
                          "note": "this path is integer-multiply bound, not HBM bound (SURVEY 0.5): fq_mul_frac = Fq "
                                  "multiplications per second in the kernel / measured chip peak of the multiplier",
-                         "fq_mul_frac": round(terms_in_kernel * digits * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4) if (timed and digits) else None,
+                         "fq_mul_frac": round(terms_in_kernel * digits * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4) if (timed and digits) else None,   # upper bound when some scalars are 0
                          "mixed_additions_per_term": digits},
         }
         if "scaling_override" in extra:
@@ -296,6 +331,10 @@ def main():
         print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def tw_batched(extra, args):
+    return bool(extra.get("table_window")) and not args.no_batch_msms
 
 
 def zkhip_fr_one():

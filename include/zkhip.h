@@ -60,6 +60,9 @@ void zkhip_bases_free(zkhip_bases* b);
 int zkhip_bases_precompute(zkhip_bases* b, int c);
 int zkhip_bases_table_window(const zkhip_bases* b);      /* 0: no table */
 int zkhip_set_crs_precompute(int on);
+/* Table-backed keys of up to 2^20 points per query vector: the five MSMs of a proof go through one launch sequence
+ * (default on; off = one launch sequence per MSM, 2 or 5 of them in flight).  A tuning / comparison switch. */
+int zkhip_set_batch_msms(int on);
 
 /* replaces: libff::multi_exp<G, Fr, multi_exp_method_BDLO12>(bases, scalars, chunks)
  * as called five times by r1cs_gg_ppzksnark_prover (reached from aggregator_circuit.tcc:168).
@@ -149,6 +152,17 @@ int zkhip_groth16_finish(const uint64_t alpha_g1[24], const uint64_t beta_g1[24]
  * [2..6] the five MSMs A, B2, B1, H, L, [7] host tail */
 int zkhip_last_prove_timings(double out_ms[8]);
 
+/* Prover instances.  The entry points above share one set of device work space and are serialised by the library;
+ * a zkhip_prover owns its streams, MSM work space and QAP buffers, so several host threads (one instance each) keep
+ * several proofs in flight on one GPU.  At the wrapping circuit's size (51k constraints) one proof cannot fill the
+ * chip: the phases after the bucket accumulation are chains of short launches.  Same results as zkhip_groth16_prove.
+ * replaces: one wsnarkT::generate_proof call (aggregator_circuit.tcc:168) per instance and call. */
+typedef struct zkhip_prover zkhip_prover;
+int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prover** out);   /* crs must outlive the prover */
+int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r[6], const uint64_t s[6], uint64_t proof_affine[72]);
+int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]);   /* as zkhip_last_prove_timings, for p's last proof */
+void zkhip_prover_free(zkhip_prover* p);
+
 /* replaces: wsnarkT::verify(primary_inputs, proof, vk) (libzecale/tests/aggregator/aggregator_dummy_test.cpp:61-62)
  * = libsnark r1cs_gg_ppzksnark_verifier_strong_IC for the Clearmatics Groth16 (no gamma in the key:
  * testdata/dummy_app/aggregator_vk.json), i.e. the equation of contracts/Groth16BW6_761.sol:166-176.
@@ -175,6 +189,8 @@ int zkhip_bls12_377_groth16_verify(const uint64_t vk_alpha_g1[12], const uint64_
 typedef struct zkhip_aggregator zkhip_aggregator;
 int zkhip_aggregator_new(size_t num_proofs, size_t inputs_per_proof, zkhip_aggregator** out);
 void zkhip_aggregator_free(zkhip_aggregator* a);
+size_t zkhip_aggregator_num_proofs(const zkhip_aggregator* a);
+size_t zkhip_aggregator_inputs_per_proof(const zkhip_aggregator* a);
 size_t zkhip_aggregator_num_constraints(const zkhip_aggregator* a);
 size_t zkhip_aggregator_num_variables(const zkhip_aggregator* a);      /* including the constant ONE */
 size_t zkhip_aggregator_num_primary_inputs(const zkhip_aggregator* a); /* aggregator_circuit::num_primary_inputs, .tcc:172-180 */
@@ -186,6 +202,21 @@ int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, con
                              const uint64_t* nested_inputs, uint64_t* z_out);
 /* replaces: verification_key_hash_gadget::compute_hash(vk, num_inputs) (verification_key_hash_gadget.tcc:42-59) */
 int zkhip_aggregator_vk_hash(const uint64_t* nested_vk, size_t inputs_per_proof, uint64_t out[6]);
+
+/* Streaming form of aggregator_circuit::prove for a server that wraps batch after batch (the reference's
+ * GenerateAggregatedTransaction loop, aggregator_server.cpp:300-420, handles one batch at a time on the CPU):
+ * `witness_workers` host threads generate witnesses (zkhip_aggregator_witness) while `gpu_slots` prover instances
+ * keep that many proofs in flight on the GPU; the host tail of one proof overlaps the device work of the next.
+ * submit copies its inputs and returns a ticket (it blocks only when 4 x (gpu_slots + witness_workers) batches are
+ * outstanding); wait blocks until that batch is done and returns the extended proof: primary inputs
+ * (num_primary_inputs x 6 limbs: vk hash, packed results, nested inputs) and the proof (a | b | c, 72 limbs).
+ * Every result is bit-identical to zkhip_aggregator_witness + zkhip_groth16_prove on the same inputs, r and s. */
+typedef struct zkhip_pipeline zkhip_pipeline;
+int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, zkhip_pipeline** out);
+int zkhip_aggregator_pipeline_submit(zkhip_pipeline* p, const uint64_t* nested_vk, const uint64_t* nested_proofs,
+                                     const uint64_t* nested_inputs, const uint64_t r[6], const uint64_t s[6], uint64_t* ticket);
+int zkhip_aggregator_pipeline_wait(zkhip_pipeline* p, uint64_t ticket, uint64_t* primary_inputs, uint64_t proof_affine[72]);
+void zkhip_aggregator_pipeline_free(zkhip_pipeline* p);
 
 /* replaces: wsnarkT::generate_setup(pb) = libsnark::r1cs_gg_ppzksnark_generator, reached from
  * aggregator_circuit::generate_trusted_setup (libzecale/circuits/aggregator_circuit.tcc:100-109).

@@ -39,3 +39,64 @@ def test_aggregate_two_dummy_app_proofs(zk, oracle_lib):
         assert not zk.groth16_verify(vk, tampered, proof)
         print("wrapping proof ok, result bits", expected_bits, zk.last_prove_timings())
     crs.free(); r1.free(); kp.free(); agg.free()
+
+
+def _setup(zk):
+    agg = zk.AggregatorCircuit(2, 1)
+    desc = zk.r1cs_desc_from_aggregator(agg)
+    kp = zk.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
+    nvk, proofs = load_nested_fixtures()
+    return agg, desc, kp, nested_vk_limbs(nvk), proofs
+
+
+def test_prover_instances_match_the_plain_entry_point(zk):
+    """zkhip_prover: same proof as zkhip_groth16_prove, also when two instances run at the same time on two host threads
+    (ctypes releases the GIL: both proofs are in flight on the GPU together)."""
+    from concurrent.futures import ThreadPoolExecutor
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
+    zs, rs = [], []
+    for a, b in ((0, 1), (2, 3), (4, 5), (1, 0)):
+        (pa, ia), (pb, ib) = proofs[a], proofs[b]
+        zs.append(agg.witness(nvk_l, np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)]), np.array([fr_limbs(ia[0]), fr_limbs(ib[0])])))
+        rs.append((fr_limbs(0x1111 + a), fr_limbs(0x2222 + b)))
+    expected = [zk.groth16_prove(crs, r1, z, r, s) for z, (r, s) in zip(zs, rs)]
+    provers = [zk.Prover(crs, desc), zk.Prover(crs, desc)]
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        for rep in range(2):
+            futs = [pool.submit(provers[i % 2].prove, zs[i], *rs[i]) for i in range(4)]
+            for i, f in enumerate(futs):
+                assert (f.result() == expected[i]).all(), (rep, i)
+    assert provers[0].timings()["qap"] > 0
+    for p in provers:
+        p.free()
+    crs.free(); r1.free(); kp.free(); agg.free()
+
+
+@pytest.mark.parametrize("slots,workers", [(1, 1), (3, 2)])
+def test_pipeline_matches_serial_path(zk, slots, workers):
+    """Streaming aggregator (zkhip_aggregator_pipeline_*): every extended proof equals witness + groth16_prove done one
+    after the other, whatever the number of GPU slots / witness workers and the order of completion; an invalid nested
+    proof in the stream yields result bits {1, 0} for its batch only (aggregator_dummy_test.cpp:162-186)."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    vk = kp.vk()
+    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
+    pipe = zk.AggregatorPipeline(agg, crs, gpu_slots=slots, witness_workers=workers)
+    jobs = []
+    for i, (a, b, bump) in enumerate(((0, 1, 0), (2, 3, 0), (4, 5, 1), (1, 2, 0), (3, 3, 0), (5, 0, 0), (0, 1, 0))):
+        (pa, ia), (pb, ib) = proofs[a], proofs[b]
+        npr = np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)])
+        nin = np.array([fr_limbs(ia[0]), fr_limbs(ib[0] + bump)])
+        r, s = fr_limbs(0xaaaa + i), fr_limbs(0xbbbb + 7 * i)
+        jobs.append((npr, nin, r, s, 1 if bump else 3, pipe.submit(nvk_l, npr, nin, r, s)))
+    for npr, nin, r, s, bits, ticket in reversed(jobs):                 # collect out of order
+        prim, proof = pipe.wait(ticket)
+        z = agg.witness(nvk_l, npr, nin)
+        assert (prim == z[1:1 + agg.num_primary_inputs()]).all()
+        assert (proof == zk.groth16_prove(crs, r1, z, r, s)).all()
+        assert fr_int(prim[1]) == bits
+        assert zk.groth16_verify(vk, prim, proof)
+    with pytest.raises(zk.ZkhipError):
+        pipe.wait(12345)                                                # unknown ticket
+    pipe.free()
+    crs.free(); r1.free(); kp.free(); agg.free()

@@ -65,7 +65,6 @@ struct zkhip_aggregator {
   size_t n_vars = 0, n_primary = 0, n_constraints = 0;
   std::vector<uint32_t> rp[3], col[3];
   std::vector<uint64_t> val[3];
-  std::mutex mu;
 };
 
 namespace {
@@ -239,6 +238,8 @@ int zkhip_aggregator_new(size_t num_proofs, size_t inputs_per_proof, zkhip_aggre
 }
 
 void zkhip_aggregator_free(zkhip_aggregator* a) { delete a; }
+size_t zkhip_aggregator_num_proofs(const zkhip_aggregator* a) { return a ? a->num_proofs : 0; }
+size_t zkhip_aggregator_inputs_per_proof(const zkhip_aggregator* a) { return a ? a->inputs_per_proof : 0; }
 size_t zkhip_aggregator_num_constraints(const zkhip_aggregator* a) { return a ? a->n_constraints : 0; }
 size_t zkhip_aggregator_num_variables(const zkhip_aggregator* a) { return a ? a->n_vars : 0; }
 size_t zkhip_aggregator_num_primary_inputs(const zkhip_aggregator* a) { return a ? a->n_primary : 0; }
@@ -255,8 +256,7 @@ int zkhip_aggregator_get_r1cs(const zkhip_aggregator* a, zkhip_r1cs_desc* d) {
 int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, const uint64_t* nested_proofs,
                              const uint64_t* nested_inputs, uint64_t* z_out) {
   if (!a || !nested_vk || !nested_proofs || !nested_inputs || !z_out) return ZKHIP_ERR_ARG;
-  std::lock_guard<std::mutex> lk(a->mu);
-  std::vector<HFr> z;
+  std::vector<HFr> z;                  // re-entrant: the circuit description is read-only after zkhip_aggregator_new
   NestedData d{nested_vk, nested_proofs, nested_inputs};
   try {
     witness_parallel(z, a->num_proofs, a->inputs_per_proof, &d);

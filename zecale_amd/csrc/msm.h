@@ -10,10 +10,21 @@ namespace zkhip {
 
 struct AffPacked;
 
+#define MSM_MAX_JOBS 5   // MSMs sharing one launch sequence (the five query vectors of a proof)
+struct MsmJob {
+  const AffPacked* bases;        // table-backed base set (level 0 at bases[0 .. n))
+  const uint8_t* inf_flags;
+  const uint64_t* scalars;       // device memory, n x 6 u64
+  size_t n;
+  int scalars_mode;              // 0 canonical, 1 Montgomery (ABI), 2 packed device form
+  size_t table_stride;           // distance between table levels, in points
+};
+
 struct MsmCtx {
   int c, W, L, logL;   // W: bucket windows (each owns 2^(c-1) buckets)
   int Wd;              // digits per scalar: W without a table; with a precomputed table all Wd digit positions share ONE bucket window
   int merged;          // 1: bases are a table  table[w * stride + i] = 2^(c w) P_i  (msm_table_build)
+  int K;               // merged plans: MSMs per launch sequence, one bucket window each (W == K); plain plans: 1
   uint16_t win_off[96];
   uint8_t win_bits[96];
   size_t B, max_n;
@@ -30,13 +41,17 @@ struct MsmCtx {
   char errbuf[256];
 };
 
-int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged);
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K);
 void msm_plan_free(MsmCtx* ctx);
 int msm_bases_convert(const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags, char* errbuf, size_t errlen);
 // table_stride: distance (in points) between the levels of a precomputed table (merged plans only)
 int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
                int scalars_montgomery, size_t table_stride);
 int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]);
+// merged plans: up to ctx->K independent MSMs (same window, each at most max_n terms) through ONE launch sequence:
+// one sort, one accumulation launch, one reduction chain with a bucket window per job.  out_jac: K x 36.
+int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs);
+int msm_finish_multi(MsmCtx* ctx, int K, uint64_t* out_jac);
 int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
             int scalars_montgomery, size_t table_stride, uint64_t out_jac[36]);
 // levels of a window table for window size c

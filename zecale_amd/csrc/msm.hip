@@ -63,11 +63,12 @@ struct WindowPlan {
 
 // one thread per scalar.  digits[w*n + i] = signed digit of window w (|d| <= 2^(bits_w - 1));
 // counts[w*B + |d|-1] += 1 for d != 0   (B = 2^(c-1) bucket slots per window).
-// merged != 0 (precomputed table): every digit position uses the SAME bucket window (bucket = |d| - 1) because the
-// entry will point at 2^(c w) P_i instead of P_i; inf_flags then has one row of `tab_stride` flags per level.
+// merged != 0 (precomputed table): every digit position uses the SAME bucket window (bucket = bucket_base + |d| - 1)
+// because the entry will point at 2^(c w) P_i instead of P_i; inf_flags then has one row of `tab_stride` flags per
+// level.  bucket_base = k * B selects the bucket window of job k when several MSMs share one launch sequence (0 otherwise).
 __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restrict__ scalars, size_t n, int c, int W,
                                                         WindowPlan plan, int montgomery, const uint8_t* __restrict__ inf_flags,
-                                                        int merged, size_t tab_stride,
+                                                        int merged, size_t tab_stride, uint32_t bucket_base,
                                                         int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
@@ -108,11 +109,11 @@ __global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restric
     const bool hot = (w == 0) && (sd == 1);
     const unsigned long long hot_mask = __ballot(hot);
     if (hot_mask) {
-      if (hot && (__ffsll((long long)hot_mask) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&counts[0], (uint32_t)__popcll(hot_mask));
+      if (hot && (__ffsll((long long)hot_mask) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&counts[bucket_base], (uint32_t)__popcll(hot_mask));
     }
     if (sd != 0 && !hot) {
       uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
-      atomicAdd(&counts[(merged ? (size_t)0 : (size_t)w * B) + (mag - 1)], 1u);
+      atomicAdd(&counts[(merged ? (size_t)bucket_base : (size_t)w * B) + (mag - 1)], 1u);
     }
   }
 }
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ out, co
 }
 
 __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, size_t n, int c, int W,
-                                                  int merged, size_t tab_stride,
+                                                  int merged, size_t tab_stride, uint32_t bucket_base,
                                                   const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                                                   uint32_t* __restrict__ entries) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,13 +187,13 @@ __global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ dig
     if (hot_mask) {
       const int leader = __ffsll((long long)hot_mask) - 1;
       uint32_t base = 0;
-      if ((int)lane == leader) base = atomicAdd(&cursor[0], (uint32_t)__popcll(hot_mask));
+      if ((int)lane == leader) base = atomicAdd(&cursor[bucket_base], (uint32_t)__popcll(hot_mask));
       base = __shfl(base, leader);
-      if (hot) entries[offsets[0] + base + (uint32_t)__popcll(hot_mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
+      if (hot) entries[offsets[bucket_base] + base + (uint32_t)__popcll(hot_mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
     }
     if (sd == 0 || hot) continue;
     uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
-    size_t b = (merged ? (size_t)0 : (size_t)w * B) + (mag - 1);
+    size_t b = (merged ? (size_t)bucket_base : (size_t)w * B) + (mag - 1);
     uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
     entries[pos] = (uint32_t)(merged ? (size_t)w * tab_stride + i : i) | (sd < 0 ? 0x80000000u : 0u);
   }
@@ -217,7 +218,17 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offse
   return lo;
 }
 
-__global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ entries,
+// Several MSMs may share one launch (merged plans: bucket window k belongs to job k): the base set of a run is chosen
+// by its bucket, b >> bshift (plain plans: one base set, bshift = 31).
+struct BasePtrs { const AffPacked* p[MSM_MAX_JOBS]; };
+__device__ __forceinline__ const AffPacked* base_of(const BasePtrs& bp, uint32_t k) {
+  const AffPacked* r = bp.p[0];
+#pragma unroll
+  for (int j = 1; j < MSM_MAX_JOBS; j++) r = (k == (uint32_t)j) ? bp.p[j] : r;
+  return r;
+}
+
+__global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, const uint32_t* __restrict__ entries,
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                         uint32_t nb, uint32_t S, uint32_t T, uint32_t* __restrict__ slots,
                                                         uint32_t stride, uint32_t* __restrict__ max_span) {
@@ -257,7 +268,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const AffPacked* __restri
     }
     uint32_t e = e_next;
     if (k + 1 < pos1) e_next = entries[k + 1];        // fetched a whole addition ahead of its use
-    const AffPacked* p = &bases[e & 0x7fffffffu];
+    const AffPacked* p = base_of(bp, b >> bshift) + (e & 0x7fffffffu);
     bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_scalar_digits drops them)
     if (inf) {
 #pragma unroll
@@ -596,14 +607,16 @@ __global__ void __launch_bounds__(256, 2) k_table_build(AffPacked* __restrict__ 
 
 static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
-int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged) {
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   memset(ctx, 0, sizeof *ctx);
+  if (K < 1 || K > MSM_MAX_JOBS || (!merged && K != 1)) return ZKHIP_ERR_ARG;
+  ctx->K = K;
   // 108 * (W * 2^(c-1) + 2T) * 4 bytes must stay below 4 GiB (buffer descriptor); checked below
   if (c < 4 || c > (merged ? 22 : 18)) return ZKHIP_ERR_ARG;
   ctx->c = c;
   ctx->merged = merged ? 1 : 0;
   ctx->Wd = (378 + c - 1) / c;   // scalars < 2^377, +1 bit for the signed-digit carry
-  ctx->W = merged ? 1 : ctx->Wd;
+  ctx->W = merged ? K : ctx->Wd;
   if (!merged) {
     int n_small = ctx->Wd * c - 378, bit = 0;   // that many windows get c-1 bits (the top ones)
     for (int w = 0; w < ctx->Wd; w++) {
@@ -630,16 +643,17 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged) {
   HIP_TRY(hipEventCreate(&ctx->ev_acc0));
   HIP_TRY(hipEventCreate(&ctx->ev_acc1));
   if ((size_t)ctx->Wd * max_n >= ((size_t)1 << 31)) return ZKHIP_ERR_ARG;   // entry = 31-bit point index + sign
-  HIP_TRY(hipMalloc(&ctx->digits, (size_t)ctx->Wd * max_n * sizeof(int32_t)));
+  if ((size_t)ctx->Wd * max_n * K >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;  // positions in the entry list are 32-bit
+  HIP_TRY(hipMalloc(&ctx->digits, (size_t)K * ctx->Wd * max_n * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&ctx->counts, nb * 4));
   HIP_TRY(hipMalloc(&ctx->offsets, nb * 4));
   HIP_TRY(hipMalloc(&ctx->cursor, nb * 4));
   HIP_TRY(hipMalloc(&ctx->block_tot, (nb / 1024 + 2) * 4));
-  HIP_TRY(hipMalloc(&ctx->entries, (size_t)ctx->Wd * max_n * 4));
+  HIP_TRY(hipMalloc(&ctx->entries, (size_t)K * ctx->Wd * max_n * 4));
   // slice length: every lane gets the same number of point operations; aim at a whole number of
   // machine fills (256 CUs x 8 waves x 64 lanes at two waves per SIMD)
   {
-    const size_t lanes = 131072, m_max = (size_t)ctx->Wd * max_n;
+    const size_t lanes = 131072, m_max = (size_t)K * ctx->Wd * max_n;
     size_t fills = (m_max + lanes * 48 - 1) / (lanes * 48);     // ~48 entries per lane and fill
     if (fills < 1) fills = 1;
     size_t S = (m_max + lanes * fills - 1) / (lanes * fills);
@@ -703,32 +717,53 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, c
 // in flight so that the latency-bound reduction of one MSM overlaps the accumulation of the next).
 int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
                int scalars_montgomery, size_t table_stride) {
-  if (n > ctx->max_n) return ZKHIP_ERR_ARG;
+  MsmJob job{d_bases, d_inf_flags, d_scalars, n, scalars_montgomery, table_stride};
+  return msm_launch_multi(ctx, 1, &job);
+}
+
+int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   const int c = ctx->c, W = ctx->W, Wd = ctx->Wd, merged = ctx->merged;
-  if (merged && (table_stride < n || (size_t)Wd * table_stride >= ((size_t)1 << 31))) return ZKHIP_ERR_ARG;
+  if (K < 1 || K > ctx->K) return ZKHIP_ERR_ARG;
+  size_t n_tot = 0;
+  for (int k = 0; k < K; k++) {
+    if (jobs[k].n > ctx->max_n) return ZKHIP_ERR_ARG;
+    if (merged && jobs[k].n && (jobs[k].table_stride < jobs[k].n || (size_t)Wd * jobs[k].table_stride >= ((size_t)1 << 31))) return ZKHIP_ERR_ARG;
+    n_tot += jobs[k].n;
+  }
   const size_t B = ctx->B, nb = B * W;
   hipStream_t st = ctx->stream;
-  ctx->pending_n = n;
+  ctx->pending_n = n_tot;
   ctx->pending = true;
-  if (n == 0) return ZKHIP_OK;
+  if (n_tot == 0) return ZKHIP_OK;
   HIP_TRY(hipMemsetAsync(ctx->counts, 0, nb * 4, st));
   HIP_TRY(hipMemsetAsync(ctx->cursor, 0, nb * 4, st));
   WindowPlan plan;
   memset(&plan, 0, sizeof plan);
   for (int w = 0; w < Wd; w++) { plan.off[w] = ctx->win_off[w]; plan.bits[w] = ctx->win_bits[w]; }
-  hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(n, 256)), dim3(256), 0, st, d_scalars, n, c, Wd, plan, scalars_montgomery,
-                     d_inf_flags, merged, table_stride, ctx->digits, ctx->counts);
+  for (int k = 0; k < K; k++) {
+    const MsmJob& jb = jobs[k];
+    if (jb.n == 0) continue;
+    hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(jb.n, 256)), dim3(256), 0, st, jb.scalars, jb.n, c, Wd, plan, jb.scalars_mode,
+                       jb.inf_flags, merged, jb.table_stride, (uint32_t)(k * B), ctx->digits + (size_t)k * Wd * ctx->max_n, ctx->counts);
+  }
   unsigned sb = nblk(nb, 1024);
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->counts, ctx->offsets, ctx->block_tot, nb);
   hipLaunchKernelGGL(k_scan_tot, dim3(1), dim3(1024), 0, st, ctx->block_tot, (size_t)sb);
   hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, ctx->offsets, ctx->block_tot, nb);
-  hipLaunchKernelGGL(k_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->digits, n, c, Wd, merged, table_stride, ctx->offsets,
-                     ctx->cursor, ctx->entries);
+  BasePtrs bp;
+  for (int k = 0; k < MSM_MAX_JOBS; k++) bp.p[k] = jobs[k < K ? k : 0].bases;
+  for (int k = 0; k < K; k++) {
+    const MsmJob& jb = jobs[k];
+    if (jb.n == 0) continue;
+    hipLaunchKernelGGL(k_scatter, dim3(nblk(jb.n, 256)), dim3(256), 0, st, ctx->digits + (size_t)k * Wd * ctx->max_n, jb.n, c, Wd, merged,
+                       jb.table_stride, (uint32_t)(k * B), ctx->offsets, ctx->cursor, ctx->entries);
+  }
+  const int bshift = merged ? c - 1 : 31;     // bucket -> job
   HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 4, st));   // block_tot[0] is reused as the max-span cell (scan is done)
   // slice length for THIS n (the plan's slot array is sized for max_n)
   uint32_t S_run, T_run;
   {
-    const size_t lanes = 131072, m = (size_t)Wd * n;
+    const size_t lanes = 131072, m = (size_t)Wd * n_tot;
     size_t fills = (m + lanes * 48 - 1) / (lanes * 48);
     if (fills < 1) fills = 1;
     size_t S = (m + lanes * fills - 1) / (lanes * fills);
@@ -738,7 +773,7 @@ int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags
   }
   HIP_TRY(hipMemsetAsync(ctx->buckets, 0, (size_t)ctx->slot_stride * 108 * 4, st));
   HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
-  hipLaunchKernelGGL(k_accumulate, dim3(nblk(T_run, 256)), dim3(256), 0, st, d_bases, ctx->entries, ctx->offsets, ctx->counts,
+  hipLaunchKernelGGL(k_accumulate, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, ctx->entries, ctx->offsets, ctx->counts,
                      (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
   for (uint32_t d = 1; d < T_run; d <<= 1) {
@@ -847,9 +882,39 @@ int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags
 }
 
 // Wait for the MSM enqueued by msm_launch and finish it on the host.
+static void xyzz_abi_to_jac(const uint64_t* p, host::HJac& q) {
+  using namespace host;
+  HFq X = HFq::from_limbs(p), Y = HFq::from_limbs(p + 12), ZZ = HFq::from_limbs(p + 24), ZZZ = HFq::from_limbs(p + 36);
+  if (ZZ.is_zero()) { q = HJac::infinity(); return; }
+  // XYZZ -> Jacobian with Z = ZZ*ZZZ:  X' = X ZZ ZZZ^2,  Y' = Y ZZ^3 ZZZ^2
+  HFq z3s = ZZZ.sqr(), zz2 = ZZ.sqr();
+  q.X = X * ZZ * z3s;
+  q.Y = Y * zz2 * ZZ * z3s;
+  q.Z = ZZ * ZZZ;
+}
+
+int msm_finish_multi(MsmCtx* ctx, int K, uint64_t* out_jac) {
+  using namespace host;
+  if (!ctx->pending || !ctx->merged || K < 1 || K > ctx->K) return ZKHIP_ERR_STATE;
+  ctx->pending = false;
+  if (ctx->pending_n) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
+    ctx->last_accumulate_ms = ms;
+  }
+  for (int k = 0; k < K; k++) {
+    HJac q = HJac::infinity();
+    if (ctx->pending_n) xyzz_abi_to_jac(ctx->win_host + (size_t)k * 48, q);    // one bucket window per job: nothing to combine
+    q.X.to_limbs(out_jac + 36 * k); q.Y.to_limbs(out_jac + 36 * k + 12); q.Z.to_limbs(out_jac + 36 * k + 24);
+  }
+  return ZKHIP_OK;
+}
+
 int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]) {
   using namespace host;
   if (!ctx->pending) return ZKHIP_ERR_STATE;
+  if (ctx->merged) return msm_finish_multi(ctx, 1, out_jac);
   ctx->pending = false;
   const int W = ctx->W;
   if (ctx->pending_n == 0) {
@@ -866,15 +931,8 @@ int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]) {
   HJac acc = HJac::infinity();
   for (int w = W - 1; w >= 0; w--) {
     for (int d = 0; d < ctx->win_bits[w]; d++) acc = acc.dbl();
-    const uint64_t* p = ctx->win_host + (size_t)w * 48;
-    HFq X = HFq::from_limbs(p), Y = HFq::from_limbs(p + 12), ZZ = HFq::from_limbs(p + 24), ZZZ = HFq::from_limbs(p + 36);
-    if (ZZ.is_zero()) continue;
-    // XYZZ -> Jacobian with Z = ZZ*ZZZ:  X' = X ZZ ZZZ^2,  Y' = Y ZZ^3 ZZZ^2
-    HFq z3s = ZZZ.sqr(), zz2 = ZZ.sqr();
     HJac q;
-    q.X = X * ZZ * z3s;
-    q.Y = Y * zz2 * ZZ * z3s;
-    q.Z = ZZ * ZZZ;
+    xyzz_abi_to_jac(ctx->win_host + (size_t)w * 48, q);
     acc = acc.add(q);
   }
   acc.X.to_limbs(out_jac); acc.Y.to_limbs(out_jac + 12); acc.Z.to_limbs(out_jac + 24);

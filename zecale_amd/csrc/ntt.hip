@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "fp29.cuh"
@@ -208,6 +209,8 @@ static std::map<int, NttTables>& table_cache() {
 
 static int get_tables(int log_d, int inverse, NttTables** out, char* err, size_t errlen) {
   int key = log_d * 2 + (inverse ? 1 : 0);
+  static std::mutex mu;                        // prover instances call in from several host threads
+  std::lock_guard<std::mutex> lk(mu);
   auto& c = table_cache();
   auto it = c.find(key);
   if (it != c.end()) { *out = &it->second; return ZKHIP_OK; }

@@ -1,0 +1,169 @@
+// Streaming form of the wrapping prover: the shape of the reference's server loop (aggregator_server.cpp:300-420
+// GenerateAggregatedTransaction -> aggregator_circuit::prove, one batch at a time, CPU) re-cut for one MI355X.
+//
+// A batch goes through three stages with very different resource needs:
+//   witness   host only: ~1500 serial field inversions inside the in-circuit pairing, ~12 ms on 3 cores;
+//   prove     GPU: upload z, QAP map, five MSMs.  At this circuit's size (51k constraints) every MSM phase after the
+//             accumulation is a chain of short latency-bound launches, so ONE proof leaves most of the chip idle;
+//   tail      host: three 377-bit scalar multiplications + affine normalisation, ~2 ms.
+// The pipeline keeps `witness_workers` witnesses and `gpu_slots` proofs in flight: each GPU slot is a zkhip_prover
+// (own streams, own MSM work space, own QAP buffers) driven by its own host thread, so the accumulation kernels of one
+// proof fill the gaps in the reduction chains of another and the host stages overlap the device ones.
+// Built only on the C ABI (zkhip_aggregator_witness, zkhip_prover_*): a host-side scheduler, no device code.
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <string.h>
+
+#include "../../include/zkhip.h"
+
+namespace {
+struct Job {
+  uint64_t id = 0;
+  std::vector<uint64_t> vk, proofs, inputs, z;
+  uint64_t r[6], s[6], proof[72];
+  int rc = ZKHIP_OK;
+  bool done = false;
+};
+}  // namespace
+
+struct zkhip_pipeline {
+  zkhip_aggregator* agg = nullptr;
+  size_t n_vars = 0, n_primary = 0, vk_words = 0, proofs_words = 0, inputs_words = 0;
+  std::vector<zkhip_prover*> provers;
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_wit, cv_gpu, cv_done, cv_room;
+  std::deque<std::shared_ptr<Job>> q_wit, q_gpu;
+  std::map<uint64_t, std::shared_ptr<Job>> jobs;   // submitted and not yet collected
+  size_t max_outstanding = 0;
+  uint64_t next_id = 1;
+  bool stop = false;
+};
+
+namespace {
+
+void witness_loop(zkhip_pipeline* p) {
+  for (;;) {
+    std::shared_ptr<Job> j;
+    {
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv_wit.wait(lk, [&] { return p->stop || !p->q_wit.empty(); });
+      if (p->stop) return;
+      j = p->q_wit.front();
+      p->q_wit.pop_front();
+    }
+    j->z.resize(p->n_vars * 6);
+    int rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (rc != ZKHIP_OK) {
+      j->rc = rc; j->done = true;
+      p->cv_done.notify_all();
+    } else {
+      p->q_gpu.push_back(j);
+      p->cv_gpu.notify_one();
+    }
+  }
+}
+
+void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
+  for (;;) {
+    std::shared_ptr<Job> j;
+    {
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv_gpu.wait(lk, [&] { return p->stop || !p->q_gpu.empty(); });
+      if (p->stop) return;
+      j = p->q_gpu.front();
+      p->q_gpu.pop_front();
+    }
+    int rc = zkhip_prover_prove(pr, j->z.data(), j->r, j->s, j->proof);
+    std::lock_guard<std::mutex> lk(p->mu);
+    j->rc = rc; j->done = true;
+    p->cv_done.notify_all();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, zkhip_pipeline** out) {
+  if (!a || !crs || !out || gpu_slots < 1 || gpu_slots > 8 || witness_workers < 1 || witness_workers > 64) return ZKHIP_ERR_ARG;
+  zkhip_r1cs_desc desc;
+  int rc = zkhip_aggregator_get_r1cs(a, &desc);
+  if (rc != ZKHIP_OK) return rc;
+  zkhip_pipeline* p = new zkhip_pipeline();
+  p->agg = a;
+  p->n_vars = desc.n_vars; p->n_primary = desc.n_primary;
+  const size_t np = zkhip_aggregator_num_proofs(a), k = zkhip_aggregator_inputs_per_proof(a);
+  p->vk_words = 60 + 12 * (k + 1); p->proofs_words = 48 * np; p->inputs_words = 6 * k * np;
+  p->max_outstanding = (size_t)4 * (size_t)(gpu_slots + witness_workers);
+  for (int i = 0; i < gpu_slots; i++) {
+    zkhip_prover* pr = nullptr;
+    rc = zkhip_prover_new(crs, &desc, &pr);
+    if (rc != ZKHIP_OK) {
+      for (zkhip_prover* q : p->provers) zkhip_prover_free(q);
+      delete p;
+      return rc;
+    }
+    p->provers.push_back(pr);
+  }
+  for (int i = 0; i < witness_workers; i++) p->threads.emplace_back(witness_loop, p);
+  for (zkhip_prover* pr : p->provers) p->threads.emplace_back(gpu_loop, p, pr);
+  *out = p;
+  return ZKHIP_OK;
+}
+
+void zkhip_aggregator_pipeline_free(zkhip_pipeline* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->stop = true;
+  }
+  p->cv_wit.notify_all(); p->cv_gpu.notify_all(); p->cv_done.notify_all(); p->cv_room.notify_all();
+  for (auto& t : p->threads) t.join();
+  for (zkhip_prover* q : p->provers) zkhip_prover_free(q);
+  delete p;
+}
+
+int zkhip_aggregator_pipeline_submit(zkhip_pipeline* p, const uint64_t* nested_vk, const uint64_t* nested_proofs, const uint64_t* nested_inputs,
+                                     const uint64_t r[6], const uint64_t s[6], uint64_t* ticket) {
+  if (!p || !nested_vk || !nested_proofs || !nested_inputs || !r || !s || !ticket) return ZKHIP_ERR_ARG;
+  auto j = std::make_shared<Job>();
+  j->vk.assign(nested_vk, nested_vk + p->vk_words);
+  j->proofs.assign(nested_proofs, nested_proofs + p->proofs_words);
+  j->inputs.assign(nested_inputs, nested_inputs + p->inputs_words);
+  memcpy(j->r, r, 48); memcpy(j->s, s, 48);
+  std::unique_lock<std::mutex> lk(p->mu);
+  p->cv_room.wait(lk, [&] { return p->stop || p->jobs.size() < p->max_outstanding; });   // back-pressure on the caller
+  if (p->stop) return ZKHIP_ERR_STATE;
+  j->id = p->next_id++;
+  p->jobs[j->id] = j;
+  p->q_wit.push_back(j);
+  *ticket = j->id;
+  p->cv_wit.notify_one();
+  return ZKHIP_OK;
+}
+
+int zkhip_aggregator_pipeline_wait(zkhip_pipeline* p, uint64_t ticket, uint64_t* primary_inputs, uint64_t proof_affine[72]) {
+  if (!p || !proof_affine) return ZKHIP_ERR_ARG;
+  std::unique_lock<std::mutex> lk(p->mu);
+  auto it = p->jobs.find(ticket);
+  if (it == p->jobs.end()) return ZKHIP_ERR_ARG;
+  std::shared_ptr<Job> j = it->second;
+  p->cv_done.wait(lk, [&] { return p->stop || j->done; });
+  if (!j->done) return ZKHIP_ERR_STATE;
+  p->jobs.erase(ticket);
+  p->cv_room.notify_one();
+  lk.unlock();
+  if (j->rc != ZKHIP_OK) return j->rc;
+  if (primary_inputs) memcpy(primary_inputs, j->z.data() + 6, p->n_primary * 48);   // z[0] is the constant ONE
+  memcpy(proof_affine, j->proof, sizeof j->proof);
+  return ZKHIP_OK;
+}
+
+}  // extern "C"

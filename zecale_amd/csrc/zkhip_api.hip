@@ -39,29 +39,44 @@ struct zkhip_keypair {
 };
 
 namespace {
-double g_prove_ms[8];
+// Everything one proof in flight needs on the device: a stream for the QAP map, the witness buffer, five MSM contexts
+// (the prover keeps 2 (large) or 5 (small circuits) MSMs in flight).  The library owns one (the plain entry points,
+// serialised by g.mu); every zkhip_prover owns another, so several host threads can keep several proofs in flight.
+struct ProveState {
+  MsmCtx ctx[5];
+  bool ready[5] = {false, false, false, false, false};
+  hipStream_t st = nullptr;
+  uint64_t* dz = nullptr;
+  size_t dz_cap = 0;
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float last_accumulate_ms = 0.f;
+  void release() {
+    for (int k = 0; k < 5; k++) if (ready[k]) { msm_plan_free(&ctx[k]); ready[k] = false; }
+    if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+    if (dz) { (void)hipFree(dz); dz = nullptr; dz_cap = 0; }
+  }
+};
+
 struct Lib {
   bool inited = false;
   int device = -1;
   int forced_c = 0;
   int crs_tables = 1;       // zkhip_crs_upload builds window tables (zkhip_set_crs_precompute)
-  MsmCtx msm;
-  bool msm_ready = false;
-  MsmCtx msmx[4];           // further contexts: the prover keeps 2 (large) or 5 (small circuits) MSMs in flight
-  bool msmx_ready[4] = {false, false, false, false};
-  char err[512] = {0};
+  int batch_msms = 1;       // table-backed keys: the five MSMs of a proof in one launch sequence
+  ProveState ps;
   std::mutex mu;
 } g;
+thread_local char t_err[512] = {0};   // zkhip_last_error(): the calling thread's last failure
 
 int fail(int code, const char* msg) {
-  snprintf(g.err, sizeof g.err, "%s", msg);
+  snprintf(t_err, sizeof t_err, "%s", msg);
   return code;
 }
 #define API_HIP(x)                                                                           \
   do {                                                                                       \
     hipError_t e_ = (x);                                                                     \
     if (e_ != hipSuccess) {                                                                  \
-      snprintf(g.err, sizeof g.err, "%s: %s", #x, hipGetErrorString(e_));                    \
+      snprintf(t_err, sizeof t_err, "%s: %s", #x, hipGetErrorString(e_));                    \
       return ZKHIP_ERR_HIP;                                                                  \
     }                                                                                        \
   } while (0)
@@ -86,17 +101,16 @@ int auto_table_window(size_t n) {
 }
 
 // table_c = 0: plain plan with the automatic window;  > 0: merged plan (bases are a window table built for table_c)
-int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c) {
+int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1) {
   const int c = table_c ? table_c : auto_window(n), merged = table_c ? 1 : 0;
-  if (*ready && cx->max_n >= n && cx->c == c && cx->merged == merged) return ZKHIP_OK;
+  if (*ready && cx->max_n >= n && cx->c == c && cx->merged == merged && cx->K == K) return ZKHIP_OK;
   if (*ready) { msm_plan_free(cx); *ready = false; }
-  int rc = msm_plan_init(cx, n, c, merged);
-  if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "msm_plan_init: %s", cx->errbuf); return rc; }
+  int rc = msm_plan_init(cx, n, c, merged, K);
+  if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "msm_plan_init: %s", cx->errbuf); return rc; }
   *ready = true;
   return ZKHIP_OK;
 }
-int ensure_msmx(int k, size_t n, int table_c = 0) { return ensure_ctx(&g.msmx[k], &g.msmx_ready[k], n, table_c); }
-int ensure_msm(size_t n, int table_c = 0) { return ensure_ctx(&g.msm, &g.msm_ready, n, table_c); }
+int ensure_msm(size_t n, int table_c = 0) { return ensure_ctx(&g.ps.ctx[0], &g.ps.ready[0], n, table_c); }
 }  // namespace
 
 extern "C" {
@@ -111,7 +125,7 @@ int zkhip_init(int device) {
   hipDeviceProp_t prop;
   API_HIP(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-    snprintf(g.err, sizeof g.err, "device %d is %s, this library contains gfx950 code only", device, prop.gcnArchName);
+    snprintf(t_err, sizeof t_err, "device %d is %s, this library contains gfx950 code only", device, prop.gcnArchName);
     return ZKHIP_ERR_NO_DEVICE;
   }
   g.device = device;
@@ -121,8 +135,7 @@ int zkhip_init(int device) {
 
 void zkhip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g.mu);
-  if (g.msm_ready) { msm_plan_free(&g.msm); g.msm_ready = false; }
-  for (int k = 0; k < 4; k++) if (g.msmx_ready[k]) { msm_plan_free(&g.msmx[k]); g.msmx_ready[k] = false; }
+  g.ps.release();
   g.inited = false;
 }
 
@@ -136,7 +149,7 @@ const char* zkhip_strerror(int code) {
     default: return "unknown error";
   }
 }
-const char* zkhip_last_error(void) { return g.err; }
+const char* zkhip_last_error(void) { return t_err; }
 
 int zkhip_set_msm_window(int c) {
   if (c != 0 && (c < 4 || c > 18)) return fail(ZKHIP_ERR_ARG, "window must be 0 or in [4, 18]");   // (tables: zkhip_bases_precompute takes up to 22)
@@ -152,7 +165,7 @@ int zkhip_bases_upload_dev(const void* d_bases_affine, size_t len, zkhip_bases**
   if (len) {
     API_HIP(hipMalloc(&b->d_pts, len * sizeof(AffPacked)));
     API_HIP(hipMalloc(&b->d_inf, len));
-    int rc = msm_bases_convert((const uint64_t*)d_bases_affine, len, b->d_pts, b->d_inf, g.err, sizeof g.err);
+    int rc = msm_bases_convert((const uint64_t*)d_bases_affine, len, b->d_pts, b->d_inf, t_err, sizeof t_err);
     if (rc != ZKHIP_OK) return rc;
   }
   *out = b;
@@ -175,6 +188,7 @@ int zkhip_bases_upload(const uint64_t* bases_affine, size_t len, zkhip_bases** o
 size_t zkhip_bases_len(const zkhip_bases* b) { return b ? b->len : 0; }
 
 int zkhip_set_crs_precompute(int on) { g.crs_tables = on ? 1 : 0; return ZKHIP_OK; }
+int zkhip_set_batch_msms(int on) { g.batch_msms = on ? 1 : 0; return ZKHIP_OK; }
 
 int zkhip_bases_precompute(zkhip_bases* b, int c) {
   std::lock_guard<std::mutex> lk(g.mu);
@@ -192,7 +206,7 @@ int zkhip_bases_precompute(zkhip_bases* b, int c) {
   API_HIP(hipMalloc(&tinf, levels * b->len));
   API_HIP(hipMemcpy(tab, b->d_pts, b->len * sizeof(AffPacked), hipMemcpyDeviceToDevice));
   API_HIP(hipMemcpy(tinf, b->d_inf, b->len, hipMemcpyDeviceToDevice));
-  int rc = msm_table_build(tab, tinf, b->len, c, g.err, sizeof g.err);
+  int rc = msm_table_build(tab, tinf, b->len, c, t_err, sizeof t_err);
   if (rc != ZKHIP_OK) { (void)hipFree(tab); (void)hipFree(tinf); return rc; }
   (void)hipFree(b->d_pts); (void)hipFree(b->d_inf);
   b->d_pts = tab; b->d_inf = tinf; b->table_c = c;
@@ -215,9 +229,10 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
   int rc = ensure_msm(len ? len : 1, bases->table_c);
   if (rc != ZKHIP_OK) return rc;
-  rc = msm_run(&g.msm, bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
+  rc = msm_run(&g.ps.ctx[0], bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                scalars_montgomery, bases->len, out_jac);
-  if (rc != ZKHIP_OK) snprintf(g.err, sizeof g.err, "%s", g.msm.errbuf);
+  if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", g.ps.ctx[0].errbuf);
+  else g.ps.last_accumulate_ms = g.ps.ctx[0].last_accumulate_ms;
   return rc;
 }
 
@@ -251,7 +266,7 @@ int zkhip_fixed_base_mul_dev(const uint64_t base_affine[24], const void* d_scala
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!base_affine || (len && (!d_scalars || !d_out_affine))) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (len == 0) return ZKHIP_OK;
-  return fixed_base_mul(base_affine, (const uint64_t*)d_scalars, len, scalars_montgomery, (uint64_t*)d_out_affine, g.err, sizeof g.err);
+  return fixed_base_mul(base_affine, (const uint64_t*)d_scalars, len, scalars_montgomery, (uint64_t*)d_out_affine, t_err, sizeof t_err);
 }
 
 int zkhip_fixed_base_mul(const uint64_t base_affine[24], const uint64_t* scalars, size_t len, int scalars_montgomery,
@@ -274,7 +289,7 @@ int zkhip_ntt_dev(void* d_data, unsigned log_d, int dir, int coset) {
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!d_data) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (log_d > 22) return fail(ZKHIP_ERR_ARG, "log_d must be <= 22");
-  return ntt_dev_abi((uint64_t*)d_data, (int)log_d, dir != 0, coset != 0, g.err, sizeof g.err);
+  return ntt_dev_abi((uint64_t*)d_data, (int)log_d, dir != 0, coset != 0, t_err, sizeof t_err);
 }
 
 int zkhip_ntt(uint64_t* data, unsigned log_d, int dir, int coset) {
@@ -296,7 +311,7 @@ int zkhip_r1cs_upload(const zkhip_r1cs_desc* d, zkhip_r1cs** out) {
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!d || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
   R1csDev* dev = nullptr;
-  int rc = r1cs_upload(d, &dev, g.err, sizeof g.err);
+  int rc = r1cs_upload(d, &dev, t_err, sizeof t_err);
   if (rc != ZKHIP_OK) return rc;
   *out = new zkhip_r1cs{dev};
   return ZKHIP_OK;
@@ -317,7 +332,7 @@ int zkhip_r1cs_is_satisfied(zkhip_r1cs* r, const uint64_t* z, int* ok) {
   uint64_t* dz = nullptr;
   API_HIP(hipMalloc(&dz, r->dev->n_vars * 48));
   API_HIP(hipMemcpy(dz, z, r->dev->n_vars * 48, hipMemcpyHostToDevice));
-  int rc = r1cs_is_satisfied_dev(r->dev, dz, 0, ok, g.err, sizeof g.err);
+  int rc = r1cs_is_satisfied_dev(r->dev, dz, 0, ok, t_err, sizeof t_err);
   (void)hipFree(dz);
   return rc;
 }
@@ -331,7 +346,7 @@ int zkhip_qap_h(zkhip_r1cs* r, const uint64_t* z, uint64_t* h_out) {
   API_HIP(hipMalloc(&dz, r->dev->n_vars * 48));
   API_HIP(hipMalloc(&dh, d * 48));
   API_HIP(hipMemcpy(dz, z, r->dev->n_vars * 48, hipMemcpyHostToDevice));
-  int rc = qap_h_dev(r->dev, dz, 0, g.err, sizeof g.err);
+  int rc = qap_h_dev(r->dev, dz, 0, t_err, sizeof t_err);
   if (rc == ZKHIP_OK) {
     fr_dev_to_abi(r->dev->bufA, dh, d, 0);
     API_HIP(hipMemcpy(h_out, dh, d * 48, hipMemcpyDeviceToHost));
@@ -404,7 +419,7 @@ void zkhip_crs_free(zkhip_crs* c) {
 
 int zkhip_last_prove_timings(double out_ms[8]) {
   if (!out_ms) return ZKHIP_ERR_ARG;
-  memcpy(out_ms, g_prove_ms, sizeof g_prove_ms);
+  memcpy(out_ms, g.ps.ms, sizeof g.ps.ms);
   return ZKHIP_OK;
 }
 
@@ -412,64 +427,80 @@ int zkhip_last_prove_timings(double out_ms[8]) {
 // GPUs of a node; each rank computes partial sums, the ranks exchange 5 x 288 bytes).  Slice = [a_lo, a_lo + a_len) of
 // the A / B queries (indices into z), [h_lo, h_lo + h_len) of the H query (indices into h), [l_lo, l_lo + l_len) of the
 // L query (indices into z[n_primary+1 ..]).  The whole key is the slice (0, n_vars), (0, d - 1), (0, n_vars - l - 1).
-static int prove_partial_locked(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
-                                uint64_t sums[5 * 36]) {
+static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
+                         uint64_t sums[5 * 36]) {
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
-  R1csDev* rd = r1cs->dev;
   const size_t m = rd->n_vars, l = rd->n_primary, d = (size_t)1 << rd->log_d;
   const size_t a_len = crs->A->len, h_len = crs->H->len, l_len = crs->L->len;
   if (crs->n_vars != m || crs->n_primary != l || crs->domain_size != d) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
   if (crs->B2->len != a_len || crs->B1->len != a_len || a_lo + a_len > m || h_lo + h_len > d - 1 || l_lo + l_len > m - l - 1)
     return fail(ZKHIP_ERR_ARG, "key slice out of range");
+  const int tc = crs->A->table_c;
+  if (crs->B2->table_c != tc || crs->B1->table_c != tc || crs->H->table_c != tc || crs->L->table_c != tc)
+    return fail(ZKHIP_ERR_ARG, "the five query vectors of a proving key must share one table window");
   auto t0 = clk::now();
-  uint64_t* dz = nullptr;
-  API_HIP(hipMalloc(&dz, m * 48));
-  API_HIP(hipMemcpy(dz, z, m * 48, hipMemcpyHostToDevice));
-  g_prove_ms[0] = ms_since(t0);
+  if (!ps.st) API_HIP(hipStreamCreate(&ps.st));
+  if (ps.dz_cap < m) {
+    if (ps.dz) { (void)hipFree(ps.dz); ps.dz = nullptr; ps.dz_cap = 0; }
+    API_HIP(hipMalloc(&ps.dz, m * 48));
+    ps.dz_cap = m;
+  }
+  uint64_t* dz = ps.dz;
+  API_HIP(hipMemcpyAsync(dz, z, m * 48, hipMemcpyHostToDevice, ps.st));
+  API_HIP(hipStreamSynchronize(ps.st));
+  ps.ms[0] = ms_since(t0);
   t0 = clk::now();
-  int rc = qap_h_dev(rd, dz, 0, g.err, sizeof g.err);
-  if (rc != ZKHIP_OK) { (void)hipFree(dz); return rc; }
-  API_HIP(hipDeviceSynchronize());
-  g_prove_ms[1] = ms_since(t0);
+  int rc = qap_h_dev(rd, dz, ps.st, t_err, sizeof t_err);
+  if (rc != ZKHIP_OK) return rc;
+  API_HIP(hipStreamSynchronize(ps.st));     // the MSM contexts run on their own streams
+  ps.ms[1] = ms_since(t0);
   size_t maxlen = a_len > h_len ? a_len : h_len;
   if (maxlen < 1) maxlen = 1;
-  const int tc = crs->A->table_c;
-  if (crs->B2->table_c != tc || crs->B1->table_c != tc || crs->H->table_c != tc || crs->L->table_c != tc) {
-    (void)hipFree(dz);
-    return fail(ZKHIP_ERR_ARG, "the five query vectors of a proving key must share one table window");
-  }
-  if ((rc = ensure_msm(maxlen, tc)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
   struct { const zkhip_bases* b; const uint64_t* sc; size_t len; int mode; uint64_t* out; } jobs[5] = {
       {crs->A, dz + a_lo * 6, a_len, 1, sums}, {crs->B2, dz + a_lo * 6, a_len, 1, sums + 36}, {crs->B1, dz + a_lo * 6, a_len, 1, sums + 72},
       {crs->H, (const uint64_t*)rd->bufA + h_lo * 6, h_len, 2, sums + 108}, {crs->L, dz + (l + 1 + l_lo) * 6, l_len, 1, sums + 144}};
+  if (tc > 0 && maxlen <= ((size_t)1 << 20) && g.batch_msms) {
+    // table-backed key: the five MSMs share ONE launch sequence (one sort, one accumulation launch over all five entry
+    // lists, one reduction chain with a bucket window per MSM) - a fifth of the launches, five times the lanes in each.
+    MsmCtx* cx = &ps.ctx[4];
+    if ((rc = ensure_ctx(cx, &ps.ready[4], maxlen, tc, 5)) != ZKHIP_OK) return rc;
+    MsmJob mj[5];
+    for (int j = 0; j < 5; j++) mj[j] = MsmJob{jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].b->len};
+    auto tl0 = clk::now();
+    if ((rc = msm_launch_multi(cx, 5, mj)) == ZKHIP_OK) rc = msm_finish_multi(cx, 5, sums);
+    if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", cx->errbuf); return rc; }
+    for (int j = 0; j < 5; j++) ps.ms[2 + j] = ms_since(tl0);
+    ps.last_accumulate_ms = cx->last_accumulate_ms;
+    return ZKHIP_OK;
+  }
   // MSMs in flight: while MSM j reduces its buckets (latency-bound, few lanes), MSM j+1 accumulates.  Large
   // circuits keep two contexts (each holds ~1.3 GB of work space at 2^20); small ones (every phase is
   // latency-bound and the chip is mostly idle) run all five MSMs side by side.
   const int nctx = (maxlen <= ((size_t)1 << 18)) ? 5 : 2;
-  MsmCtx* ctxs[5] = {&g.msm, nullptr, nullptr, nullptr, nullptr};
-  for (int k = 1; k < nctx; k++) {
-    if ((rc = ensure_msmx(k - 1, maxlen, tc)) != ZKHIP_OK) { (void)hipFree(dz); return rc; }
-    ctxs[k] = &g.msmx[k - 1];
+  MsmCtx* ctxs[5];
+  for (int k = 0; k < nctx; k++) {
+    if ((rc = ensure_ctx(&ps.ctx[k], &ps.ready[k], maxlen, tc)) != ZKHIP_OK) return rc;
+    ctxs[k] = &ps.ctx[k];
   }
   clk::time_point tl[5];
   for (int j = 0; j < 5; j++) {
     MsmCtx* cx = ctxs[j % nctx];
     if (j >= nctx) {
       rc = msm_finish(cx, jobs[j - nctx].out);
-      g_prove_ms[2 + j - nctx] = ms_since(tl[j - nctx]);
-      if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", cx->errbuf); (void)hipFree(dz); return rc; }
+      ps.ms[2 + j - nctx] = ms_since(tl[j - nctx]);
+      if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", cx->errbuf); return rc; }
     }
     tl[j] = clk::now();
     rc = msm_launch(cx, jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].b->len);
-    if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", cx->errbuf); (void)hipFree(dz); return rc; }
+    if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", cx->errbuf); return rc; }
   }
   for (int j = 5 - nctx; j < 5; j++) {
     rc = msm_finish(ctxs[j % nctx], jobs[j].out);
-    g_prove_ms[2 + j] = ms_since(tl[j]);
-    if (rc != ZKHIP_OK) { snprintf(g.err, sizeof g.err, "%s", ctxs[j % nctx]->errbuf); (void)hipFree(dz); return rc; }
+    ps.ms[2 + j] = ms_since(tl[j]);
+    if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", ctxs[j % nctx]->errbuf); return rc; }
   }
-  (void)hipFree(dz);
+  ps.last_accumulate_ms = ctxs[4 % nctx]->last_accumulate_ms;
   return ZKHIP_OK;
 }
 
@@ -478,13 +509,13 @@ int zkhip_groth16_prove_partial(const zkhip_crs* crs_slice, zkhip_r1cs* r1cs, co
   std::lock_guard<std::mutex> lk(g.mu);
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!crs_slice || !r1cs || !z || !sums_jac) return fail(ZKHIP_ERR_ARG, "null pointer");
-  return prove_partial_locked(crs_slice, r1cs, z, a_lo, h_lo, l_lo, sums_jac);
+  return prove_partial(g.ps, crs_slice, r1cs->dev, z, a_lo, h_lo, l_lo, sums_jac);
 }
 
 // tail: A = alpha + evA + r delta1;  B = beta + evB + s delta;  C = evH + evL + s A + r B1 - rs delta1
-int zkhip_groth16_finish(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
-                         const uint64_t delta_g2[24], const uint64_t sums_jac[180], const uint64_t r_m[6], const uint64_t s_m[6],
-                         uint64_t proof_affine[72]) {
+static int finish_impl(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
+                       const uint64_t delta_g2[24], const uint64_t sums_jac[180], const uint64_t r_m[6], const uint64_t s_m[6],
+                       uint64_t proof_affine[72], double* tail_ms) {
   using namespace host;
   using clk = std::chrono::steady_clock;
   if (!alpha_g1 || !beta_g1 || !beta_g2 || !delta_g1 || !delta_g2 || !sums_jac || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
@@ -509,8 +540,14 @@ int zkhip_groth16_finish(const uint64_t alpha_g1[24], const uint64_t beta_g1[24]
   gA.to_affine(x, y); x.to_limbs(proof_affine); y.to_limbs(proof_affine + 12);
   gB2.to_affine(x, y); x.to_limbs(proof_affine + 24); y.to_limbs(proof_affine + 36);
   gC.to_affine(x, y); x.to_limbs(proof_affine + 48); y.to_limbs(proof_affine + 60);
-  g_prove_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+  if (tail_ms) *tail_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
   return ZKHIP_OK;
+}
+
+int zkhip_groth16_finish(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
+                         const uint64_t delta_g2[24], const uint64_t sums_jac[180], const uint64_t r_m[6], const uint64_t s_m[6],
+                         uint64_t proof_affine[72]) {
+  return finish_impl(alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, sums_jac, r_m, s_m, proof_affine, &g.ps.ms[7]);
 }
 
 int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6],
@@ -522,10 +559,63 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
     if (!crs || !r1cs || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
     const size_t m = r1cs->dev->n_vars, l = r1cs->dev->n_primary, d = (size_t)1 << r1cs->dev->log_d;
     if (crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
-    int rc = prove_partial_locked(crs, r1cs, z, 0, 0, 0, sums);
+    int rc = prove_partial(g.ps, crs, r1cs->dev, z, 0, 0, 0, sums);
     if (rc != ZKHIP_OK) return rc;
   }
   return zkhip_groth16_finish(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine);
+}
+
+// ---- prover instances: one proof in flight each, several instances per GPU -------------------------------------------
+struct zkhip_prover {
+  const zkhip_crs* crs;
+  R1csDev* rd;          // own copy of the constraint system + QAP work buffers
+  ProveState ps;
+  std::mutex mu;
+};
+
+int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prover** out) {
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!crs || !cs || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  R1csDev* rd = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    int rc = r1cs_upload(cs, &rd, t_err, sizeof t_err);
+    if (rc != ZKHIP_OK) return rc;
+  }
+  const size_t m = rd->n_vars, l = rd->n_primary, d = (size_t)1 << rd->log_d;
+  if (crs->n_vars != m || crs->n_primary != l || crs->domain_size != d || crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) {
+    r1cs_free(rd);
+    return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+  }
+  zkhip_prover* p = new zkhip_prover();
+  p->crs = crs; p->rd = rd;
+  *out = p;
+  return ZKHIP_OK;
+}
+
+void zkhip_prover_free(zkhip_prover* p) {
+  if (!p) return;
+  p->ps.release();
+  r1cs_free(p->rd);
+  delete p;
+}
+
+int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]) {
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!p || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> lk(p->mu);
+  uint64_t sums[180];
+  int rc = prove_partial(p->ps, p->crs, p->rd, z, 0, 0, 0, sums);
+  if (rc != ZKHIP_OK) return rc;
+  const zkhip_crs* c = p->crs;
+  return finish_impl(c->alpha_g1, c->beta_g1, c->beta_g2, c->delta_g1, c->delta_g2, sums, r_m, s_m, proof_affine, &p->ps.ms[7]);
+}
+
+int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]) {
+  if (!p || !out_ms) return ZKHIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(p->mu);
+  memcpy(out_ms, p->ps.ms, sizeof p->ps.ms);
+  return ZKHIP_OK;
 }
 
 int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_g2[24], const uint64_t vk_delta_g2[24],
@@ -654,7 +744,7 @@ size_t zkhip_keypair_vk(const zkhip_keypair* kp, uint64_t alpha_g1[24], uint64_t
 
 void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 
-float zkhip_last_accumulate_ms(void) { return g.msm_ready ? g.msm.last_accumulate_ms : 0.f; }
+float zkhip_last_accumulate_ms(void) { return g.ps.last_accumulate_ms; }
 
 int zkhip_to_canonical(int which, const uint64_t* in, uint64_t* out) {
   using namespace host;

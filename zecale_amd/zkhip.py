@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libzkhip.so")
 EXPORTS = [
     "zkhip_init", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window",
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
-    "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window",
+    "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window", "zkhip_set_batch_msms",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_last_accumulate_ms",
     "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
@@ -21,7 +21,9 @@ EXPORTS = [
     "zkhip_crs_upload_slice", "zkhip_groth16_prove_partial", "zkhip_groth16_finish",
     "zkhip_bls12_377_groth16_verify", "zkhip_aggregator_new", "zkhip_aggregator_free", "zkhip_aggregator_num_constraints",
     "zkhip_aggregator_num_variables", "zkhip_aggregator_num_primary_inputs", "zkhip_aggregator_get_r1cs",
-    "zkhip_aggregator_witness", "zkhip_aggregator_vk_hash",
+    "zkhip_aggregator_witness", "zkhip_aggregator_vk_hash", "zkhip_aggregator_num_proofs", "zkhip_aggregator_inputs_per_proof",
+    "zkhip_prover_new", "zkhip_prover_prove", "zkhip_prover_timings", "zkhip_prover_free",
+    "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
 ]
@@ -95,6 +97,14 @@ def load():
     lib.zkhip_last_accumulate_ms.restype = ctypes.c_float
     lib.zkhip_jac_to_affine.argtypes = [c_u64p, c_u64p]
     lib.zkhip_jac_add.argtypes = [c_u64p, c_u64p, c_u64p]
+    lib.zkhip_prover_new.argtypes = [ctypes.c_void_p, ctypes.POINTER(R1csDesc), ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_prover_prove.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
+    lib.zkhip_prover_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+    lib.zkhip_prover_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_aggregator_pipeline_new.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_aggregator_pipeline_submit.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p, c_u64p, ctypes.POINTER(ctypes.c_uint64)]
+    lib.zkhip_aggregator_pipeline_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint64, c_u64p, c_u64p]
+    lib.zkhip_aggregator_pipeline_free.argtypes = [ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -115,6 +125,11 @@ def init(device=0):
 
 def set_msm_window(c):
     _check(load().zkhip_set_msm_window(c))
+
+
+def set_batch_msms(on):
+    """Table-backed keys: run the five MSMs of a proof through one launch sequence (default) or one each."""
+    _check(load().zkhip_set_batch_msms(int(bool(on))))
 
 
 def set_crs_precompute(on):
@@ -418,6 +433,64 @@ class AggregatorCircuit:
     def free(self):
         if self.handle:
             load().zkhip_aggregator_free(self.handle)
+            self.handle = None
+
+
+class Prover:
+    """A prover instance (zkhip_prover): own streams and work space, one proof in flight; several instances, one host
+    thread each, keep several proofs in flight on one GPU.  `crs` must outlive the instance."""
+
+    def __init__(self, crs, r1cs_desc):
+        h = ctypes.c_void_p()
+        _check(load().zkhip_prover_new(crs.handle, ctypes.byref(r1cs_desc), ctypes.byref(h)))
+        self.handle, self._crs = h, crs
+
+    def prove(self, z, r, s):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        z, r, s = c(z), c(r), c(s)
+        out = np.zeros(72, dtype=np.uint64)
+        _check(load().zkhip_prover_prove(self.handle, _p(z), _p(r), _p(s), _p(out)))
+        return out
+
+    def timings(self):
+        t = (ctypes.c_double * 8)()
+        _check(load().zkhip_prover_timings(self.handle, t))
+        return dict(zip(["upload_z", "qap", "msm_A", "msm_B2", "msm_B1", "msm_H", "msm_L", "host_tail"], list(t)))
+
+    def free(self):
+        if self.handle:
+            load().zkhip_prover_free(self.handle)
+            self.handle = None
+
+
+class AggregatorPipeline:
+    """Streaming aggregator_circuit::prove (zkhip_aggregator_pipeline_*): submit() returns a ticket at once, wait(ticket)
+    returns (primary_inputs, proof).  Witness generation, the GPU prover and the host tail of successive batches overlap."""
+
+    def __init__(self, agg, crs, gpu_slots=2, witness_workers=2):
+        h = ctypes.c_void_p()
+        _check(load().zkhip_aggregator_pipeline_new(agg.handle, crs.handle, gpu_slots, witness_workers, ctypes.byref(h)))
+        self.handle, self._agg, self._crs = h, agg, crs
+        self.n_primary = agg.num_primary_inputs()
+
+    def submit(self, nested_vk, nested_proofs, nested_inputs, r, s):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+        vk, pr, inp, r, s = c(nested_vk), c(nested_proofs), c(nested_inputs), c(r), c(s)
+        k, npf = self._agg.inputs_per_nested_proof, self._agg.num_proofs
+        assert vk.size == 60 + 12 * (k + 1) and pr.size == 48 * npf and inp.size == 6 * k * npf and r.size == 6 and s.size == 6
+        t = ctypes.c_uint64(0)
+        _check(load().zkhip_aggregator_pipeline_submit(self.handle, _p(vk), _p(pr), _p(inp), _p(r), _p(s), ctypes.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        prim = np.zeros((self.n_primary, 6), dtype=np.uint64)
+        proof = np.zeros(72, dtype=np.uint64)
+        _check(load().zkhip_aggregator_pipeline_wait(self.handle, ticket, _p(prim), _p(proof)))
+        return prim, proof
+
+    def free(self):
+        if self.handle:
+            load().zkhip_aggregator_pipeline_free(self.handle)
             self.handle = None
 
 
