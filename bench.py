@@ -79,12 +79,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-table", action="store_true", help="plain base sets: no precomputed window tables")
     ap.add_argument("--no-batch-msms", action="store_true", help="one launch sequence per MSM instead of one per proof")
-    ap.add_argument("--serial", action="store_true", help="aggregator workload: one proof in flight (per-phase timings) instead of the pipeline")
-    ap.add_argument("--gpu-slots", type=int, default=3, help="aggregator pipeline: proofs in flight on the GPU")
-    ap.add_argument("--witness-workers", type=int, default=4, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
+    ap.add_argument("--serial", action="store_true", help="one MSM / one proof in flight (per-phase timings) instead of the streaming forms")
+    ap.add_argument("--gpu-slots", type=int, default=4, help="aggregator pipeline: proofs in flight on the GPU")
+    ap.add_argument("--witness-workers", type=int, default=6, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
     ap.add_argument("--cpu-sample-log", type=int, default=17)
     args = ap.parse_args()
 
+    # the aggregator pipeline keeps several proofs in flight, each on its own streams: give the HIP runtime more than its
+    # default of 4 hardware queues (read once, when the runtime initialises)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -132,10 +135,30 @@ def main():
                     for i in range(min(args.steps + args.warmup, 4))]
         torch.cuda.synchronize()
 
-        def step(i):
-            s = scal_dev[i % len(scal_dev)]
-            part = bases.msm_dev(s.data_ptr(), n, montgomery=False)
-            return zdist.combine_partial_sums(part, device=dev) if (world > 1 or force_dist) else part
+        combine = (lambda part: zdist.combine_partial_sums(part, device=dev)) if (world > 1 or force_dist) else (lambda part: part)
+        if args.serial:
+            def step(i):
+                s = scal_dev[i % len(scal_dev)]
+                return combine(bases.msm_dev(s.data_ptr(), n, montgomery=False))
+        else:
+            # a stream of MSMs on the resident bases, two in flight (zkhip_msm_submit / zkhip_msm_collect): step i enqueues
+            # MSM i and collects MSM i-1; drain() inside the timed region collects the last one.  Every step is one full MSM.
+            inflight = []
+
+            def step(i):
+                s = scal_dev[i % len(scal_dev)]
+                bases.msm_submit(s.data_ptr(), n, slot=i % 2, montgomery=False)
+                inflight.append(i % 2)
+                if len(inflight) > 1:
+                    return combine(zkhip.msm_collect(inflight.pop(0)))
+
+            def drain():
+                out = None
+                while inflight:
+                    out = combine(zkhip.msm_collect(inflight.pop(0)))
+                return out
+            extra["drain"] = drain
+            extra["msm_in_flight"] = 2
         units_per_step = n * world
     elif args.workload == "aggregator":
         # the real wrapping circuit on the committed nested fixtures (reference testdata/dummy_app: vk.json, extproof1/2.json)

@@ -72,6 +72,16 @@ int zkhip_msm(const zkhip_bases* bases, size_t offset, const uint64_t* scalars, 
               uint64_t out_jac[36]);
 int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery,
                   uint64_t out_jac[36]);
+/* Device memory for host code that has no HIP runtime of its own (the *_dev entry points take device pointers). */
+int zkhip_device_alloc(size_t bytes, void** out);
+int zkhip_device_free(void* p);
+int zkhip_device_copy_in(void* dst, const void* src, size_t bytes);
+
+/* Asynchronous form of zkhip_msm_dev for a stream of MSMs on resident bases: submit enqueues the MSM on one of four
+ * slots and returns, collect waits for it.  d_scalars must stay valid until collect.  With two slots in flight the
+ * latency-bound bucket reduction of one MSM overlaps the accumulation of the next. */
+int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery, int slot);
+int zkhip_msm_collect(int slot, uint64_t out_jac[36]);
 /* one-shot form (BASELINE config 2): host bases + host scalars */
 int zkhip_msm_raw(const uint64_t* bases_affine, const uint64_t* scalars, size_t len, int scalars_montgomery,
                   uint64_t out_jac[36]);

@@ -216,3 +216,28 @@ def test_table_full_size_2_20_matches_plain_path(zk):
     b.precompute()
     assert (zk.jac_to_affine(b.msm(s, montgomery=False)) == plain).all()
     b.free()
+
+
+def test_submit_collect_two_in_flight(zk, oracle_lib):
+    """zkhip_msm_submit / zkhip_msm_collect: two MSMs in flight on two slots return what the blocking call returns;
+    a busy slot refuses a second submit, an idle slot has nothing to collect."""
+    O = oracle_lib
+    n = 6000
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(701, n), montgomery=False)
+    b = zk.Bases.upload(bases).precompute()
+    scal = [random_fr_canonical(710 + i, n) for i in range(3)]
+    dev = [zk.DeviceBuffer(s) for s in scal]
+    exp = [O.jac_to_affine(O.msm(bases, s)) for s in scal]
+    b.msm_submit(dev[0].ptr, n, slot=0)
+    b.msm_submit(dev[1].ptr, n, slot=1)
+    with pytest.raises(zk.ZkhipError):
+        b.msm_submit(dev[2].ptr, n, slot=1)
+    assert (zk.jac_to_affine(zk.msm_collect(0)) == exp[0]).all()
+    b.msm_submit(dev[2].ptr, n, slot=0)
+    assert (zk.jac_to_affine(zk.msm_collect(1)) == exp[1]).all()
+    assert (zk.jac_to_affine(zk.msm_collect(0)) == exp[2]).all()
+    with pytest.raises(zk.ZkhipError):
+        zk.msm_collect(0)
+    for d in dev:
+        d.free()
+    b.free()

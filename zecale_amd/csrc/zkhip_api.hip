@@ -103,6 +103,7 @@ int auto_table_window(size_t n) {
 // table_c = 0: plain plan with the automatic window;  > 0: merged plan (bases are a window table built for table_c)
 int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1) {
   const int c = table_c ? table_c : auto_window(n), merged = table_c ? 1 : 0;
+  if (*ready && cx->pending) return fail(ZKHIP_ERR_STATE, "an MSM submitted on this context has not been collected (zkhip_msm_collect)");
   if (*ready && cx->max_n >= n && cx->c == c && cx->merged == merged && cx->K == K) return ZKHIP_OK;
   if (*ready) { msm_plan_free(cx); *ready = false; }
   int rc = msm_plan_init(cx, n, c, merged, K);
@@ -154,6 +155,24 @@ const char* zkhip_last_error(void) { return t_err; }
 int zkhip_set_msm_window(int c) {
   if (c != 0 && (c < 4 || c > 18)) return fail(ZKHIP_ERR_ARG, "window must be 0 or in [4, 18]");   // (tables: zkhip_bases_precompute takes up to 22)
   g.forced_c = c;
+  return ZKHIP_OK;
+}
+
+// device memory for callers without a HIP runtime of their own (the *_dev entry points take such pointers)
+int zkhip_device_alloc(size_t bytes, void** out) {
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  API_HIP(hipMalloc(out, bytes ? bytes : 1));
+  return ZKHIP_OK;
+}
+int zkhip_device_free(void* p) {
+  if (p) API_HIP(hipFree(p));
+  return ZKHIP_OK;
+}
+int zkhip_device_copy_in(void* dst, const void* src, size_t bytes) {
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (bytes && (!dst || !src)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (bytes) API_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return ZKHIP_OK;
 }
 
@@ -233,6 +252,36 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
                scalars_montgomery, bases->len, out_jac);
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", g.ps.ctx[0].errbuf);
   else g.ps.last_accumulate_ms = g.ps.ctx[0].last_accumulate_ms;
+  return rc;
+}
+
+// Asynchronous form: enqueue on one of the library's MSM contexts and return; collect later.  Two MSMs in flight overlap
+// the latency-bound bucket reduction of one with the accumulation of the other (what the prover does between its own MSMs).
+int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery, int slot) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (!bases || (len && !d_scalars)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (slot < 0 || slot > 3) return fail(ZKHIP_ERR_ARG, "slot must be in [0, 3]");
+  if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
+  MsmCtx* cx = &g.ps.ctx[slot];
+  if (g.ps.ready[slot] && cx->pending) return fail(ZKHIP_ERR_STATE, "slot busy: collect its result first");
+  int rc = ensure_ctx(cx, &g.ps.ready[slot], len ? len : 1, bases->table_c);
+  if (rc != ZKHIP_OK) return rc;
+  rc = msm_launch(cx, bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
+                  scalars_montgomery, bases->len);
+  if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", cx->errbuf);
+  return rc;
+}
+
+int zkhip_msm_collect(int slot, uint64_t out_jac[36]) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  if (slot < 0 || slot > 3 || !out_jac) return fail(ZKHIP_ERR_ARG, "bad slot or null pointer");
+  MsmCtx* cx = &g.ps.ctx[slot];
+  if (!g.ps.ready[slot] || !cx->pending) return fail(ZKHIP_ERR_STATE, "nothing submitted on this slot");
+  int rc = msm_finish(cx, out_jac);
+  if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", cx->errbuf);
+  else g.ps.last_accumulate_ms = cx->last_accumulate_ms;
   return rc;
 }
 

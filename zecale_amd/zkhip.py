@@ -14,7 +14,8 @@ EXPORTS = [
     "zkhip_init", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window",
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
     "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window", "zkhip_set_batch_msms",
-    "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_last_accumulate_ms",
+    "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_msm_submit", "zkhip_msm_collect",
+    "zkhip_device_alloc", "zkhip_device_free", "zkhip_device_copy_in", "zkhip_last_accumulate_ms",
     "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
     "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings", "zkhip_groth16_verify",
@@ -57,6 +58,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ZkhipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(the HIP library is the only compute path; there is no CPU fallback)")
+    # several prover instances run on their own streams: more hardware queues than the runtime's default 4
+    # (only effective if the HIP runtime has not been initialised yet in this process)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = ctypes.CDLL(LIB_PATH)
     c_u64p = ctypes.POINTER(ctypes.c_uint64)
     lib.zkhip_init.argtypes = [ctypes.c_int]
@@ -75,6 +79,11 @@ def load():
     lib.zkhip_crs_table_window.argtypes = [ctypes.c_void_p]
     lib.zkhip_msm.argtypes = [ctypes.c_void_p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
     lib.zkhip_msm_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, c_u64p]
+    lib.zkhip_msm_submit.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
+    lib.zkhip_msm_collect.argtypes = [ctypes.c_int, c_u64p]
+    lib.zkhip_device_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_device_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_device_copy_in.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.zkhip_msm_raw.argtypes = [c_u64p, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
     lib.zkhip_fixed_base_mul.argtypes = [c_u64p, c_u64p, ctypes.c_size_t, ctypes.c_int, c_u64p]
     lib.zkhip_fixed_base_mul_dev.argtypes = [c_u64p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
@@ -179,10 +188,36 @@ class Bases:
         _check(load().zkhip_msm(self.handle, offset, _p(s), s.shape[0], int(montgomery), _p(out)))
         return out
 
+    def msm_submit(self, dev_ptr, n, slot, offset=0, montgomery=True):
+        """Enqueue an MSM on `slot` (0..3) and return; msm_collect(slot) waits for the result."""
+        _check(load().zkhip_msm_submit(self.handle, offset, ctypes.c_void_p(dev_ptr), n, int(montgomery), slot))
+
     def msm_dev(self, dev_ptr, n, offset=0, montgomery=True):
         out = np.zeros(36, dtype=np.uint64)
         _check(load().zkhip_msm_dev(self.handle, offset, ctypes.c_void_p(dev_ptr), n, int(montgomery), _p(out)))
         return out
+
+
+class DeviceBuffer:
+    """A host array copied into device memory owned by the library (for the *_dev / submit entry points)."""
+
+    def __init__(self, host_array):
+        a = np.ascontiguousarray(host_array)
+        p = ctypes.c_void_p()
+        _check(load().zkhip_device_alloc(a.nbytes, ctypes.byref(p)))
+        self.ptr, self.nbytes = p.value, a.nbytes
+        _check(load().zkhip_device_copy_in(ctypes.c_void_p(self.ptr), a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+
+    def free(self):
+        if self.ptr:
+            load().zkhip_device_free(ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+
+def msm_collect(slot):
+    out = np.zeros(36, dtype=np.uint64)
+    _check(load().zkhip_msm_collect(slot, _p(out)))
+    return out
 
 
 def msm_raw(bases_affine, scalars, montgomery=True):
