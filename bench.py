@@ -143,20 +143,39 @@ def main():
         else:
             # a stream of MSMs on the resident bases, two in flight (zkhip_msm_submit / zkhip_msm_collect): step i enqueues
             # MSM i and collects MSM i-1; drain() inside the timed region collects the last one.  Every step is one full MSM.
-            inflight = []
+            # N > 1: the 288-byte exchange of MSM i-1 is started when it is collected and read one step later
+            # (dist.combine_partial_sums_async): the all-gather kernel needs a free compute unit, which the accumulation of MSM i
+            # does not leave for milliseconds at a time.
+            inflight, exchanging = [], []
+            distributed = world > 1 or force_dist
+
+            def settle(keep):
+                out = None
+                while len(exchanging) > keep:
+                    out = exchanging.pop(0).result()
+                return out
 
             def step(i):
                 s = scal_dev[i % len(scal_dev)]
                 bases.msm_submit(s.data_ptr(), n, slot=i % 2, montgomery=False)
                 inflight.append(i % 2)
                 if len(inflight) > 1:
-                    return combine(zkhip.msm_collect(inflight.pop(0)))
+                    part = zkhip.msm_collect(inflight.pop(0))
+                    if not distributed:
+                        return part
+                    out = settle(0)
+                    exchanging.append(zdist.combine_partial_sums_async(part, device=dev))
+                    return out
 
             def drain():
                 out = None
                 while inflight:
-                    out = combine(zkhip.msm_collect(inflight.pop(0)))
-                return out
+                    part = zkhip.msm_collect(inflight.pop(0))
+                    if distributed:
+                        exchanging.append(zdist.combine_partial_sums_async(part, device=dev))
+                    else:
+                        out = part
+                return settle(0) if distributed else out
             extra["drain"] = drain
             extra["msm_in_flight"] = 2
         units_per_step = n * world

@@ -72,6 +72,8 @@ int zkhip_msm(const zkhip_bases* bases, size_t offset, const uint64_t* scalars, 
               uint64_t out_jac[36]);
 int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery,
                   uint64_t out_jac[36]);
+/* Device pointers handed to *_dev / submit entry points must hold complete data: the library runs on its own non-blocking
+ * streams, which are not ordered against the caller's streams (synchronise the producing stream first). */
 /* Device memory for host code that has no HIP runtime of its own (the *_dev entry points take device pointers). */
 int zkhip_device_alloc(size_t bytes, void** out);
 int zkhip_device_free(void* p);

@@ -29,8 +29,12 @@ def main():
     parts2 = np.stack([part, O.msm(bases[lo:hi], scal[lo:hi][::-1].copy(), chunks=1)])   # two MSMs in one exchange
     total = zdist.combine_partial_sums(part)
     total2 = zdist.combine_partial_sums(parts2)
+    # the non-blocking form used by the streaming bench: two exchanges in flight, read in order
+    h1 = zdist.combine_partial_sums_async(part)
+    h2 = zdist.combine_partial_sums_async(parts2)
+    async_ok = bool((h1.result() == total).all() and (h2.result() == total2).all())
     full = O.msm(bases, scal, chunks=2)
-    ok = (zkhip.jac_to_affine(total) == O.jac_to_affine(full)).all() and (zkhip.jac_to_affine(total2[0]) == O.jac_to_affine(full)).all()
+    ok = async_ok and (zkhip.jac_to_affine(total) == O.jac_to_affine(full)).all() and (zkhip.jac_to_affine(total2[0]) == O.jac_to_affine(full)).all()
     # every rank must hold identical limbs
     import torch
     t = torch.from_numpy(total.view(np.int64).copy())

@@ -636,8 +636,8 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   ctx->max_n = max_n;
   ctx->L = 4; ctx->logL = 2;
   size_t nb = ctx->B * ctx->W;
-  HIP_TRY(hipStreamCreate(&ctx->stream));
-  HIP_TRY(hipStreamCreate(&ctx->stream2));
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));   // no implicit ordering against the null stream (the host application's, e.g. torch's)
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&ctx->ev_acc0));

@@ -97,7 +97,8 @@ int auto_table_window(size_t n) {
   if (n <= (1u << 15)) return 14;
   if (n <= (1u << 17)) return 16;
   if (n <= (1u << 19)) return 18;
-  return 20;
+  if (n <= (1u << 21)) return 20;
+  return 21;
 }
 
 // table_c = 0: plain plan with the automatic window;  > 0: merged plan (bases are a window table built for table_c)
@@ -172,7 +173,10 @@ int zkhip_device_free(void* p) {
 int zkhip_device_copy_in(void* dst, const void* src, size_t bytes) {
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (bytes && (!dst || !src)) return fail(ZKHIP_ERR_ARG, "null pointer");
-  if (bytes) API_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  if (bytes) {
+    API_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    API_HIP(hipStreamSynchronize(0));
+  }
   return ZKHIP_OK;
 }
 
@@ -293,6 +297,7 @@ int zkhip_msm(const zkhip_bases* bases, size_t offset, const uint64_t* scalars, 
   if (len) {
     API_HIP(hipMalloc(&d, len * 48));
     API_HIP(hipMemcpy(d, scalars, len * 48, hipMemcpyHostToDevice));
+    API_HIP(hipStreamSynchronize(0));     // the MSM streams are not ordered against the null stream
   }
   int rc = zkhip_msm_dev(bases, offset, d, len, scalars_montgomery, out_jac);
   if (d) (void)hipFree(d);
@@ -489,7 +494,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   if (crs->B2->table_c != tc || crs->B1->table_c != tc || crs->H->table_c != tc || crs->L->table_c != tc)
     return fail(ZKHIP_ERR_ARG, "the five query vectors of a proving key must share one table window");
   auto t0 = clk::now();
-  if (!ps.st) API_HIP(hipStreamCreate(&ps.st));
+  if (!ps.st) API_HIP(hipStreamCreateWithFlags(&ps.st, hipStreamNonBlocking));
   if (ps.dz_cap < m) {
     if (ps.dz) { (void)hipFree(ps.dz); ps.dz = nullptr; ps.dz_cap = 0; }
     API_HIP(hipMalloc(&ps.dz, m * 48));

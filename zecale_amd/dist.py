@@ -40,6 +40,43 @@ def combine_partial_sums(part_jac, group=None, device=None):
     return out.reshape(shape)
 
 
+class PendingSum:
+    """An exchange of partial sums in flight (combine_partial_sums_async).  result() waits for the all-gather and adds the
+    ranks' points in rank order."""
+
+    def __init__(self, shape, gathered, work, local):
+        self._shape, self._gathered, self._work, self._local = shape, gathered, work, local
+
+    def result(self):
+        if self._gathered is None:
+            return self._local
+        if self._work is not None:
+            self._work.wait()
+        parts = [g.cpu().numpy().view(np.uint64) for g in self._gathered]
+        out = parts[0].copy()
+        for q in parts[1:]:
+            for k in range(out.shape[0]):
+                out[k] = zkhip.jac_add(out[k], q[k])
+        return out.reshape(self._shape)
+
+
+def combine_partial_sums_async(part_jac, group=None, device=None):
+    """Start the exchange of this rank's partial sum(s) and return a PendingSum.  While an MSM accumulates, the chip has no free
+    compute unit for the (tiny) all-gather kernel: a streaming caller starts the exchange of MSM i-1 when it collects it and reads
+    the result one step later, so the collective never stalls the MSM stream.  Collective: every rank must call it, in the same order."""
+    p = np.ascontiguousarray(part_jac, dtype=np.uint64)
+    shape = p.shape
+    if not dist.is_initialized():
+        return PendingSum(shape, None, None, p.copy())
+    world = dist.get_world_size(group)
+    mine = torch.from_numpy(p.reshape(-1, 36).view(np.int64).copy())
+    if device is not None:
+        mine = mine.to(device, non_blocking=True)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    work = dist.all_gather(gathered, mine, group=group, async_op=True)
+    return PendingSum(shape, gathered, work, None)
+
+
 def key_slices(n_vars, n_primary, domain_size, world, rank):
     """Ranges of the A/B, H and L queries owned by `rank` (contiguous, sizes differ by at most one)."""
     return (partition(n_vars, world, rank), partition(domain_size - 1, world, rank), partition(n_vars - n_primary - 1, world, rank))
