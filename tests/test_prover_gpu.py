@@ -22,7 +22,18 @@ def _golden_case():
     return g, pk
 
 
-def test_golden_small_circuit(zk):
+@pytest.fixture(params=["tables+batched", "tables", "plain"])
+def key_mode(zk, request):
+    """The three ways a proving key is held and its five MSMs are launched (all must give the same proof): window tables with
+    the five MSMs in one launch sequence (default), window tables with one launch sequence per MSM, plain base sets."""
+    zk.set_crs_precompute(request.param != "plain")
+    zk.set_batch_msms(request.param == "tables+batched")
+    yield request.param
+    zk.set_crs_precompute(True)
+    zk.set_batch_msms(True)
+
+
+def test_golden_small_circuit(zk, key_mode):
     g, pk = _golden_case()
     A, B, C = (csr_from_rows(g[k]) for k in "ABC")
     z = fr_array([h2i(x) for x in g["z"]])
@@ -33,6 +44,7 @@ def test_golden_small_circuit(zk):
     assert not r1.is_satisfied(zbad)
     assert fr_ints(r1.qap_h(z)) == [h2i(x) for x in g["h"]]
     crs = zk.Crs(pk, len(g["z"]), g["n_primary"], 1 << g["log_d"])
+    assert (crs.table_window > 0) == (key_mode != "plain")
     proof = zk.groth16_prove(crs, r1, z, fr_limbs(h2i(g["r"])), fr_limbs(h2i(g["s"])))
     assert aff_point(proof[:24]) == pt_from_json(g["proof"]["a"])
     assert aff_point(proof[24:48]) == pt_from_json(g["proof"]["b"])
@@ -41,7 +53,7 @@ def test_golden_small_circuit(zk):
 
 
 @pytest.mark.parametrize("n,bool_frac", [(3000, 0.0), (4000, 0.6)])
-def test_synthetic_circuit_vs_oracle_and_trapdoor(zk, oracle_lib, n, bool_frac):
+def test_synthetic_circuit_vs_oracle_and_trapdoor(zk, oracle_lib, key_mode, n, bool_frac):
     O = oracle_lib
     n_primary, n_aux = 4, n                # the wrapping circuit has 4 primary inputs (aggregator_circuit.tcc:172-180)
     A, B, C, z = make_r1cs(11 + n, n, n_primary, n_aux, bool_frac)
