@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--workload", choices=["msm", "prover", "aggregator"], default="msm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-table", action="store_true", help="plain base sets: no precomputed window tables")
+    ap.add_argument("--window", type=int, default=0, help="override the MSM window c (tuning; 0 = automatic, at most 18)")
     ap.add_argument("--no-batch-msms", action="store_true", help="one launch sequence per MSM instead of one per proof")
     ap.add_argument("--serial", action="store_true", help="one MSM / one proof in flight (per-phase timings) instead of the streaming forms")
     ap.add_argument("--gpu-slots", type=int, default=4, help="aggregator pipeline: proofs in flight on the GPU")
@@ -108,6 +109,7 @@ def main():
     zkhip.init(local)
     zkhip.set_crs_precompute(not args.no_table)
     zkhip.set_batch_msms(not args.no_batch_msms)
+    zkhip.set_msm_window(args.window)
     n = 1 << args.log_n
     g1 = g1_generator_limbs()
 

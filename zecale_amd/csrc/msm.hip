@@ -511,7 +511,8 @@ __global__ void __launch_bounds__(256, 2) k_fixed_base_mul(const AffPacked* __re
   fp_to_abi<FqParams>(mem_ld(acc, CY), o + 12);
 }
 
-// ---- window tables: table[w * n + i] = 2^(c w) P_i, affine, for w = 1 .. levels-1 (level 0 is the base set itself).
+// ---- window tables: table[w * n + i] = 2^(off_w) P_i, affine, for w = 1 .. levels-1 (level 0 is the base set itself; off_w is
+// the first bit of window w in the balanced layout, c*w for most of them).
 // With the table every digit position of a scalar addresses the same bucket window (the entry points at the
 // pre-shifted base), so one MSM has 2^(c-1) buckets instead of W * 2^(c-1): the bucket reduction shrinks W-fold and c
 // can grow until the accumulation (n * ceil(378/c) mixed additions) stops shrinking.  Built once per base set (a
@@ -531,7 +532,7 @@ __device__ __forceinline__ XyzzRef make_ref5(uint32_t* base, uint32_t stride, ui
 }
 
 __global__ void __launch_bounds__(256, 2) k_table_build(AffPacked* __restrict__ table, uint8_t* __restrict__ tinf, size_t n, size_t i0,
-                                                         uint32_t cn, int c, int levels, uint32_t* __restrict__ work, uint32_t stride) {
+                                                         uint32_t cn, WindowPlan plan, int levels, uint32_t* __restrict__ work, uint32_t stride) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cn) return;
   const size_t i = i0 + t;
@@ -556,8 +557,9 @@ __global__ void __launch_bounds__(256, 2) k_table_build(AffPacked* __restrict__ 
     } else {
       mem_copy(r, make_ref5(work, stride, (uint32_t)(w - 2) * cn + t));
     }
+    const int nd = plan.bits[w - 1];       // level w = 2^(off_w) P, off_w - off_(w-1) = bits of window w-1
 #pragma unroll 1
-    for (int d = 0; d < c; d++) dbl_mem(r);
+    for (int d = 0; d < nd; d++) dbl_mem(r);
   }
   // prefix products of ZZ * ZZZ over the finite levels
   Fq q = fp_one<FqParams>();
@@ -607,6 +609,17 @@ __global__ void __launch_bounds__(256, 2) k_table_build(AffPacked* __restrict__ 
 
 static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// Window layout: W = ceil(378 / c) windows tile exactly 378 bits; the top W*c - 378 of them get c-1 bits.
+static void window_layout(int c, uint16_t* off, uint8_t* bits) {
+  const int W = (378 + c - 1) / c, n_small = W * c - 378;
+  int bit = 0;
+  for (int w = 0; w < W; w++) {
+    int cw = (w >= W - n_small) ? c - 1 : c;
+    off[w] = (uint16_t)bit; bits[w] = (uint8_t)cw;
+    bit += cw;
+  }
+}
+
 int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   memset(ctx, 0, sizeof *ctx);
   if (K < 1 || K > MSM_MAX_JOBS || (!merged && K != 1)) return ZKHIP_ERR_ARG;
@@ -617,21 +630,9 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   ctx->merged = merged ? 1 : 0;
   ctx->Wd = (378 + c - 1) / c;   // scalars < 2^377, +1 bit for the signed-digit carry
   ctx->W = merged ? K : ctx->Wd;
-  if (!merged) {
-    int n_small = ctx->Wd * c - 378, bit = 0;   // that many windows get c-1 bits (the top ones)
-    for (int w = 0; w < ctx->Wd; w++) {
-      int cw = (w >= ctx->Wd - n_small) ? c - 1 : c;
-      ctx->win_off[w] = (uint16_t)bit; ctx->win_bits[w] = (uint8_t)cw;
-      bit += cw;
-    }
-  } else {
-    // table levels are 2^(c w) P: uniform windows, the top one takes what is left of the 378 bits (all digit
-    // positions share one bucket window, so a short top window costs nothing)
-    for (int w = 0; w < ctx->Wd; w++) {
-      int cw = 378 - w * c < c ? 378 - w * c : c;
-      ctx->win_off[w] = (uint16_t)(w * c); ctx->win_bits[w] = (uint8_t)cw;
-    }
-  }
+  // plain and merged plans share the balanced layout: a table's level w is 2^(off_w) P.  (A short top window would also
+  // hurt a merged plan: its n digits of a few bits would all land in a handful of the shared buckets.)
+  window_layout(c, ctx->win_off, ctx->win_bits);
   ctx->B = (size_t)1 << (c - 1);
   ctx->max_n = max_n;
   ctx->L = 4; ctx->logL = 2;
@@ -942,6 +943,9 @@ int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]) {
 int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, char* errbuf, size_t errlen) {
   const int levels = msm_table_levels(c);
   if (n == 0 || levels < 2) return ZKHIP_OK;
+  WindowPlan plan;
+  memset(&plan, 0, sizeof plan);
+  window_layout(c, plan.off, plan.bits);
   // points per launch: (levels - 1) * chunk slots of 135 words, at most 4M slots (2.2 GB of work space)
   size_t chunk = ((size_t)1 << 22) / (size_t)(levels - 1);
   chunk &= ~(size_t)255;
@@ -951,7 +955,7 @@ int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, char* 
   hipError_t e = hipMalloc(&work, (size_t)stride * 135 * 4);
   for (size_t i0 = 0; e == hipSuccess && i0 < n; i0 += chunk) {
     uint32_t cn = (uint32_t)((n - i0 < chunk) ? n - i0 : chunk);
-    hipLaunchKernelGGL(k_table_build, dim3(nblk(cn, 256)), dim3(256), 0, 0, d_table, d_tinf, n, i0, cn, c, levels, work, stride);
+    hipLaunchKernelGGL(k_table_build, dim3(nblk(cn, 256)), dim3(256), 0, 0, d_table, d_tinf, n, i0, cn, plan, levels, work, stride);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
   }
