@@ -128,28 +128,56 @@ class aggregator_circuit {
     return std::unique_ptr<keypair>(new keypair(kp));
   }
 
+  // Streaming form for a server that wraps batch after batch (zkhip_aggregator_pipeline_*): submit() returns a ticket at
+  // once, wait(ticket) the extended proof.  Witness generation, the GPU prover (gpu_slots proofs in flight) and the host
+  // tail of successive batches overlap.  The stream must not outlive the circuit or the keypair.
+  class stream {
+   public:
+    stream(aggregator_circuit& c, const keypair& kp, int gpu_slots, int witness_workers) : c_(c) {
+      zk_check(zkhip_aggregator_pipeline_new(c.agg_, kp.pk(), gpu_slots, witness_workers, &p_), "zkhip_aggregator_pipeline_new");
+    }
+    stream(const stream&) = delete;
+    stream& operator=(const stream&) = delete;
+    ~stream() { zkhip_aggregator_pipeline_free(p_); }
+    uint64_t submit(const nested_verification_key& nested_vk, const std::array<const nested_extended_proof*, NumProofs>& nested_proofs) {
+      std::vector<uint64_t> vk, proofs, inputs;
+      c_.flatten(nested_vk, nested_proofs, vk, proofs, inputs);
+      uint64_t r[6], s[6], ticket = 0;
+      random_scalars(r, s);
+      zk_check(zkhip_aggregator_pipeline_submit(p_, vk.data(), proofs.data(), inputs.data(), r, s, &ticket), "zkhip_aggregator_pipeline_submit");
+      return ticket;
+    }
+    extended_proof wait(uint64_t ticket) {
+      const size_t np = c_.num_primary_inputs();
+      std::vector<uint64_t> prim(np * 6);
+      uint64_t out[72];
+      zk_check(zkhip_aggregator_pipeline_wait(p_, ticket, prim.data(), out), "zkhip_aggregator_pipeline_wait");
+      extended_proof ep;
+      std::memcpy(ep.proof.a.data(), out, 192); std::memcpy(ep.proof.b.data(), out + 24, 192); std::memcpy(ep.proof.c.data(), out + 48, 192);
+      for (size_t i = 0; i < np; i++) {
+        std::array<uint64_t, 6> x;
+        std::memcpy(x.data(), &prim[i * 6], 48);
+        ep.primary_inputs.push_back(x);
+      }
+      return ep;
+    }
+   private:
+    aggregator_circuit& c_;
+    zkhip_pipeline* p_ = nullptr;
+  };
+  std::unique_ptr<stream> open_stream(const keypair& kp, int gpu_slots = 4, int witness_workers = 6) {
+    return std::unique_ptr<stream>(new stream(*this, kp, gpu_slots, witness_workers));
+  }
+
   // Non-const like the reference (it fills its protoboard); not re-entrant.
   extended_proof prove(const nested_verification_key& nested_vk,
                        const std::array<const nested_extended_proof*, NumProofs>& nested_proofs, const keypair& kp) {
-    std::vector<uint64_t> proofs, inputs;
-    for (size_t i = 0; i < NumProofs; i++) {
-      const auto& in = nested_proofs[i]->get_primary_inputs();
-      if (in.size() != inputs_per_nested_proof_)
-        throw std::runtime_error("unexpected number of inputs in nested proof " + std::to_string(i));   // tcc:138-141
-      const nested_proof& p = nested_proofs[i]->get_proof();
-      proofs.insert(proofs.end(), p.a.begin(), p.a.end());
-      proofs.insert(proofs.end(), p.b.begin(), p.b.end());
-      proofs.insert(proofs.end(), p.c.begin(), p.c.end());
-      for (const auto& x : in) inputs.insert(inputs.end(), x.begin(), x.end());
-    }
-    if (nested_vk.abc_g1.size() != inputs_per_nested_proof_ + 1) throw std::runtime_error("nested verification key has the wrong size");
-    std::vector<uint64_t> vk = nested_vk.flat(), z(cs_.n_vars * 6);
+    std::vector<uint64_t> vk, proofs, inputs, z(cs_.n_vars * 6);
+    flatten(nested_vk, nested_proofs, vk, proofs, inputs);
     zk_check(zkhip_aggregator_witness(agg_, vk.data(), proofs.data(), inputs.data(), z.data()), "zkhip_aggregator_witness");
     if (!r1cs_) zk_check(zkhip_r1cs_upload(&cs_, &r1cs_), "zkhip_r1cs_upload");
-    std::random_device rd;
     uint64_t r[6], s[6];
-    for (int i = 0; i < 6; i++) { r[i] = ((uint64_t)rd() << 32) | rd(); s[i] = ((uint64_t)rd() << 32) | rd(); }
-    r[5] &= (1ull << 56) - 1; s[5] &= (1ull << 56) - 1;
+    random_scalars(r, s);
     uint64_t out[72];
     zk_check(zkhip_groth16_prove(kp.pk(), r1cs_, z.data(), r, s, out), "zkhip_groth16_prove");
     extended_proof ep;
@@ -163,6 +191,27 @@ class aggregator_circuit {
   }
 
  private:
+  // argument checks of the reference's prove (tcc:138-141) + the flat limb arrays the C ABI takes
+  void flatten(const nested_verification_key& nested_vk, const std::array<const nested_extended_proof*, NumProofs>& nested_proofs,
+               std::vector<uint64_t>& vk, std::vector<uint64_t>& proofs, std::vector<uint64_t>& inputs) const {
+    for (size_t i = 0; i < NumProofs; i++) {
+      const auto& in = nested_proofs[i]->get_primary_inputs();
+      if (in.size() != inputs_per_nested_proof_)
+        throw std::runtime_error("unexpected number of inputs in nested proof " + std::to_string(i));   // tcc:138-141
+      const nested_proof& p = nested_proofs[i]->get_proof();
+      proofs.insert(proofs.end(), p.a.begin(), p.a.end());
+      proofs.insert(proofs.end(), p.b.begin(), p.b.end());
+      proofs.insert(proofs.end(), p.c.begin(), p.c.end());
+      for (const auto& x : in) inputs.insert(inputs.end(), x.begin(), x.end());
+    }
+    if (nested_vk.abc_g1.size() != inputs_per_nested_proof_ + 1) throw std::runtime_error("nested verification key has the wrong size");
+    vk = nested_vk.flat();
+  }
+  static void random_scalars(uint64_t r[6], uint64_t s[6]) {      // < 2^376 < r: valid residues
+    std::random_device rd;
+    for (int i = 0; i < 6; i++) { r[i] = ((uint64_t)rd() << 32) | rd(); s[i] = ((uint64_t)rd() << 32) | rd(); }
+    r[5] &= (1ull << 56) - 1; s[5] &= (1ull << 56) - 1;
+  }
   size_t inputs_per_nested_proof_;
   zkhip_aggregator* agg_ = nullptr;
   zkhip_r1cs_desc cs_;

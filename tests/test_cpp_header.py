@@ -59,6 +59,9 @@ def test_aggregator_circuit_mirror_compiles_and_runs_host_part(tmp_path):
             agg.prove(vk, ps, *(const keypair*)nullptr);
           } catch (const std::runtime_error& e) { std::printf("caught: %s\n", e.what()); }
           try { agg.generate_trusted_setup(); } catch (const std::runtime_error& e) { std::printf("setup: %s\n", e.what()); }
+          // the streaming form needs a device: instantiate it only
+          auto f_open = &aggregator_circuit<2>::open_stream; auto f_sub = &aggregator_circuit<2>::stream::submit;
+          auto f_wait = &aggregator_circuit<2>::stream::wait; (void)f_open; (void)f_sub; (void)f_wait;
           extended_proof ep{};
           ep.primary_inputs.resize(1);
           std::printf("%s\n", ep.to_json().substr(0, 40).c_str());

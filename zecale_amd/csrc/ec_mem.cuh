@@ -268,6 +268,61 @@ __device__ __forceinline__ void add_mem(const XyzzRef& A, const XyzzRef& B) {
   if (same_x) add_same_x(A, B);
 }
 
+// add_mem with a per-lane LDS scratch of 2 x 27 words (limb-major images, ZK_LDS_STRIDE lanes per block): A's ZZ and ZZZ are
+// fetched once instead of three times each, and the two-step products ZZ1 PP ZZ2 / ZZZ1 PPP ZZZ2 keep their intermediate in
+// LDS instead of a global round trip: 15 coordinate transfers per addition instead of 22 (the throughput-bound reduction
+// launches run at the L2's bandwidth, not at the multiplier's).
+__device__ __forceinline__ void add_mem_s(const XyzzRef& A, const XyzzRef& B, uint32_t* zz, uint32_t* zzz) {
+  if (mem_is_inf(B)) return;
+  {
+    Fq z1 = mem_ld(A, CZZ);
+    if (fp_is_zero_2p(z1)) { mem_copy(A, B); return; }
+    lds_st(zz, z1);
+    lds_st(zzz, mem_ld(A, CZZZ));
+  }
+  Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
+  bool same_x = false;
+#pragma unroll 1
+  for (int step = 0; step < 14; step++) {
+    Fq a, b;
+    switch (step) {
+      case 0: a = mem_ld(A, CX); b = mem_ld(B, CZZ); break;          // U1
+      case 1: a = mem_ld(B, CX); b = lds_ld(zz); break;              // U2
+      case 2: a = T1; b = T1; break;                                 // PP
+      case 3: a = T1; b = T2; break;                                 // PPP
+      case 4: a = T0; b = T2; break;                                 // Q = U1 PP
+      case 5: a = lds_ld(zz); b = T2; break;                         // ZZ1 PP
+      case 6: a = lds_ld(zz); b = mem_ld(B, CZZ); break;             // (ZZ1 PP) ZZ2
+      case 7: a = mem_ld(A, CY); b = mem_ld(B, CZZZ); break;         // S1
+      case 8: a = mem_ld(B, CY); b = lds_ld(zzz); break;             // S2
+      case 9: a = lds_ld(zzz); b = T1; break;                        // ZZZ1 PPP
+      case 10: a = lds_ld(zzz); b = mem_ld(B, CZZZ); break;          // (ZZZ1 PPP) ZZZ2
+      case 11: a = T2; b = T1; break;                                // Y3b = S1 PPP
+      case 12: a = T3; b = T3; break;                                // RR
+      default: a = T3; b = fp_sub<FqParams, 16>(T0, T1); break;      // Y3a = R (Q - X3)
+    }
+    Fq r = fp_mul(a, b);
+    switch (step) {
+      case 0: T0 = r; break;                                         // U1
+      case 1: T1 = fp_sub<FqParams, 2>(r, T0); break;                // P [4]
+      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
+      case 3: T1 = r; break;                                         // PPP
+      case 4: T0 = r; break;                                         // Q
+      case 5: lds_st(zz, r); break;
+      case 6: mem_st(A, CZZ, r); break;                              // ZZ3
+      case 7: T2 = r; break;                                         // S1
+      case 8: T3 = fp_sub<FqParams, 2>(r, T2); break;                // R [4]
+      case 9: lds_st(zzz, r); break;
+      case 10: mem_st(A, CZZZ, r); break;                            // ZZZ3
+      case 11: T2 = r; break;                                        // Y3b
+      case 12: T1 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T1), fp_dbl(T0)); mem_st(A, CX, T1); break;   // X3 [10]
+      default: mem_st(A, CY, fp_sub<FqParams, 2>(r, T2)); break;     // Y3 [4]
+    }
+    if (same_x) break;
+  }
+  if (same_x) add_same_x(A, B);     // memory still holds A's original ZZ, ZZZ at this point (first stores are steps 6 and 10)
+}
+
 // a (memory) = 2 a.   dbl-2008-s-1 as a micro-program: 9 multiplications
 __device__ __forceinline__ void dbl_mem(const XyzzRef& A) {
   if (mem_is_inf(A)) return;

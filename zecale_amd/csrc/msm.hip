@@ -289,8 +289,13 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
 // Point operations on memory accumulators executed by one lane (QUAD = false: throughput-bound
 // launches with at least as many additions as lanes) or by a DPP quad (QUAD = true: latency-bound
 // launches; see ec_mem.cuh).  In quad mode all four lanes of a quad receive the same references.
-template <bool QUAD> __device__ __forceinline__ void pt_add(const XyzzRef& a, const XyzzRef& b, uint32_t q) {
-  if constexpr (QUAD) add_mem_quad(a, b, q); else add_mem(a, b);
+// per-lane LDS scratch of the one-lane additions (add_mem_s): two 27-word limb-major images per 256-lane block
+struct AddScratch { uint32_t* zz; uint32_t* zzz; };
+#define ADD_SCRATCH_DECL(QUADFLAG)                                                                   \
+  __shared__ uint32_t s_add_zz_[(QUADFLAG) ? 1 : 27 * ZK_LDS_STRIDE], s_add_zzz_[(QUADFLAG) ? 1 : 27 * ZK_LDS_STRIDE]; \
+  const AddScratch sc{s_add_zz_ + ((QUADFLAG) ? 0 : threadIdx.x), s_add_zzz_ + ((QUADFLAG) ? 0 : threadIdx.x)}
+template <bool QUAD> __device__ __forceinline__ void pt_add(const XyzzRef& a, const XyzzRef& b, uint32_t q, const AddScratch& sc) {
+  if constexpr (QUAD) add_mem_quad(a, b, q); else add_mem_s(a, b, sc.zz, sc.zzz);
 }
 template <bool QUAD> __device__ __forceinline__ void pt_dbl(const XyzzRef& a, uint32_t q) {
   if constexpr (QUAD) dbl_mem_quad(a, q); else dbl_mem(a);
@@ -312,6 +317,7 @@ __global__ void __launch_bounds__(256, 2) k_fixup_round(const uint32_t* __restri
                                                          uint32_t nb, uint32_t S, uint32_t T, uint32_t d,
                                                          const uint32_t* __restrict__ max_span, uint32_t* __restrict__ slots,
                                                          uint32_t stride) {
+  ADD_SCRATCH_DECL(QUAD);
   if (d >= *max_span) return;
   uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt, q = gt & 3u;   // one lane or one quad per slice
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
@@ -321,12 +327,13 @@ __global__ void __launch_bounds__(256, 2) k_fixup_round(const uint32_t* __restri
   if (offsets[b] >= pos0) return;                       // slice does not start inside a bucket
   uint32_t tF0 = offsets[b] / S + 1, tF1 = (offsets[b] + counts[b] - 1) / S;
   if ((t - tF0) % (2 * d) != 0 || t + d > tF1) return;
-  pt_add<QUAD>(make_ref(slots, stride, nb + t), make_ref(slots, stride, nb + t + d), q);
+  pt_add<QUAD>(make_ref(slots, stride, nb + t), make_ref(slots, stride, nb + t + d), q, sc);
 }
 
 // final stitch: the slice in which a cut bucket STARTS owns it: bucket = L[t0] + F[t0+1] (folded).
 __global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                    uint32_t nb, uint32_t S, uint32_t T, uint32_t* __restrict__ slots, uint32_t stride) {
+  ADD_SCRATCH_DECL(false);
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // throughput-bound (one addition per slice): one lane each
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
   uint32_t pos0 = t * S;
@@ -337,7 +344,7 @@ __global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ o
   if (bend <= pos1 || offsets[b] < pos0) return;      // not cut at this slice's end, or started earlier
   XyzzRef dst = make_ref(slots, stride, b);
   mem_copy(dst, make_ref(slots, stride, nb + T + t));
-  add_mem(dst, make_ref(slots, stride, nb + t + 1));
+  add_mem_s(dst, make_ref(slots, stride, nb + t + 1), sc.zz, sc.zzz);
 }
 
 // Segment pass of the bucket reduction.  in: n_in items (XYZZ limb-major, stride n_in), grouped in
@@ -346,6 +353,7 @@ __global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ o
 template <bool QUAD>
 __global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_t n_in, uint32_t in_stride, int L, int o,
                                                  uint32_t* __restrict__ outS, uint32_t* __restrict__ outR) {
+  ADD_SCRATCH_DECL(QUAD);
   size_t n_out = n_in / L;
   size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt;    // one lane / quad per segment
   const uint32_t q = (uint32_t)(gt & 3);
@@ -355,8 +363,8 @@ __global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_
   pt_set_inf<QUAD>(acc, q);
   for (int u = L - 1; u >= 0; u--) {
     XyzzRef it = make_ref(in, in_stride, (uint32_t)(t * L + u));
-    pt_add<QUAD>(run, it, q);
-    if (u + o > 0) pt_add<QUAD>(acc, run, q);
+    pt_add<QUAD>(run, it, q, sc);
+    if (u + o > 0) pt_add<QUAD>(acc, run, q, sc);
   }
 }
 
@@ -366,6 +374,7 @@ __global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_
 template <bool QUAD>
 __global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_t n_in, uint32_t in_stride, int L, uint32_t row_len,
                                                  uint32_t* __restrict__ out) {
+  ADD_SCRATCH_DECL(QUAD);
   size_t n_out = n_in / L;
   size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt;    // one lane / quad per output
   const uint32_t q = (uint32_t)(gt & 3);
@@ -373,7 +382,7 @@ __global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_
   const size_t i0 = (t / row_len) * ((size_t)L * row_len) + (t % row_len);
   XyzzRef acc = make_ref(out, (uint32_t)n_out, (uint32_t)t);
   pt_copy<QUAD>(acc, make_ref(in, in_stride, (uint32_t)i0), q);
-  for (int u = 1; u < L; u++) pt_add<QUAD>(acc, make_ref(in, in_stride, (uint32_t)(i0 + (size_t)u * row_len)), q);
+  for (int u = 1; u < L; u++) pt_add<QUAD>(acc, make_ref(in, in_stride, (uint32_t)(i0 + (size_t)u * row_len)), q, sc);
 }
 
 // Two-level split of the bucket index j = hi * R + lo (R = 2^lo_bits, H = 2^hi_bits rows):
@@ -816,7 +825,9 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     while (left > 1) {
       int L = ctx->L; while ((uint32_t)L > left) L >>= 1;
       uint32_t* out = ctx->segS[pp];
-      launch_sum(st, in, n_in, in_stride, L, 1, out);
+      // halving-style grouping inside each row of `left` items (item lo' + u * left/L): lanes of a wave read adjacent
+      // slots (summing L CONSECUTIVE items instead makes every lane stride L slots: a quarter of each sector used)
+      launch_sum(st, in, n_in, in_stride, L, left / L, out);
       n_in /= L; left /= L; in = out; in_stride = (uint32_t)n_in; pp ^= 1; rows = out;
     }
     // column tree: [W][H][R] -> [W][R]  (sum over hi, stride R)
@@ -863,7 +874,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
       while ((size_t)Ls > rn / G) Ls >>= 1;
       size_t ro = rn / Ls;
       uint32_t* dst = (ro == (size_t)G) ? ctx->Rlevels + (size_t)level * 108 * G : ctx->sumR[pp];
-      launch_sum(st2, rc, rn, (uint32_t)rn, Ls, 1, dst);
+      launch_sum(st2, rc, rn, (uint32_t)rn, Ls, (uint32_t)(rn / G / Ls), dst);      // same coalesced grouping inside each group
       rc = dst; rn = ro; pp ^= 1;
     }
     if (n_out == (size_t)G) {   // R already one per group
