@@ -243,6 +243,11 @@ int zkhip_keypair_crs_desc(const zkhip_keypair* kp, zkhip_crs_desc* out);
 /* verification half: alpha (G1), beta, delta (G2), abc = (n_primary + 1) x 24 limbs; returns n_primary + 1 */
 size_t zkhip_keypair_vk(const zkhip_keypair* kp, uint64_t alpha_g1[24], uint64_t beta_g2[24], uint64_t delta_g2[24],
                         const uint64_t** abc);
+/* replaces: wsnarkT::keypair_write_bytes / keypair_read_bytes (aggregator_server.cpp:77-94: the server writes the key after
+ * the first setup and reads it on later starts).  The reference's byte layout lives in the absent libzeth; this is the library's
+ * own container (header, the limb arrays as they cross this ABI, checksum): not interchangeable with a reference key file. */
+int zkhip_keypair_write(const zkhip_keypair* kp, const char* path);
+int zkhip_keypair_read(const char* path, zkhip_keypair** out);
 void zkhip_keypair_free(zkhip_keypair* kp);
 
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */

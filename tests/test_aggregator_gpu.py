@@ -100,3 +100,22 @@ def test_pipeline_matches_serial_path(zk, slots, workers):
         pipe.wait(12345)                                                # unknown ticket
     pipe.free()
     crs.free(); r1.free(); kp.free(); agg.free()
+
+
+def test_keypair_file_round_trip_proves_the_same(zk, tmp_path):
+    """The server's start-up path (aggregator_server.cpp:483-514): the key written after setup and read back on a later
+    start proves exactly what the in-memory key proves, and the verification key is the same."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    path = tmp_path / "zecale_keypair.bin"
+    kp.write(path)
+    kp2 = zk.Keypair.read(path)
+    vk, vk2 = kp.vk(), kp2.vk()
+    assert all((vk[k] == vk2[k]).all() for k in vk)
+    (pa, ia), (pb, ib) = proofs[0], proofs[1]
+    z = agg.witness(nvk_l, np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)]), np.array([fr_limbs(ia[0]), fr_limbs(ib[0])]))
+    r1 = zk.r1cs_from_desc(desc)
+    crs, crs2 = kp.upload_crs(), kp2.upload_crs()
+    r, s = fr_limbs(0x777), fr_limbs(0x999)
+    p1, p2 = zk.groth16_prove(crs, r1, z, r, s), zk.groth16_prove(crs2, r1, z, r, s)
+    assert (p1 == p2).all() and zk.groth16_verify(vk2, z[1:1 + agg.num_primary_inputs()], p2)
+    crs.free(); crs2.free(); r1.free(); kp.free(); kp2.free(); agg.free()

@@ -796,6 +796,65 @@ size_t zkhip_keypair_vk(const zkhip_keypair* kp, uint64_t alpha_g1[24], uint64_t
   return kp->n_primary + 1;
 }
 
+// ---- keypair file (the role of wsnarkT::keypair_write_bytes / keypair_read_bytes, aggregator_server.cpp:77-94).  The
+// reference's byte format is defined in the absent libzeth, so this is the library's own container: a 64-byte header
+// ("ZKHIPKP1", sizes) followed by the limb arrays exactly as they cross the C ABI (Montgomery u64 limbs, little-endian),
+// and a 64-bit FNV-1a checksum of everything before it.  Host code, no device needed.
+namespace {
+const char KP_MAGIC[8] = {'Z', 'K', 'H', 'I', 'P', 'K', 'P', '1'};
+uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+}  // namespace
+
+int zkhip_keypair_write(const zkhip_keypair* kp, const char* path) {
+  if (!kp || !path) return fail(ZKHIP_ERR_ARG, "null pointer");
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(ZKHIP_ERR_ARG, "cannot open the keypair file for writing");
+  uint64_t hdr[8] = {0, (uint64_t)kp->n_vars, (uint64_t)kp->n_primary, (uint64_t)kp->domain_size, 0, 0, 0, 0};
+  memcpy(&hdr[0], KP_MAGIC, 8);
+  uint64_t h = 0xcbf29ce484222325ull;
+  bool ok = fwrite(hdr, 8, 8, f) == 8;
+  h = fnv1a(h, hdr, sizeof hdr);
+  const std::vector<uint64_t>* parts[] = {&kp->alpha_g1, &kp->beta_g1, &kp->beta_g2, &kp->delta_g1, &kp->delta_g2, &kp->A, &kp->B2, &kp->B1, &kp->H, &kp->L, &kp->ABC};
+  for (const auto* v : parts) {
+    ok = ok && fwrite(v->data(), 8, v->size(), f) == v->size();
+    h = fnv1a(h, v->data(), v->size() * 8);
+  }
+  ok = ok && fwrite(&h, 8, 1, f) == 1;
+  ok = (fclose(f) == 0) && ok;
+  return ok ? ZKHIP_OK : fail(ZKHIP_ERR_ARG, "short write on the keypair file");
+}
+
+int zkhip_keypair_read(const char* path, zkhip_keypair** out) {
+  if (!path || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(ZKHIP_ERR_ARG, "cannot open the keypair file");
+  uint64_t hdr[8];
+  if (fread(hdr, 8, 8, f) != 8 || memcmp(&hdr[0], KP_MAGIC, 8) != 0) { fclose(f); return fail(ZKHIP_ERR_ARG, "not a keypair file (bad magic)"); }
+  const uint64_t m = hdr[1], l = hdr[2], d = hdr[3];
+  if (m < l + 1 || d < 1 || (d & (d - 1)) || m > ((uint64_t)1 << 28) || d > ((uint64_t)1 << 28)) { fclose(f); return fail(ZKHIP_ERR_ARG, "keypair file: implausible sizes"); }
+  zkhip_keypair* kp = new zkhip_keypair();
+  kp->n_vars = m; kp->n_primary = l; kp->domain_size = d;
+  struct { std::vector<uint64_t>* v; size_t pts; } parts[] = {{&kp->alpha_g1, 1}, {&kp->beta_g1, 1}, {&kp->beta_g2, 1}, {&kp->delta_g1, 1}, {&kp->delta_g2, 1},
+                                                              {&kp->A, m}, {&kp->B2, m}, {&kp->B1, m}, {&kp->H, d - 1}, {&kp->L, m - l - 1}, {&kp->ABC, l + 1}};
+  uint64_t h = fnv1a(0xcbf29ce484222325ull, hdr, sizeof hdr), stored = 0;
+  bool ok = true;
+  for (auto& p : parts) {
+    p.v->resize(p.pts * 24);
+    ok = ok && fread(p.v->data(), 8, p.v->size(), f) == p.v->size();
+    if (!ok) break;
+    h = fnv1a(h, p.v->data(), p.v->size() * 8);
+  }
+  ok = ok && fread(&stored, 8, 1, f) == 1 && stored == h;
+  fclose(f);
+  if (!ok) { delete kp; return fail(ZKHIP_ERR_ARG, "keypair file truncated or corrupted (checksum)"); }
+  *out = kp;
+  return ZKHIP_OK;
+}
+
 void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 
 float zkhip_last_accumulate_ms(void) { return g.ps.last_accumulate_ms; }

@@ -25,7 +25,7 @@ EXPORTS = [
     "zkhip_aggregator_witness", "zkhip_aggregator_vk_hash", "zkhip_aggregator_num_proofs", "zkhip_aggregator_inputs_per_proof",
     "zkhip_prover_new", "zkhip_prover_prove", "zkhip_prover_timings", "zkhip_prover_free",
     "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
-    "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free",
+    "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
 ]
 
@@ -106,6 +106,8 @@ def load():
     lib.zkhip_last_accumulate_ms.restype = ctypes.c_float
     lib.zkhip_jac_to_affine.argtypes = [c_u64p, c_u64p]
     lib.zkhip_jac_add.argtypes = [c_u64p, c_u64p, c_u64p]
+    lib.zkhip_keypair_write.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    lib.zkhip_keypair_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
     lib.zkhip_prover_new.argtypes = [ctypes.c_void_p, ctypes.POINTER(R1csDesc), ctypes.POINTER(ctypes.c_void_p)]
     lib.zkhip_prover_prove.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
     lib.zkhip_prover_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
@@ -537,6 +539,19 @@ class Keypair:
         c = lambda a: _p(np.ascontiguousarray(a, dtype=np.uint64))
         _check(load().zkhip_groth16_setup(ctypes.byref(r1cs_desc), c(tau), c(alpha), c(beta), c(delta), ctypes.byref(h)))
         self.handle = h
+
+    def write(self, path):
+        """Mirror of wsnark::keypair_write_bytes (aggregator_server.cpp:88-94); the library's own container format."""
+        _check(load().zkhip_keypair_write(self.handle, str(path).encode()))
+
+    @classmethod
+    def read(cls, path):
+        """Mirror of wsnark::keypair_read_bytes (aggregator_server.cpp:77-86)."""
+        h = ctypes.c_void_p()
+        _check(load().zkhip_keypair_read(str(path).encode(), ctypes.byref(h)))
+        kp = cls.__new__(cls)
+        kp.handle = h
+        return kp
 
     def upload_crs(self):
         d = CrsDesc()
