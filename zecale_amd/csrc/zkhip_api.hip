@@ -225,12 +225,14 @@ int zkhip_bases_precompute(zkhip_bases* b, int c) {
   if (levels * b->len >= ((size_t)1 << 31)) return fail(ZKHIP_ERR_ARG, "table too large (levels * len must stay below 2^31)");
   AffPacked* tab = nullptr;
   uint8_t* tinf = nullptr;
-  API_HIP(hipMalloc(&tab, levels * b->len * sizeof(AffPacked)));
-  API_HIP(hipMalloc(&tinf, levels * b->len));
-  API_HIP(hipMemcpy(tab, b->d_pts, b->len * sizeof(AffPacked), hipMemcpyDeviceToDevice));
-  API_HIP(hipMemcpy(tinf, b->d_inf, b->len, hipMemcpyDeviceToDevice));
-  int rc = msm_table_build(tab, tinf, b->len, c, t_err, sizeof t_err);
-  if (rc != ZKHIP_OK) { (void)hipFree(tab); (void)hipFree(tinf); return rc; }
+  hipError_t e = hipMalloc(&tab, levels * b->len * sizeof(AffPacked));
+  if (e == hipSuccess) e = hipMalloc(&tinf, levels * b->len);
+  if (e == hipSuccess) e = hipMemcpy(tab, b->d_pts, b->len * sizeof(AffPacked), hipMemcpyDeviceToDevice);
+  if (e == hipSuccess) e = hipMemcpy(tinf, b->d_inf, b->len, hipMemcpyDeviceToDevice);
+  int rc = ZKHIP_OK;
+  if (e != hipSuccess) { snprintf(t_err, sizeof t_err, "window table allocation: %s", hipGetErrorString(e)); rc = ZKHIP_ERR_HIP; }
+  else rc = msm_table_build(tab, tinf, b->len, c, t_err, sizeof t_err);
+  if (rc != ZKHIP_OK) { if (tab) (void)hipFree(tab); if (tinf) (void)hipFree(tinf); return rc; }
   (void)hipFree(b->d_pts); (void)hipFree(b->d_inf);
   b->d_pts = tab; b->d_inf = tinf; b->table_c = c;
   return ZKHIP_OK;
@@ -432,12 +434,13 @@ int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) {
   memcpy(c->alpha_g1, d->alpha_g1, 192); memcpy(c->beta_g1, d->beta_g1, 192); memcpy(c->beta_g2, d->beta_g2, 192);
   memcpy(c->delta_g1, d->delta_g1, 192); memcpy(c->delta_g2, d->delta_g2, 192);
   int rc;
-  if ((rc = zkhip_bases_upload(d->a_query, d->n_vars, &c->A)) != ZKHIP_OK) return rc;
-  if ((rc = zkhip_bases_upload(d->b_g2_query, d->n_vars, &c->B2)) != ZKHIP_OK) return rc;
-  if ((rc = zkhip_bases_upload(d->b_g1_query, d->n_vars, &c->B1)) != ZKHIP_OK) return rc;
-  if ((rc = zkhip_bases_upload(d->h_query, d->domain_size - 1, &c->H)) != ZKHIP_OK) return rc;
-  if ((rc = zkhip_bases_upload(d->l_query, d->n_vars - d->n_primary - 1, &c->L)) != ZKHIP_OK) return rc;
-  if ((rc = crs_build_tables(c)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->a_query, d->n_vars, &c->A)) == ZKHIP_OK &&
+      (rc = zkhip_bases_upload(d->b_g2_query, d->n_vars, &c->B2)) == ZKHIP_OK &&
+      (rc = zkhip_bases_upload(d->b_g1_query, d->n_vars, &c->B1)) == ZKHIP_OK &&
+      (rc = zkhip_bases_upload(d->h_query, d->domain_size - 1, &c->H)) == ZKHIP_OK &&
+      (rc = zkhip_bases_upload(d->l_query, d->n_vars - d->n_primary - 1, &c->L)) == ZKHIP_OK)
+    rc = crs_build_tables(c);
+  if (rc != ZKHIP_OK) { zkhip_crs_free(c); return rc; }     // frees what was uploaded so far (null members are skipped)
   *out = c;
   return ZKHIP_OK;
 }
@@ -453,12 +456,13 @@ int zkhip_crs_upload_slice(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, s
   memcpy(c->alpha_g1, d->alpha_g1, 192); memcpy(c->beta_g1, d->beta_g1, 192); memcpy(c->beta_g2, d->beta_g2, 192);
   memcpy(c->delta_g1, d->delta_g1, 192); memcpy(c->delta_g2, d->delta_g2, 192);
   int rc;
-  if ((rc = zkhip_bases_upload(d->a_query + a_lo * 24, a_len, &c->A)) != ZKHIP_OK) return rc;
-  if ((rc = zkhip_bases_upload(d->b_g2_query + a_lo * 24, a_len, &c->B2)) != ZKHIP_OK) return rc;
-  if ((rc = zkhip_bases_upload(d->b_g1_query + a_lo * 24, a_len, &c->B1)) != ZKHIP_OK) return rc;
-  if ((rc = zkhip_bases_upload(d->h_query + h_lo * 24, h_len, &c->H)) != ZKHIP_OK) return rc;
-  if ((rc = zkhip_bases_upload(d->l_query + l_lo * 24, l_len, &c->L)) != ZKHIP_OK) return rc;
-  if ((rc = crs_build_tables(c)) != ZKHIP_OK) return rc;
+  if ((rc = zkhip_bases_upload(d->a_query + a_lo * 24, a_len, &c->A)) == ZKHIP_OK &&
+      (rc = zkhip_bases_upload(d->b_g2_query + a_lo * 24, a_len, &c->B2)) == ZKHIP_OK &&
+      (rc = zkhip_bases_upload(d->b_g1_query + a_lo * 24, a_len, &c->B1)) == ZKHIP_OK &&
+      (rc = zkhip_bases_upload(d->h_query + h_lo * 24, h_len, &c->H)) == ZKHIP_OK &&
+      (rc = zkhip_bases_upload(d->l_query + l_lo * 24, l_len, &c->L)) == ZKHIP_OK)
+    rc = crs_build_tables(c);
+  if (rc != ZKHIP_OK) { zkhip_crs_free(c); return rc; }
   *out = c;
   return ZKHIP_OK;
 }
