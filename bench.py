@@ -347,6 +347,16 @@ def main():
                          "fq_mul_frac": round(terms_in_kernel * digits * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4) if (timed and digits) else None,   # upper bound when some scalars are 0
                          "mixed_additions_per_term": digits},
         }
+        if args.workload == "msm" and not args.serial and timed and digits:
+            # the timed region streams two MSMs at a time, so its k_accumulate shares the chip with the reduction tail of the
+            # previous MSM; for the kernel on its own, two more MSMs one at a time (outside the timed region)
+            alone = []
+            for i in range(2):
+                bases.msm_dev(scal_dev[i % len(scal_dev)].data_ptr(), n, montgomery=False)
+                alone.append(zkhip.last_accumulate_ms())
+            ka = float(np.mean(alone))
+            out["roofline"]["kernel_ms_alone"] = round(ka, 3)
+            out["roofline"]["fq_mul_frac_alone"] = round(terms_in_kernel * digits * MULS_PER_MIXED_ADD / (ka * 1e-3) / FQ_MUL_PEAK_PER_S, 4)
         if "scaling_override" in extra:
             out["scaling"] = extra.pop("scaling_override")
             out["config"]["parallelism"] = "proving key partitioned x%d, RCCL all-gather of 5 x 288-byte partial sums per proof" % world
