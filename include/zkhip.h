@@ -173,6 +173,7 @@ typedef struct zkhip_prover zkhip_prover;
 int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prover** out);   /* crs must outlive the prover */
 int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r[6], const uint64_t s[6], uint64_t proof_affine[72]);
 int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]);   /* as zkhip_last_prove_timings, for p's last proof */
+float zkhip_prover_last_accumulate_ms(zkhip_prover* p);          /* as zkhip_last_accumulate_ms, for p's last proof */
 void zkhip_prover_free(zkhip_prover* p);
 
 /* replaces: wsnarkT::verify(primary_inputs, proof, vk) (libzecale/tests/aggregator/aggregator_dummy_test.cpp:61-62)

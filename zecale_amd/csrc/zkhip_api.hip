@@ -669,6 +669,12 @@ int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r_m[6]
   return finish_impl(c->alpha_g1, c->beta_g1, c->beta_g2, c->delta_g1, c->delta_g2, sums, r_m, s_m, proof_affine, &p->ps.ms[7]);
 }
 
+float zkhip_prover_last_accumulate_ms(zkhip_prover* p) {
+  if (!p) return 0.f;
+  std::lock_guard<std::mutex> lk(p->mu);
+  return p->ps.last_accumulate_ms;
+}
+
 int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]) {
   if (!p || !out_ms) return ZKHIP_ERR_ARG;
   std::lock_guard<std::mutex> lk(p->mu);

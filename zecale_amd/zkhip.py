@@ -23,7 +23,7 @@ EXPORTS = [
     "zkhip_bls12_377_groth16_verify", "zkhip_aggregator_new", "zkhip_aggregator_free", "zkhip_aggregator_num_constraints",
     "zkhip_aggregator_num_variables", "zkhip_aggregator_num_primary_inputs", "zkhip_aggregator_get_r1cs",
     "zkhip_aggregator_witness", "zkhip_aggregator_vk_hash", "zkhip_aggregator_num_proofs", "zkhip_aggregator_inputs_per_proof",
-    "zkhip_prover_new", "zkhip_prover_prove", "zkhip_prover_timings", "zkhip_prover_free",
+    "zkhip_prover_new", "zkhip_prover_prove", "zkhip_prover_timings", "zkhip_prover_free", "zkhip_prover_last_accumulate_ms",
     "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
@@ -112,6 +112,8 @@ def load():
     lib.zkhip_prover_prove.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
     lib.zkhip_prover_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.zkhip_prover_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_prover_last_accumulate_ms.argtypes = [ctypes.c_void_p]
+    lib.zkhip_prover_last_accumulate_ms.restype = ctypes.c_float
     lib.zkhip_aggregator_pipeline_new.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.zkhip_aggregator_pipeline_submit.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p, c_u64p, ctypes.POINTER(ctypes.c_uint64)]
     lib.zkhip_aggregator_pipeline_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint64, c_u64p, c_u64p]
@@ -255,6 +257,25 @@ def ntt(data, log_d, inverse=False, coset=False):
 
 def ntt_dev(dev_ptr, log_d, inverse=False, coset=False):
     _check(load().zkhip_ntt_dev(ctypes.c_void_p(dev_ptr), log_d, int(inverse), int(coset)))
+
+
+def make_r1cs_desc(A, B, C, n_vars, n_primary):
+    """zkhip_r1cs_desc over CSR triples (row_ptr u32[n+1], col u32[nnz], val u64[nnz, 6]).  Returns (desc, keep): `keep` holds
+    the arrays the descriptor points into and must stay alive while the descriptor is used (e.g. for Prover(crs, desc))."""
+    keep = []
+    d = R1csDesc()
+    d.n_constraints = len(A[0]) - 1
+    d.n_vars, d.n_primary = n_vars, n_primary
+    for name, (rp, col, val) in zip("abc", (A, B, C)):
+        rp = np.ascontiguousarray(rp, dtype=np.uint32)
+        col = np.ascontiguousarray(col, dtype=np.uint32)
+        val = np.ascontiguousarray(val, dtype=np.uint64).reshape(-1, 6)
+        assert len(rp) == d.n_constraints + 1 and len(col) == len(val) == int(rp[-1])
+        keep += [rp, col, val]
+        setattr(d, name + "_row_ptr", rp.ctypes.data)
+        setattr(d, name + "_col", col.ctypes.data if len(col) else None)
+        setattr(d, name + "_val", val.ctypes.data if len(val) else None)
+    return d, keep
 
 
 class R1cs:
@@ -488,6 +509,9 @@ class Prover:
         out = np.zeros(72, dtype=np.uint64)
         _check(load().zkhip_prover_prove(self.handle, _p(z), _p(r), _p(s), _p(out)))
         return out
+
+    def last_accumulate_ms(self):
+        return float(load().zkhip_prover_last_accumulate_ms(self.handle))
 
     def timings(self):
         t = (ctypes.c_double * 8)()
