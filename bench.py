@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one MSM / one proof in flight (per-phase timings) instead of the streaming forms")
     ap.add_argument("--gpu-slots", type=int, default=4, help="aggregator pipeline: proofs in flight on the GPU")
     ap.add_argument("--witness-workers", type=int, default=6, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
-    ap.add_argument("--cpu-sample-log", type=int, default=17)
+    ap.add_argument("--cpu-sample-log", type=int, default=20)
     args = ap.parse_args()
 
     # the aggregator pipeline keeps several proofs in flight, each on its own streams: give the HIP runtime more than its
@@ -389,24 +389,37 @@ def main():
         extra.pop("accumulate_ms", None)
         out.update(extra)
         if not args.no_cpu_baseline:
+            # host cores this process may actually use: the GPU box caps a one-GPU job with a cgroup CPU quota (16 of its 256 hardware
+            # threads); OpenMP would otherwise start one thread per hardware thread and split the MSM into that many tiny chunks
+            quota = None
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                quota = None if q == "max" else max(1, int(int(q) / int(per)))
+            except Exception:
+                pass
+            avail = len(os.sched_getaffinity(0))
             from oracle import oracle as O
             O.load()
+            O.set_threads(min(avail, quota) if quota else avail)
             ns = 1 << min(args.cpu_sample_log, args.log_n)
             bs = gen_bases(0x5EED, ns).cpu().numpy().view(np.uint64)
             ss_ = random_fr_canonical(0xABC0, ns)
             threads = O.max_threads()
-            t = time.time()
+            t, ct = time.time(), os.times()
             cpu_out = O.msm(bs, ss_, chunks=threads, with_mixed=True)   # canonical words used as Montgomery residues on both sides
             cpu_dt = time.time() - t
+            ct2 = os.times()
+            busy = ((ct2.user + ct2.system) - (ct.user + ct.system)) / cpu_dt    # cores actually kept busy (a container may cap them)
             b2 = zkhip.Bases.upload(bs)
             parity = bool((zkhip.jac_to_affine(b2.msm(ss_, montgomery=True)) == O.jac_to_affine(cpu_out)).all())
             b2.free()
             cpu_val = ns / cpu_dt / 1e6
             out["cpu_baseline"] = {
                 "value": round(cpu_val if args.workload == "msm" else cpu_val * 1e6 / (5.0 * n), 6), "unit": unit, "cores": threads, "kind": "port",
-                "sample": "one 2^%d-term G1 MSM, CPU restatement of libff multi_exp (BDLO12, %d OpenMP chunks, -O2), %.1f s; "
+                "sample": "one 2^%d-term G1 MSM, CPU restatement of libff multi_exp (BDLO12, %d OpenMP chunks, -O2), %.1f s wall, "
+                          "%.1f cores busy on average (process CPU time / wall); "
                           "not libsnark itself (its sources are absent from the reference tree)%s"
-                          % (ns.bit_length() - 1, threads, cpu_dt,
+                          % (ns.bit_length() - 1, threads, cpu_dt, busy,
                              "" if args.workload == "msm" else "; proofs/s extrapolated as 5 MSMs of 2^%d terms per proof" % args.log_n),
                 "parity_with_gpu_on_sample": parity}
         print(json.dumps(out))

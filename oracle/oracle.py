@@ -90,6 +90,10 @@ def point_progression(p0_aff, d_aff, n):
     return out
 
 
+def set_threads(n):
+    load().oracle_set_threads(int(n))
+
+
 def max_threads():
     return int(load().oracle_max_threads())
 
