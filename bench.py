@@ -81,14 +81,14 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="override the MSM window c (tuning; 0 = automatic, at most 18)")
     ap.add_argument("--no-batch-msms", action="store_true", help="one launch sequence per MSM instead of one per proof")
     ap.add_argument("--serial", action="store_true", help="one MSM / one proof in flight (per-phase timings) instead of the streaming forms")
-    ap.add_argument("--gpu-slots", type=int, default=4, help="aggregator pipeline: proofs in flight on the GPU")
-    ap.add_argument("--witness-workers", type=int, default=6, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
+    ap.add_argument("--gpu-slots", type=int, default=6, help="aggregator pipeline: proofs in flight on the GPU")
+    ap.add_argument("--witness-workers", type=int, default=8, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
     ap.add_argument("--cpu-sample-log", type=int, default=20)
     args = ap.parse_args()
 
     # the aggregator pipeline keeps several proofs in flight, each on its own streams: give the HIP runtime more than its
     # default of 4 hardware queues (read once, when the runtime initialises)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -304,6 +304,7 @@ def main():
     drain()
     barrier()
     kernel_ms, phase = [], []
+    cpu0 = os.times()
     t0 = time.time()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -313,6 +314,8 @@ def main():
     drain()
     barrier()
     dt = time.time() - t0
+    cpu1 = os.times()
+    extra["host_cores_busy"] = round(((cpu1.user + cpu1.system) - (cpu0.user + cpu0.system)) / dt, 2)   # this rank's process, timed region
     if world > 1 or force_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

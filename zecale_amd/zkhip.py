@@ -60,7 +60,7 @@ def load():
                          "(the HIP library is the only compute path; there is no CPU fallback)")
     # several prover instances run on their own streams: more hardware queues than the runtime's default 4
     # (only effective if the HIP runtime has not been initialised yet in this process)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     lib = ctypes.CDLL(LIB_PATH)
     c_u64p = ctypes.POINTER(ctypes.c_uint64)
     lib.zkhip_init.argtypes = [ctypes.c_int]
