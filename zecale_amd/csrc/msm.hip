@@ -629,6 +629,17 @@ static void window_layout(int c, uint16_t* off, uint8_t* bits) {
   }
 }
 
+// target number of entries per lane and machine fill (tuning knob; ZKHIP_SLICE_TARGET overrides for experiments)
+static size_t slice_target() {
+  static size_t v = 0;
+  if (!v) {
+    const char* e = getenv("ZKHIP_SLICE_TARGET");
+    v = e ? (size_t)atoi(e) : 48;
+    if (v < 8 || v > 4096) v = 48;
+  }
+  return v;
+}
+
 int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   memset(ctx, 0, sizeof *ctx);
   if (K < 1 || K > MSM_MAX_JOBS || (!merged && K != 1)) return ZKHIP_ERR_ARG;
@@ -664,7 +675,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   // machine fills (256 CUs x 8 waves x 64 lanes at two waves per SIMD)
   {
     const size_t lanes = 131072, m_max = (size_t)K * ctx->Wd * max_n;
-    size_t fills = (m_max + lanes * 48 - 1) / (lanes * 48);     // ~48 entries per lane and fill
+    size_t fills = (m_max + lanes * slice_target() - 1) / (lanes * slice_target());     // ~48 entries per lane and fill
     if (fills < 1) fills = 1;
     size_t S = (m_max + lanes * fills - 1) / (lanes * fills);
     if (S < 16) S = 16;
@@ -774,7 +785,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   uint32_t S_run, T_run;
   {
     const size_t lanes = 131072, m = (size_t)Wd * n_tot;
-    size_t fills = (m + lanes * 48 - 1) / (lanes * 48);
+    size_t fills = (m + lanes * slice_target() - 1) / (lanes * slice_target());
     if (fills < 1) fills = 1;
     size_t S = (m + lanes * fills - 1) / (lanes * fills);
     if (S < 16) S = 16;
