@@ -119,3 +119,18 @@ def test_keypair_file_round_trip_proves_the_same(zk, tmp_path):
     p1, p2 = zk.groth16_prove(crs, r1, z, r, s), zk.groth16_prove(crs2, r1, z, r, s)
     assert (p1 == p2).all() and zk.groth16_verify(vk2, z[1:1 + agg.num_primary_inputs()], p2)
     crs.free(); crs2.free(); r1.free(); kp.free(); kp2.free(); agg.free()
+
+
+def test_pipeline_can_be_freed_with_batches_outstanding(zk):
+    """Shutting the streaming prover down while batches are queued or in flight neither hangs nor crashes (a server stops this way)."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    crs = kp.upload_crs()
+    pipe = zk.AggregatorPipeline(agg, crs, gpu_slots=2, witness_workers=2)
+    (pa, ia), (pb, ib) = proofs[0], proofs[1]
+    npr = np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)])
+    nin = np.array([fr_limbs(ia[0]), fr_limbs(ib[0])])
+    tickets = [pipe.submit(nvk_l, npr, nin, fr_limbs(3 + i), fr_limbs(5 + i)) for i in range(6)]
+    prim, proof = pipe.wait(tickets[0])
+    assert zk.groth16_verify(kp.vk(), prim, proof)
+    pipe.free()                      # five batches still somewhere between the queues and the GPU
+    crs.free(); kp.free(); agg.free()
