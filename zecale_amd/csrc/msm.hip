@@ -23,6 +23,10 @@
 #include "host_field.hpp"
 #include "msm.h"
 
+#ifndef ZK_ACC_REGY
+#define ZK_ACC_REGY 1
+#endif
+
 namespace zkhip {
 
 // ------------------------------------------------------------------------------------------
@@ -251,11 +255,19 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   uint32_t* xs = lds_x + threadIdx.x;
   XyzzRef acc = make_ref(slots, stride, 0);
   bool inf = true;
+#if ZK_ACC_REGY
+  Fq ty = fp_zero<FqParams>();     // Y of the running accumulator, carried in registers across the additions of a run
+#endif
   uint32_t e_next = entries[pos0];
   for (uint32_t k = pos0; k < pos1; k++) {
     if (k == bend) {
       if (!first) {
-        if (!inf) { mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz)); }   // close the finished run
+        if (!inf) {   // close the finished run
+          mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));
+#if ZK_ACC_REGY
+          mem_st(acc, CY, ty);
+#endif
+        }
         b++;
         while (offsets[b] + counts[b] <= k) b++;     // next non-empty bucket
       }
@@ -273,15 +285,28 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
     if (inf) {
 #pragma unroll
       for (int i = 0; i < 24; i++) xs[i * ZK_LDS_STRIDE] = p->x[i];       // packed words straight into LDS
+#if ZK_ACC_REGY
+      ty = aff_ld_y(p, neg);
+#else
       mem_st(acc, CY, aff_ld_y(p, neg));
+#endif
       lds_st(zz, fp_one<FqParams>());
       lds_st(zzz, fp_one<FqParams>());
       inf = false;
       continue;
     }
+#if ZK_ACC_REGY
+    if (madd_lds_regy(acc, xs, zz, zzz, ty, p, neg)) inf = fp_is_zero_2p(lds_ld(zz));   // same-x path may have cancelled to infinity
+#else
     if (madd_mem_lds(acc, xs, zz, zzz, p, neg)) inf = fp_is_zero_2p(lds_ld(zz));   // same-x path may have cancelled to infinity
+#endif
   }
-  if (!inf) { mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz)); }
+  if (!inf) {
+    mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));
+#if ZK_ACC_REGY
+    mem_st(acc, CY, ty);
+#endif
+  }
   // a run that cancelled to infinity leaves ZZ = 0 in its slot: madd_same_x wrote the zeros, or the slot
   // was never written (zero-filled array)
 }
