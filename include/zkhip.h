@@ -220,8 +220,8 @@ int zkhip_aggregator_vk_hash(const uint64_t* nested_vk, size_t inputs_per_proof,
  * GenerateAggregatedTransaction loop, aggregator_server.cpp:300-420, handles one batch at a time on the CPU):
  * `witness_workers` host threads generate witnesses (zkhip_aggregator_witness) while `gpu_slots` prover instances
  * keep that many proofs in flight on the GPU; the host tail of one proof overlaps the device work of the next.
- * submit copies its inputs and returns a ticket (it blocks only when 4 x (gpu_slots + witness_workers) batches are
- * outstanding); wait blocks until that batch is done and returns the extended proof: primary inputs
+ * submit copies its inputs and returns a ticket (it blocks only while 4 x (gpu_slots + witness_workers) batches are
+ * still unproved; finished batches wait for their collector and never block a submitter); wait blocks until that batch is done and returns the extended proof: primary inputs
  * (num_primary_inputs x 6 limbs: vk hash, packed results, nested inputs) and the proof (a | b | c, 72 limbs).
  * Every result is bit-identical to zkhip_aggregator_witness + zkhip_groth16_prove on the same inputs, r and s. */
 typedef struct zkhip_pipeline zkhip_pipeline;

@@ -134,3 +134,21 @@ def test_pipeline_can_be_freed_with_batches_outstanding(zk):
     assert zk.groth16_verify(kp.vk(), prim, proof)
     pipe.free()                      # five batches still somewhere between the queues and the GPU
     crs.free(); kp.free(); agg.free()
+
+
+def test_pipeline_submitter_is_not_blocked_by_uncollected_results(zk):
+    """Back-pressure counts unproved batches only: one thread can submit more batches than the pipeline keeps in flight
+    (4 x (slots + workers) = 8 here) before collecting any."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    crs = kp.upload_crs()
+    pipe = zk.AggregatorPipeline(agg, crs, gpu_slots=1, witness_workers=1)
+    (pa, ia), (pb, ib) = proofs[2], proofs[4]
+    npr = np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)])
+    nin = np.array([fr_limbs(ia[0]), fr_limbs(ib[0])])
+    tickets = [pipe.submit(nvk_l, npr, nin, fr_limbs(30 + i), fr_limbs(50 + i)) for i in range(12)]
+    vk = kp.vk()
+    results = [pipe.wait(t) for t in tickets]
+    assert all(zk.groth16_verify(vk, prim, proof) for prim, proof in results)
+    assert len({bytes(proof) for _, proof in results}) == 12          # different (r, s): different proofs
+    pipe.free()
+    crs.free(); kp.free(); agg.free()

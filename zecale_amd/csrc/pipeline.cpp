@@ -40,7 +40,7 @@ struct zkhip_pipeline {
   std::condition_variable cv_wit, cv_gpu, cv_done, cv_room;
   std::deque<std::shared_ptr<Job>> q_wit, q_gpu;
   std::map<uint64_t, std::shared_ptr<Job>> jobs;   // submitted and not yet collected
-  size_t max_outstanding = 0;
+  size_t max_unfinished = 0, unfinished = 0;     // back-pressure counts batches not yet proved (finished ones wait for their collector)
   uint64_t next_id = 1;
   bool stop = false;
 };
@@ -62,7 +62,9 @@ void witness_loop(zkhip_pipeline* p) {
     std::lock_guard<std::mutex> lk(p->mu);
     if (rc != ZKHIP_OK) {
       j->rc = rc; j->done = true;
+      p->unfinished--;
       p->cv_done.notify_all();
+      p->cv_room.notify_one();
     } else {
       p->q_gpu.push_back(j);
       p->cv_gpu.notify_one();
@@ -83,7 +85,11 @@ void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
     int rc = zkhip_prover_prove(pr, j->z.data(), j->r, j->s, j->proof);
     std::lock_guard<std::mutex> lk(p->mu);
     j->rc = rc; j->done = true;
+    std::vector<uint64_t> prim(j->z.begin() + 6, j->z.begin() + 6 + p->n_primary * 6);   // keep the primary inputs, drop the 2.4 MB witness
+    j->z.swap(prim);
+    p->unfinished--;
     p->cv_done.notify_all();
+    p->cv_room.notify_one();
   }
 }
 
@@ -101,7 +107,7 @@ int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int
   p->n_vars = desc.n_vars; p->n_primary = desc.n_primary;
   const size_t np = zkhip_aggregator_num_proofs(a), k = zkhip_aggregator_inputs_per_proof(a);
   p->vk_words = 60 + 12 * (k + 1); p->proofs_words = 48 * np; p->inputs_words = 6 * k * np;
-  p->max_outstanding = (size_t)4 * (size_t)(gpu_slots + witness_workers);
+  p->max_unfinished = (size_t)4 * (size_t)(gpu_slots + witness_workers);
   for (int i = 0; i < gpu_slots; i++) {
     zkhip_prover* pr = nullptr;
     rc = zkhip_prover_new(crs, &desc, &pr);
@@ -139,8 +145,9 @@ int zkhip_aggregator_pipeline_submit(zkhip_pipeline* p, const uint64_t* nested_v
   j->inputs.assign(nested_inputs, nested_inputs + p->inputs_words);
   memcpy(j->r, r, 48); memcpy(j->s, s, 48);
   std::unique_lock<std::mutex> lk(p->mu);
-  p->cv_room.wait(lk, [&] { return p->stop || p->jobs.size() < p->max_outstanding; });   // back-pressure on the caller
-  if (p->stop) return ZKHIP_ERR_STATE;
+  p->cv_room.wait(lk, [&] { return p->stop || p->unfinished < p->max_unfinished; });   // back-pressure on the caller
+  p->unfinished++;
+  if (p->stop) { p->unfinished--; return ZKHIP_ERR_STATE; }
   j->id = p->next_id++;
   p->jobs[j->id] = j;
   p->q_wit.push_back(j);
@@ -158,10 +165,9 @@ int zkhip_aggregator_pipeline_wait(zkhip_pipeline* p, uint64_t ticket, uint64_t*
   p->cv_done.wait(lk, [&] { return p->stop || j->done; });
   if (!j->done) return ZKHIP_ERR_STATE;
   p->jobs.erase(ticket);
-  p->cv_room.notify_one();
   lk.unlock();
   if (j->rc != ZKHIP_OK) return j->rc;
-  if (primary_inputs) memcpy(primary_inputs, j->z.data() + 6, p->n_primary * 48);   // z[0] is the constant ONE
+  if (primary_inputs) memcpy(primary_inputs, j->z.data(), p->n_primary * 48);   // (the prover thread kept z[1 .. n_primary])
   memcpy(proof_affine, j->proof, sizeof j->proof);
   return ZKHIP_OK;
 }
