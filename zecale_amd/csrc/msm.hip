@@ -4,14 +4,17 @@
 //
 // Pipeline (all kernels hand-written for wave64; one lane owns one field element, see fp29.cuh):
 //   k_bases_to_dev      ABI affine points -> packed device-form points (once per base set)
+//   k_table_build       optional, once per resident base set: 2^(off_w) P_i for every window position (window table)
 //   k_scalar_digits     Montgomery scalars -> canonical -> signed c-bit digits + bucket histogram
 //   k_scan_*            exclusive prefix sum of the histogram (bucket offsets)
 //   k_scatter           counting-sort scatter: bucket-ordered list of (point index, sign)
-//   k_accumulate        one lane per bucket: XYZZ mixed additions of its points   <-- dominant
-//   k_seg / k_sum       bucket reduction  sum_j (j+1) B_j  by recursive L-ary running sums
-//   k_window_combine    per window: R0 + L (R1 + L (R2 + ...))
-// The last step, sum_w 2^(c w) W_w (about 380 serial doublings of ONE point), runs on the host:
-// a serial chain has no parallelism for a GPU lane (one lane needs ~5 us per Fq multiplication).
+//   k_accumulate        one lane per fixed-size SLICE of the sorted list: XYZZ mixed additions   <-- dominant
+//   k_fixup_round/_fixup  stitch the buckets that slice boundaries cut
+//   k_sum / k_seg       bucket reduction  sum_j (j+1) B_j : two-level split of the bucket index, then L-ary running sums
+//   k_window_combine / k_hilo_combine   per bucket window: Horner over the levels, R * hi + lo
+// Plain base sets: one bucket window per digit position, and the last step, sum_w 2^(off_w) W_w (about 380 serial
+// doublings of ONE point), runs on the host.  Table-backed base sets: ONE bucket window for all digit positions (nothing
+// left to combine), and up to five MSMs share one launch sequence with a bucket window each (msm_launch_multi).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
