@@ -389,6 +389,8 @@ def main():
         if "scaling_override" in extra:
             out["scaling"] = extra.pop("scaling_override")
             out["config"]["parallelism"] = "proving key partitioned x%d, RCCL all-gather of 5 x 288-byte partial sums per proof" % world
+        if args.workload == "aggregator":
+            out["config"]["parallelism"] = "replicas x%d: one streaming prover per GPU, independent batches, no collective" % world
         extra.pop("accumulate_ms", None)
         out.update(extra)
         if not args.no_cpu_baseline:
