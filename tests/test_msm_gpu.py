@@ -241,3 +241,24 @@ def test_submit_collect_two_in_flight(zk, oracle_lib):
     for d in dev:
         d.free()
     b.free()
+
+
+def test_table_2_22_closed_form(zk, oracle_lib):
+    """BASELINE config 4 size on one GPU (2^22 terms, window table with c = 21): sum s_i (k_i G) = (sum s_i k_i mod r) G
+    against ONE oracle scalar multiplication - the size-independent check at the largest configured size."""
+    O = oracle_lib
+    n = 1 << 22
+    g = aff_limbs(R.G1_GEN)
+    ks = random_fr_canonical(81, n)
+    bases = zk.fixed_base_mul(g, ks, montgomery=False)
+    b = zk.Bases.upload(bases).precompute()
+    del bases
+    assert b.table_window == 21
+    s = random_fr_canonical(82, n)
+    to_int = lambda a: [int(x[0]) | int(x[1]) << 64 | int(x[2]) << 128 | int(x[3]) << 192 | int(x[4]) << 256 | int(x[5]) << 320
+                        for x in a.tolist()]
+    dot = sum(a * k for a, k in zip(to_int(s), to_int(ks))) % R.R_MOD
+    got = zk.jac_to_affine(b.msm(s, montgomery=False))
+    exp = O.jac_to_affine(O.scalar_mul(g, np.array(R.int_to_limbs(R.to_mont(dot, R.R_MOD, 6), 6), dtype=np.uint64)))
+    assert (got == exp).all()
+    b.free()
