@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--gpu-slots", type=int, default=6, help="aggregator pipeline: proofs in flight on the GPU")
     ap.add_argument("--witness-workers", type=int, default=8, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
     ap.add_argument("--cpu-sample-log", type=int, default=20)
+    ap.add_argument("--no-secondary", action="store_true", help="msm workload: skip the wrapping-proofs/s measurement after the timed region")
     args = ap.parse_args()
 
     # the aggregator pipeline keeps several proofs in flight, each on its own streams: give the HIP runtime more than its
@@ -386,6 +387,8 @@ def main():
             ka = float(np.mean(alone))
             out["roofline"]["kernel_ms_alone"] = round(ka, 3)
             out["roofline"]["fq_mul_frac_alone"] = round(terms_in_kernel * digits * MULS_PER_MIXED_ADD / (ka * 1e-3) / FQ_MUL_PEAK_PER_S, 4)
+        if args.workload == "msm" and world == 1 and not force_dist and not args.no_secondary:
+            out["wrapping_prover"] = wrapping_prover_secondary(zkhip, args)
         if "scaling_override" in extra:
             out["scaling"] = extra.pop("scaling_override")
             out["config"]["parallelism"] = "proving key partitioned x%d, RCCL all-gather of 5 x 288-byte partial sums per proof" % world
@@ -430,6 +433,48 @@ def main():
         print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def wrapping_prover_secondary(zkhip, args, steps=60, warmup=8):
+    """The other half of BASELINE.json's metric, measured in the same run after the MSM's timed region (N = 1 only): wrapping
+    proofs/s of the real batch-2 aggregator circuit through the streaming prover, witness generation included, nothing cached.
+    The same loop as `--workload aggregator`; the last proof is verified (host pairing check) before the number is reported."""
+    from tests.test_aggregator_host import nested_proof_limbs, nested_vk_limbs
+    from tests.test_oracle_pins import load_nested_fixtures
+    from tests.helpers import fr_limbs
+    agg = zkhip.AggregatorCircuit(2, 1)
+    desc = zkhip.r1cs_desc_from_aggregator(agg)
+    kp = zkhip.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
+    crs = kp.upload_crs()
+    nvk, proofs = load_nested_fixtures()
+    nvk_l = nested_vk_limbs(nvk)
+    npr = np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])])
+    nin = np.array([fr_limbs(proofs[0][1][0]), fr_limbs(proofs[1][1][0])])
+    rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
+    pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers)
+    depth = args.gpu_slots + args.witness_workers + 2
+
+    def run(k):
+        tickets, last = [], None
+        for _ in range(k):
+            tickets.append(pipe.submit(nvk_l, npr, nin, rr, ss))
+            if len(tickets) > depth:
+                last = pipe.wait(tickets.pop(0))
+        while tickets:
+            last = pipe.wait(tickets.pop(0))
+        return last
+    run(warmup)
+    t0 = time.time()
+    prim, proof = run(steps)
+    dt = time.time() - t0
+    ok = bool(zkhip.groth16_verify(kp.vk(), prim, proof))
+    out = {"metric": "wrapping proofs/sec (batch-2 BLS12_377 -> BW6_761 aggregation, %d constraints), same run, after the timed region"
+                     % agg.num_constraints,
+           "value": round(steps / dt, 3), "unit": "proofs/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+           "last_proof_verifies": ok, "gpu_slots": args.gpu_slots, "witness_workers": args.witness_workers,
+           "includes": "host witness generation + QAP + 5 MSMs + host tail per proof, reference dummy_app fixtures, nothing cached"}
+    pipe.free(); crs.free(); kp.free(); agg.free()
+    return out
 
 
 def tw_batched(extra, args):
