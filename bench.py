@@ -184,17 +184,11 @@ def main():
         units_per_step = n * world
     elif args.workload == "aggregator":
         # the real wrapping circuit on the committed nested fixtures (reference testdata/dummy_app: vk.json, extproof1/2.json)
-        from tests.test_aggregator_host import nested_proof_limbs, nested_vk_limbs
-        from tests.test_oracle_pins import load_nested_fixtures
-        from tests.helpers import fr_limbs
+        nvk_l, npr, nin, trapdoor = aggregator_inputs()
         agg = zkhip.AggregatorCircuit(2, 1)
         desc = zkhip.r1cs_desc_from_aggregator(agg)
-        kp = zkhip.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
+        kp = zkhip.Keypair(desc, *trapdoor)
         crs, r1 = kp.upload_crs(), zkhip.r1cs_from_desc(desc)
-        nvk, proofs = load_nested_fixtures()
-        nvk_l = nested_vk_limbs(nvk)
-        npr = np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])])
-        nin = np.array([fr_limbs(proofs[0][1][0]), fr_limbs(proofs[1][1][0])])
         rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
         wit_ms = []
         if args.serial:
@@ -435,21 +429,30 @@ def main():
         dist.destroy_process_group()
 
 
+def aggregator_inputs():
+    """Nested key and two nested proofs from the reference's data fixtures (tests/golden/dummy_app = testdata/dummy_app: vk.json,
+    extproof1.json, extproof2.json), decoded by the package's own JSON codec; toxic waste and (r, s) of the synthetic wrapping key."""
+    from zecale_amd import encoding as E
+    gold = os.path.join(ROOT, "tests", "golden", "dummy_app")
+    load = lambda name: json.load(open(os.path.join(gold, name)))
+    nvk_l = E.nested_verification_key_from_json(load("vk.json"))
+    txs = [E.nested_transaction_from_json(load("extproof%d.json" % k)) for k in (1, 2)]
+    npr = np.concatenate([t[1] for t in txs])
+    nin = np.concatenate([t[2] for t in txs])
+    fr = lambda x: np.array(E.fr_from_json(hex(x)), dtype=np.uint64)
+    trapdoor = [fr(0x1234567), fr(0x2345678), fr(0x3456789), fr(0x456789a)]
+    return nvk_l, npr, nin, trapdoor
+
+
 def wrapping_prover_secondary(zkhip, args, steps=60, warmup=8):
     """The other half of BASELINE.json's metric, measured in the same run after the MSM's timed region (N = 1 only): wrapping
     proofs/s of the real batch-2 aggregator circuit through the streaming prover, witness generation included, nothing cached.
     The same loop as `--workload aggregator`; the last proof is verified (host pairing check) before the number is reported."""
-    from tests.test_aggregator_host import nested_proof_limbs, nested_vk_limbs
-    from tests.test_oracle_pins import load_nested_fixtures
-    from tests.helpers import fr_limbs
+    nvk_l, npr, nin, trapdoor = aggregator_inputs()
     agg = zkhip.AggregatorCircuit(2, 1)
     desc = zkhip.r1cs_desc_from_aggregator(agg)
-    kp = zkhip.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
+    kp = zkhip.Keypair(desc, *trapdoor)
     crs = kp.upload_crs()
-    nvk, proofs = load_nested_fixtures()
-    nvk_l = nested_vk_limbs(nvk)
-    npr = np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])])
-    nin = np.array([fr_limbs(proofs[0][1][0]), fr_limbs(proofs[1][1][0])])
     rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
     pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers)
     depth = args.gpu_slots + args.witness_workers + 2
