@@ -151,6 +151,9 @@ def main():
             # does not leave for milliseconds at a time.
             inflight, exchanging = [], []
             distributed = world > 1 or force_dist
+            for slot in (0, 1):       # set-up: allocate both slots' work space once (like any buffer allocation, not part of a step)
+                bases.msm_submit(scal_dev[0].data_ptr(), n, slot=slot, montgomery=False)
+                zkhip.msm_collect(slot)
 
             def settle(keep):
                 out = None
@@ -214,6 +217,8 @@ def main():
             # the rest, so exactly `steps` wrapping proofs are produced between the two barriers.
             pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers)
             tickets, depth = [], args.gpu_slots + args.witness_workers + 2
+            for t_ in [pipe.submit(nvk_l, npr, nin, rr, ss) for _ in range(2 * args.gpu_slots)]:   # set-up: every slot allocates its work space
+                pipe.wait(t_)
 
             def step(i):
                 tickets.append(pipe.submit(nvk_l, npr, nin, rr, ss))
@@ -272,6 +277,8 @@ def main():
             from concurrent.futures import ThreadPoolExecutor
             desc, keep_csr = zkhip.make_r1cs_desc(*csr, m, l)
             provers = [zkhip.Prover(crs, desc) for _ in range(2)]
+            for p_ in provers:          # set-up: every instance allocates its work space on its first proof
+                p_.prove(z, rr, ss)
             pool2 = ThreadPoolExecutor(max_workers=2)
             futs = []
 
