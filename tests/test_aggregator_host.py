@@ -83,3 +83,26 @@ def test_vk_hash_differs_between_keys():
     nvk2 = dict(nvk); nvk2["alpha"] = nvk["ABC"][0]
     h2 = zkhip.aggregator_vk_hash(nested_vk_limbs(nvk2), 1)
     assert fr_int(h1) != 0 and fr_int(h2) != 0 and fr_int(h1) != fr_int(h2)
+
+
+@pytest.mark.parametrize("num_proofs", [1, 3])
+def test_other_batch_sizes(oracle_lib, num_proofs):
+    """NumProofs is a template parameter of the reference (aggregator_circuit.hpp:32-37; the server fixes it at 2): batches of 1 and 3
+    nested proofs give 1 + 1 + NumProofs primary inputs, a satisfying witness, and result bits packed LSB-first (the last
+    proof of the batch of 3 gets a bumped input: bits {1,1,0} = 3)."""
+    from zecale_amd import zkhip
+    c = zkhip.AggregatorCircuit(num_proofs, 1)
+    assert c.num_primary_inputs() == 2 + num_proofs
+    nvk, proofs = load_nested_fixtures()
+    vk = nested_vk_limbs(nvk)
+    chosen = [proofs[k] for k in range(num_proofs)]
+    xs = [inp[0] for _, inp in chosen]
+    if num_proofs == 3:
+        xs[2] += 1
+    z = c.witness(vk, np.concatenate([nested_proof_limbs(p) for p, _ in chosen]), np.array([fr_limbs(x) for x in xs]))
+    A, B, C = c.get_constraint_system()
+    assert oracle_lib.r1cs_first_unsatisfied(A, B, C, z) == -1
+    assert (z[1] == zkhip.aggregator_vk_hash(vk, 1)).all()
+    assert fr_int(z[2]) == (1 if num_proofs == 1 else 3)
+    assert [fr_int(z[3 + k]) for k in range(num_proofs)] == xs
+    c.free()
