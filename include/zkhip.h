@@ -166,7 +166,7 @@ int zkhip_last_prove_timings(double out_ms[8]);
 
 /* Prover instances.  The entry points above share one set of device work space and are serialised by the library;
  * a zkhip_prover owns its streams, MSM work space and QAP buffers, so several host threads (one instance each) keep
- * several proofs in flight on one GPU.  At the wrapping circuit's size (51k constraints) one proof cannot fill the
+ * several proofs in flight on one GPU.  At the wrapping circuit's size (50k constraints) one proof cannot fill the
  * chip: the phases after the bucket accumulation are chains of short launches.  Same results as zkhip_groth16_prove.
  * replaces: one wsnarkT::generate_proof call (aggregator_circuit.tcc:168) per instance and call. */
 typedef struct zkhip_prover zkhip_prover;

@@ -106,3 +106,27 @@ def test_other_batch_sizes(oracle_lib, num_proofs):
     assert fr_int(z[2]) == (1 if num_proofs == 1 else 3)
     assert [fr_int(z[3 + k]) for k in range(num_proofs)] == xs
     c.free()
+
+
+def test_nine_inputs_per_nested_proof(oracle_lib):
+    """A Zeth joinsplit proof has 9 primary inputs (BASELINE configs[4]).  No such nested proofs are in the tree, so the nested
+    key is padded with further G1 points from the fixtures and the inputs are arbitrary: the nested proofs are then INVALID, which
+    the circuit must accept with result bits 0 (aggregator_circuit.hpp:51-54) - the witness satisfies every constraint."""
+    from zecale_amd import zkhip
+    k = 9
+    c = zkhip.AggregatorCircuit(2, k)
+    assert c.num_primary_inputs() == 2 + 2 * k
+    nvk, proofs = load_nested_fixtures()
+    nvk9 = dict(nvk)
+    nvk9["ABC"] = list(nvk["ABC"]) + [proofs[i][0]["a"] for i in range(6)] + [proofs[0][0]["c"], proofs[1][0]["c"]]
+    assert len(nvk9["ABC"]) == k + 1
+    vk = nested_vk_limbs(nvk9)
+    xs = [[1000 * p + j for j in range(k)] for p in range(2)]
+    z = c.witness(vk, np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])]),
+                  np.array([fr_limbs(x) for row in xs for x in row]))
+    A, B, C = c.get_constraint_system()
+    assert oracle_lib.r1cs_first_unsatisfied(A, B, C, z) == -1
+    assert (z[1] == zkhip.aggregator_vk_hash(vk, k)).all()
+    assert fr_int(z[2]) == 0                                  # both nested proofs rejected
+    assert [fr_int(z[3 + i]) for i in range(2 * k)] == xs[0] + xs[1]
+    c.free()

@@ -221,7 +221,7 @@ void to_csr(const std::vector<LC>& M, std::vector<uint32_t>& rp, std::vector<uin
 extern "C" {
 
 int zkhip_aggregator_new(size_t num_proofs, size_t inputs_per_proof, zkhip_aggregator** out) {
-  if (!out || num_proofs == 0 || num_proofs > 16 || inputs_per_proof == 0 || inputs_per_proof > 8) return ZKHIP_ERR_ARG;
+  if (!out || num_proofs == 0 || num_proofs > 16 || inputs_per_proof == 0 || inputs_per_proof > 16) return ZKHIP_ERR_ARG;
   zkhip_aggregator* a = new zkhip_aggregator();
   a->num_proofs = num_proofs; a->inputs_per_proof = inputs_per_proof;
   Builder b;

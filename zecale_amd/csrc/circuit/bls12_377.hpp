@@ -20,15 +20,15 @@ template <class F> struct G2 { Fq2<F> x, y; };
 
 template <class F> inline G1<F> g1_add(const G1<F>& p, const G1<F>& q) {       // p != +-q
   F lam = f_div(q.y - p.y, q.x - p.x);
-  F x3 = lam * lam - p.x - q.x;
-  F y3 = lam * (p.x - x3) - p.y;
+  F x3 = f_mul_minus(lam, lam, p.x + q.x);
+  F y3 = f_mul_minus(lam, p.x - x3, p.y);
   return G1<F>{x3, y3};
 }
 template <class F> inline G1<F> g1_dbl(const G1<F>& p) {
   F xx = p.x * p.x;
   F lam = f_div(xx + xx + xx, p.y + p.y);
-  F x3 = lam * lam - p.x - p.x;
-  F y3 = lam * (p.x - x3) - p.y;
+  F x3 = f_mul_minus(lam, lam, p.x + p.x);
+  F y3 = f_mul_minus(lam, p.x - x3, p.y);
   return G1<F>{x3, y3};
 }
 template <class F> inline G1<F> g1_select(const F& bit, const G1<F>& a, const G1<F>& b) {
@@ -52,16 +52,16 @@ template <class F> inline Fq12<F> miller_dbl_step(MillerState<F>& s) {
   Fq2<F> xx = s.T.x.sqr();
   Fq2<F> lam = fq2_div(xx + xx + xx, s.T.y + s.T.y);
   Fq12<F> l = line_eval(lam, s.T.x, s.T.y, s.P);
-  Fq2<F> x3 = lam.sqr() - s.T.x - s.T.x;
-  Fq2<F> y3 = lam * (s.T.x - x3) - s.T.y;
+  Fq2<F> x3 = fq2_sqr_minus(lam, s.T.x + s.T.x);
+  Fq2<F> y3 = fq2_mul_minus(lam, s.T.x - x3, s.T.y);
   s.T.x = x3; s.T.y = y3;
   return l;
 }
 template <class F> inline Fq12<F> miller_add_step(MillerState<F>& s) {
   Fq2<F> lam = fq2_div(s.Q.y - s.T.y, s.Q.x - s.T.x);
   Fq12<F> l = line_eval(lam, s.T.x, s.T.y, s.P);
-  Fq2<F> x3 = lam.sqr() - s.T.x - s.Q.x;
-  Fq2<F> y3 = lam * (s.T.x - x3) - s.T.y;
+  Fq2<F> x3 = fq2_sqr_minus(lam, s.T.x + s.Q.x);
+  Fq2<F> y3 = fq2_mul_minus(lam, s.T.x - x3, s.T.y);
   s.T.x = x3; s.T.y = y3;
   return l;
 }

@@ -204,8 +204,25 @@ template <class F> inline F f_is_zero(const F& x) {
   F::assert_product(x, z, f_zero<F>());
   return z;
 }
-// sel ? a : b   (sel boolean)
-template <class F> inline F f_select(const F& sel, const F& a, const F& b) { return b + sel * (a - b); }
+// Results of chained operations (point additions along a scalar, Miller-loop steps) are FRESH variables: the product
+// constraint a b = r + off defines r directly instead of defining a product variable p and returning the linear combination
+// p - off.  Same number of variables and constraints, but the linear combinations no longer grow along the chain (they used to
+// reach 500 terms at the end of a 253-bit accumulator and made every row that touched them that long).
+// r = a b - off
+template <class F> inline F f_mul_minus(const F& a, const F& b, const F& off) {
+  if (f_is_const(a) || f_is_const(b)) return a * b - off;          // stays linear: no variable, no constraint
+  F r = F::witness(a.value() * b.value() - off.value());
+  F::assert_product(a, b, r + off);
+  return r;
+}
+// sel ? a : b   (sel boolean): one variable, one constraint  sel (a - b) = out - b
+template <class F> inline F f_select(const F& sel, const F& a, const F& b) {
+  F d = a - b;
+  if (f_is_const(sel) || f_is_const(d)) return b + sel * d;
+  F out = F::witness(b.value() + sel.value() * d.value());
+  F::assert_product(sel, d, out - b);
+  return out;
+}
 
 }  // namespace circuit
 }  // namespace zkhip

@@ -54,12 +54,41 @@ inline V2 v2_inv(const V2& x) {
 }
 template <class F> inline V2 v2_of(const Fq2<F>& x) { return V2{x.c0.value(), x.c1.value()}; }
 
-// a / b in Fq2: witness q, enforce q b = a   (3 products + 2 equalities)
+template <class F> inline bool fq2_is_const(const Fq2<F>& x) { return f_is_const(x.c0) && f_is_const(x.c1); }
+
+// enforce x y = t for a given (linear) t: one auxiliary variable v1 = x1 y1 and
+//   x0 y0 = t0 + 5 v1,   (x0 + x1)(y0 + y1) = t1 + t0 + 6 v1          (3 constraints, like a Karatsuba product)
+template <class F> inline void fq2_assert_mul(const Fq2<F>& x, const Fq2<F>& y, const Fq2<F>& t) {
+  F v1 = x.c1 * y.c1;
+  F::assert_product(x.c0, y.c0, t.c0 + v1.mulc(HFr::from_u64(5)));
+  F::assert_product(x.c0 + x.c1, y.c0 + y.c1, t.c1 + t.c0 + v1.mulc(HFr::from_u64(6)));
+}
+// r = a b - off with r FRESH variables (see f_mul_minus): 3 constraints, 3 variables
+template <class F> inline Fq2<F> fq2_mul_minus(const Fq2<F>& a, const Fq2<F>& b, const Fq2<F>& off) {
+  if (fq2_is_const(a) || fq2_is_const(b)) return a * b - off;
+  V2 p = v2_mul(v2_of(a), v2_of(b));
+  Fq2<F> r = Fq2<F>::witness(p.a - off.c0.value(), p.b - off.c1.value());
+  fq2_assert_mul(a, b, r + off);
+  return r;
+}
+// r = a^2 - off with r FRESH: a0 a1 = t1 / 2,  (a0 + a1)(a0 - 5 a1) = t0 - 2 t1  with t = r + off     (2 constraints, 2 variables)
+template <class F> inline Fq2<F> fq2_sqr_minus(const Fq2<F>& a, const Fq2<F>& off) {
+  if (fq2_is_const(a)) return a.sqr() - off;
+  V2 p = v2_mul(v2_of(a), v2_of(a));
+  Fq2<F> r = Fq2<F>::witness(p.a - off.c0.value(), p.b - off.c1.value());
+  Fq2<F> t = r + off;
+  static const HFr half = HFr::from_u64(2).inv();
+  F::assert_product(a.c0, a.c1, t.c1.mulc(half));
+  F::assert_product(a.c0 + a.c1, a.c0 - a.c1.mulc(HFr::from_u64(5)), t.c0 - t.c1.mulc(HFr::from_u64(2)));
+  return r;
+}
+
+// a / b in Fq2: witness q, enforce q b = a   (3 constraints, 3 variables)
 template <class F> inline Fq2<F> fq2_div(const Fq2<F>& a, const Fq2<F>& b) {
   V2 q = v2_mul(v2_of(a), v2_inv(v2_of(b)));
-  if (f_is_const(a.c0) && f_is_const(a.c1) && f_is_const(b.c0) && f_is_const(b.c1)) return Fq2<F>::constant(q.a, q.b);
+  if (fq2_is_const(a) && fq2_is_const(b)) return Fq2<F>::constant(q.a, q.b);
   Fq2<F> w = Fq2<F>::witness(q.a, q.b);
-  Fq2<F>::assert_eq(w * b, a);
+  fq2_assert_mul(w, b, a);
   return w;
 }
 

@@ -3,7 +3,7 @@
 //
 // A batch goes through three stages with very different resource needs:
 //   witness   host only: ~1500 serial field inversions inside the in-circuit pairing, ~12 ms on 3 cores;
-//   prove     GPU: upload z, QAP map, five MSMs.  At this circuit's size (51k constraints) every MSM phase after the
+//   prove     GPU: upload z, QAP map, five MSMs.  At this circuit's size (50k constraints) every MSM phase after the
 //             accumulation is a chain of short latency-bound launches, so ONE proof leaves most of the chip idle;
 //   tail      host: three 377-bit scalar multiplications + affine normalisation, ~2 ms.
 // The pipeline keeps `witness_workers` witnesses and `gpu_slots` proofs in flight: each GPU slot is a zkhip_prover
