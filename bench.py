@@ -354,6 +354,7 @@ def main():
             terms_in_kernel = (3 * al + hl + ll) if tw_batched(extra, args) else ll
             if phase:
                 extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
+        tw_batched_flag = tw_batched(extra, args)
         tw = extra.pop("table_window", None)
         digits = -(-378 // tw) if tw else 24 if terms_in_kernel > (1 << 18) else None
         timed = k_ms > 0        # the prover replays captured hipGraphs: no per-kernel events there (profiles/ has the kernel traces)
@@ -371,7 +372,7 @@ def main():
                        "parallelism": "point-partitioned x%d, RCCL all-gather of 288-byte partial sums" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3) if timed else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6) if timed else None, "traffic": measured_traffic() if (timed and args.workload == "msm") else None,
-                         "kernel": "zkhip::k_accumulate", "kernel_ms": round(k_ms, 3) if timed else None,
+                         "kernel": "zkhip::k_accumulate<1>" if args.workload == "msm" else ("zkhip::k_accumulate<5>" if tw_batched_flag else "zkhip::k_accumulate<1>"), "kernel_ms": round(k_ms, 3) if timed else None,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_TERM * terms_in_kernel,
                          "note": "this path is integer-multiply bound, not HBM bound (SURVEY 0.5): fq_mul_frac = Fq "
                                  "multiplications per second in the kernel / measured chip peak of the multiplier",

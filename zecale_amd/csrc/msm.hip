@@ -227,14 +227,17 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offse
 
 // Several MSMs may share one launch (merged plans: bucket window k belongs to job k): the base set of a run is chosen
 // by its bucket, b >> bshift (plain plans: one base set, bshift = 31).
+// NJ = 1: a plan for single MSMs (the selection folds away); NJ = MSM_MAX_JOBS: the five MSMs of a proof in one launch.  Two
+// instantiations, two kernel names in a trace: k_accumulate<1> and k_accumulate<5>.
 struct BasePtrs { const AffPacked* p[MSM_MAX_JOBS]; };
-__device__ __forceinline__ const AffPacked* base_of(const BasePtrs& bp, uint32_t k) {
+template <int NJ> __device__ __forceinline__ const AffPacked* base_of(const BasePtrs& bp, uint32_t k) {
   const AffPacked* r = bp.p[0];
 #pragma unroll
-  for (int j = 1; j < MSM_MAX_JOBS; j++) r = (k == (uint32_t)j) ? bp.p[j] : r;
+  for (int j = 1; j < NJ; j++) r = (k == (uint32_t)j) ? bp.p[j] : r;
   return r;
 }
 
+template <int NJ>
 __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, const uint32_t* __restrict__ entries,
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                         uint32_t nb, uint32_t S, uint32_t T, uint32_t* __restrict__ slots,
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
     }
     uint32_t e = e_next;
     if (k + 1 < pos1) e_next = entries[k + 1];        // fetched a whole addition ahead of its use
-    const AffPacked* p = base_of(bp, b >> bshift) + (e & 0x7fffffffu);
+    const AffPacked* p = base_of<NJ>(bp, b >> bshift) + (e & 0x7fffffffu);
     bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_scalar_digits drops them)
     if (inf) {
 #pragma unroll
@@ -822,8 +825,12 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   }
   HIP_TRY(hipMemsetAsync(ctx->buckets, 0, (size_t)ctx->slot_stride * 108 * 4, st));
   HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
-  hipLaunchKernelGGL(k_accumulate, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, ctx->entries, ctx->offsets, ctx->counts,
-                     (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
+  if (ctx->K == 1)
+    hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, ctx->entries, ctx->offsets, ctx->counts,
+                       (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
+  else
+    hipLaunchKernelGGL(k_accumulate<MSM_MAX_JOBS>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, ctx->entries, ctx->offsets,
+                       ctx->counts, (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
   for (uint32_t d = 1; d < T_run; d <<= 1) {
     // d = 1 touches up to every slice (throughput-bound: one lane per addition); later rounds only serve
