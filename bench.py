@@ -255,13 +255,13 @@ def main():
             pk[key] = gen_bases(seed * 7919 + rank, hi - lo).cpu().numpy().view(np.uint64)
         crs = zkhip.crs_from_slice_arrays(consts, pk, m, l, d, a_rng, h_rng, l_rng)
         del pk
-        # witness shaped like the wrapping circuit's: 3.4 % of its 50,218 variables are 0 or 1 (measured on the real
-        # batch-2 witness: 1,690 zeros, 27 ones - the variables are Fq elements of the in-circuit pairing), the rest uniform
+        # witness shaped like the wrapping circuit's: 1.3 % of its 45,958 variables are 0 or 1 (measured on the real
+        # batch-2 witness: 590 zeros, 27 ones - the variables are Fq elements of the in-circuit pairing), the rest uniform
         z = random_fr_canonical(99, m)
         sel = rng.random(m)
         one_m = np.array(zkhip_fr_one(), dtype=np.uint64)
-        z[sel < 0.0336] = 0
-        z[(sel >= 0.0336) & (sel < 0.0342)] = one_m
+        z[sel < 0.0128] = 0
+        z[(sel >= 0.0128) & (sel < 0.0134)] = one_m
         z[0] = one_m
         rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
 

@@ -73,17 +73,18 @@ template <class F> inline Fq12<F> multi_miller_loop(std::vector<MillerState<F>>&
   bool first = true;
   for (int i = 62; i >= 0; i--) {
     if (!first) f = f.sqr();
-    for (auto& s : ps) { Fq12<F> l = miller_dbl_step(s); f = first ? l : f * l; first = false; }
+    for (auto& s : ps) { Fq12<F> l = miller_dbl_step(s); f = first ? l : fq12_mul_line(f, l); first = false; }
     if ((BLS_U >> i) & 1)
-      for (auto& s : ps) f = f * miller_add_step(s);
+      for (auto& s : ps) f = fq12_mul_line(f, miller_add_step(s));
   }
   return f;
 }
 
+// x^u for x in the cyclotomic subgroup (every use is after the easy part of the final exponentiation)
 template <class F> inline Fq12<F> exp_by_u(const Fq12<F>& x) {
   Fq12<F> acc = x;
   for (int i = 62; i >= 0; i--) {
-    acc = acc.sqr();
+    acc = fq12_cyclotomic_sqr(acc);
     if ((BLS_U >> i) & 1) acc = acc * x;
   }
   return acc;
@@ -99,7 +100,7 @@ template <class F> inline Fq12<F> final_exponentiation(const Fq12<F>& f) {
   Fq12<F> t1 = exp_by_u(t0) * t0.conjugate();          // f2^l3
   Fq12<F> t2 = exp_by_u(t1);                           // f2^l2
   Fq12<F> t3 = exp_by_u(t2) * t1.conjugate();          // f2^l1
-  Fq12<F> t4 = exp_by_u(t3) * (f2.sqr() * f2);         // f2^l0
+  Fq12<F> t4 = exp_by_u(t3) * (fq12_cyclotomic_sqr(f2) * f2);   // f2^l0
   return t4 * t3.frobenius(1) * t2.frobenius(2) * t1.frobenius(3);
 }
 

@@ -187,6 +187,129 @@ template <> inline Fq12<WV> fq12_mul_impl<WV>(const Fq12<WV>& a, const Fq12<WV>&
   return r;
 }
 
+// a * l for a LINE l (non-zero coefficients at w^0, w^1, w^3, w^7, w^9 only: degree 9): the unreduced product has degree 20, so 21
+// evaluation points pin it - two constraints and two variables fewer than a general multiplication (280 line multiplications per
+// in-circuit verification).  The caller guarantees l.c[i] = 0 for i > 9 (structural zeros: never read here).
+constexpr int FQ12_LINE_PTS = 21;
+template <class F> Fq12<F> fq12_mul_line(const Fq12<F>& a, const Fq12<F>& l);
+template <> inline Fq12<NF> fq12_mul_line<NF>(const Fq12<NF>& a, const Fq12<NF>& l) { return fq12_mul_impl<NF>(a, l); }
+template <> inline Fq12<CV> fq12_mul_line<CV>(const Fq12<CV>& a, const Fq12<CV>& l) {
+  const Fq12Consts& K = fq12_consts();
+  HFr av[12], bv[12], cv[23];
+  for (int i = 0; i < 12; i++) { av[i] = a.c[i].val; bv[i] = l.c[i].val; }
+  v12_full_product(av, bv, cv);
+  CV cc[FQ12_LINE_PTS];
+  for (int m = 0; m < FQ12_LINE_PTS; m++) cc[m] = CV::witness(cv[m]);
+  for (int k = 0; k < FQ12_LINE_PTS; k++) {
+    CV ea, eb, ec;
+    for (int i = 0; i < 12; i++) ea = ea + a.c[i].mulc(K.pw[k][i]);
+    for (int i = 0; i <= 9; i++) eb = eb + l.c[i].mulc(K.pw[k][i]);
+    for (int m = 0; m < FQ12_LINE_PTS; m++) ec = ec + cc[m].mulc(K.pw[k][m]);
+    CV::assert_product(ea, eb, ec);
+  }
+  Fq12<CV> r;
+  HFr five = HFr::from_u64(5);
+  for (int i = 0; i < 12; i++) r.c[i] = (i + 12 < FQ12_LINE_PTS) ? cc[i] - cc[i + 12].mulc(five) : cc[i];
+  return r;
+}
+template <> inline Fq12<WV> fq12_mul_line<WV>(const Fq12<WV>& a, const Fq12<WV>& l) {
+  HFr av[12], bv[12], cv[23];
+  for (int i = 0; i < 12; i++) { av[i] = a.c[i].val; bv[i] = l.c[i].val; }
+  v12_full_product(av, bv, cv);
+  WV cc[FQ12_LINE_PTS];
+  for (int m = 0; m < FQ12_LINE_PTS; m++) cc[m] = WV::witness(cv[m]);       // same 21 allocations as the CV version
+  Fq12<WV> r;
+  HFr five = HFr::from_u64(5);
+  for (int i = 0; i < 12; i++) r.c[i] = (i + 12 < FQ12_LINE_PTS) ? cc[i] - cc[i + 12].mulc(five) : cc[i];
+  return r;
+}
+
+// ---- squaring in the cyclotomic subgroup (Granger-Scott) --------------------------------------------------------------
+// After the easy part of the final exponentiation every element satisfies x^(q^4 - q^2 + 1) = 1, and its square needs only three
+// squarings in Fq4.  Tower inside the direct representation: u = w^6 (Fq2 = Fq[u]), s = w^3 (Fq4 = Fq2[s], s^2 = u),
+// Fq12 = Fq4[w]/(w^3 - s):  x = g0 + g1 w + g2 w^2,  g_k = a_k + a_(k+3) s,  a_j = c[j] + c[j+6] u.  Then
+//   x^2 = (3 g0^2 - 2 conj g0) + (3 s g2^2 + 2 conj g1) w + (3 g1^2 - 2 conj g2) w^2        (conj: s -> -s)
+// 9 squarings in Fq2 = 18 constraints instead of 23, and - as everywhere in a chain - the six Fq2 coefficients of the result are
+// FRESH variables: the constraints read  a^2 = P, b^2 = Q, (a + b)^2 = P + Q + S  with P and S expressed through the outputs.
+struct SmallConsts {       // 2, 3, 5 and their inverses in Montgomery form, computed once
+  HFr two, three, five, half, third, fifth_neg, five_neg;
+  SmallConsts() {
+    two = HFr::from_u64(2); three = HFr::from_u64(3); five = HFr::from_u64(5);
+    half = two.inv(); third = three.inv(); fifth_neg = five.inv().neg(); five_neg = five.neg();
+  }
+};
+inline const SmallConsts& small_consts() { static SmallConsts c; return c; }
+template <class F> inline Fq2<F> fq2_mul_u(const Fq2<F>& a) { return Fq2<F>(a.c1.mulc(small_consts().five_neg), a.c0); }       // u (c0 + c1 u)
+template <class F> inline Fq2<F> fq2_div_u(const Fq2<F>& a) { return Fq2<F>(a.c1, a.c0.mulc(small_consts().fifth_neg)); }      // (c0 + c1 u) / u
+// enforce a^2 = t for a linear t (2 constraints)
+template <class F> inline void fq2_assert_sqr(const Fq2<F>& a, const Fq2<F>& t) {
+  const SmallConsts& K = small_consts();
+  F::assert_product(a.c0, a.c1, t.c1.mulc(K.half));
+  F::assert_product(a.c0 + a.c1, a.c0 - a.c1.mulc(K.five), t.c0 - t.c1.mulc(K.two));
+}
+inline V2 v2_add(const V2& x, const V2& y) { return V2{x.a + y.a, x.b + y.b}; }
+inline V2 v2_sub(const V2& x, const V2& y) { return V2{x.a - y.a, x.b - y.b}; }
+inline V2 v2_dbl(const V2& x) { return V2{x.a + x.a, x.b + x.b}; }
+inline V2 v2_tpl(const V2& x) { return V2{x.a + x.a + x.a, x.b + x.b + x.b}; }
+inline V2 v2_mul_u(const V2& x) { return V2{x.b * small_consts().five_neg, x.a}; }
+
+// One Fq4 squaring g = a + b s:  g^2 = (a^2 + u b^2) + (2 a b) s.  The caller supplies P (= a^2) and S (= 2 a b) as LINEAR
+// expressions in its own fresh outputs; Q = b^2 is a fresh variable here.  6 constraints.
+template <class F> inline Fq2<F> fq4_sqr_witness_q(const Fq2<F>& b) {
+  V2 q = v2_mul(v2_of(b), v2_of(b));
+  return Fq2<F>::witness(q.a, q.b);
+}
+template <class F> inline void fq4_sqr_assert(const Fq2<F>& a, const Fq2<F>& b, const Fq2<F>& P, const Fq2<F>& Q, const Fq2<F>& S) {
+  fq2_assert_sqr(a, P);
+  fq2_assert_sqr(b, Q);
+  fq2_assert_sqr(a + b, P + Q + S);
+}
+
+template <class F> inline Fq12<F> fq12_cyclotomic_sqr(const Fq12<F>& x) {
+  const HFr& third = small_consts().third;
+  Fq2<F> a[6];
+  for (int j = 0; j < 6; j++) a[j] = Fq2<F>(x.c[j], x.c[j + 6]);
+  auto val = [](const Fq2<F>& t) { return v2_of(t); };
+  Fq2<F> h[6];
+  // native values of the three Fq4 squares
+  auto sq = [&](const Fq2<F>& p, const Fq2<F>& q, V2& re, V2& im) {      // (p + q s)^2 = re + im s
+    V2 pp = v2_mul(val(p), val(p)), qq = v2_mul(val(q), val(q)), pq = v2_mul(val(p), val(q));
+    re = v2_add(pp, v2_mul_u(qq)); im = v2_add(pq, pq);
+  };
+  V2 r0, i0, r1, i1, r2, i2;
+  sq(a[0], a[3], r0, i0); sq(a[1], a[4], r1, i1); sq(a[2], a[5], r2, i2);
+  // h0 = 3 g0^2 - 2 conj g0:  (3 r0 - 2 a0) + (3 i0 + 2 a3) s
+  {
+    V2 hx = v2_sub(v2_tpl(r0), v2_dbl(val(a[0]))), hy = v2_add(v2_tpl(i0), v2_dbl(val(a[3])));
+    h[0] = Fq2<F>::witness(hx.a, hx.b); h[3] = Fq2<F>::witness(hy.a, hy.b);
+    Fq2<F> Q = fq4_sqr_witness_q(a[3]);
+    Fq2<F> P = (h[0] + a[0].dbl()).mulc(third) - fq2_mul_u(Q);           // a0^2 = (h0x + 2 a0)/3 - u Q
+    Fq2<F> S = (h[3] - a[3].dbl()).mulc(third);                          // 2 a0 a3 = (h0y - 2 a3)/3
+    fq4_sqr_assert(a[0], a[3], P, Q, S);
+  }
+  // h2 = 3 g1^2 - 2 conj g2:  (3 r1 - 2 a2) + (3 i1 + 2 a5) s
+  {
+    V2 hx = v2_sub(v2_tpl(r1), v2_dbl(val(a[2]))), hy = v2_add(v2_tpl(i1), v2_dbl(val(a[5])));
+    h[2] = Fq2<F>::witness(hx.a, hx.b); h[5] = Fq2<F>::witness(hy.a, hy.b);
+    Fq2<F> Q = fq4_sqr_witness_q(a[4]);
+    Fq2<F> P = (h[2] + a[2].dbl()).mulc(third) - fq2_mul_u(Q);
+    Fq2<F> S = (h[5] - a[5].dbl()).mulc(third);
+    fq4_sqr_assert(a[1], a[4], P, Q, S);
+  }
+  // h1 = 3 s g2^2 + 2 conj g1:  s (r2 + i2 s) = u i2 + r2 s  ->  (3 u i2 + 2 a1) + (3 r2 - 2 a4) s
+  {
+    V2 hx = v2_add(v2_tpl(v2_mul_u(i2)), v2_dbl(val(a[1]))), hy = v2_sub(v2_tpl(r2), v2_dbl(val(a[4])));
+    h[1] = Fq2<F>::witness(hx.a, hx.b); h[4] = Fq2<F>::witness(hy.a, hy.b);
+    Fq2<F> Q = fq4_sqr_witness_q(a[5]);
+    Fq2<F> P = (h[4] + a[4].dbl()).mulc(third) - fq2_mul_u(Q);           // a2^2 = (h1y + 2 a4)/3 - u Q
+    Fq2<F> S = fq2_div_u(h[1] - a[1].dbl()).mulc(third);                  // 2 a2 a5 = (h1x - 2 a1) / (3 u)
+    fq4_sqr_assert(a[2], a[5], P, Q, S);
+  }
+  Fq12<F> r;
+  for (int j = 0; j < 6; j++) { r.c[j] = h[j].c0; r.c[j + 6] = h[j].c1; }
+  return r;
+}
+
 // 1 / a: witness + a * inv = 1
 template <class F> inline void v12_of(const Fq12<F>& a, HFr* out) { for (int i = 0; i < 12; i++) out[i] = a.c[i].value(); }
 
