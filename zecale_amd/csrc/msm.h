@@ -30,7 +30,7 @@ struct MsmCtx {
   size_t B, max_n;
   uint32_t S, T, slot_stride;   // slice length, slice count, words per row of the slot array
   hipStream_t stream, stream2;
-  hipEvent_t ev, ev2, ev_acc0, ev_acc1;
+  hipEvent_t ev, ev2, ev_acc0, ev_acc1, ev_done;
   int32_t* digits;
   uint32_t *counts, *offsets, *cursor, *block_tot, *entries;
   uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels, *colS[2], *hilo;

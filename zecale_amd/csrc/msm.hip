@@ -694,6 +694,9 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&ctx->ev_acc0));
   HIP_TRY(hipEventCreate(&ctx->ev_acc1));
+  // completion of a launch sequence: a BLOCKING event, so that the host thread that collects the result sleeps instead of
+  // spinning on the stream (several prover instances wait side by side and share the cores with the witness generators)
+  HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done, hipEventBlockingSync | hipEventDisableTiming));
   if ((size_t)ctx->Wd * max_n >= ((size_t)1 << 31)) return ZKHIP_ERR_ARG;   // entry = 31-bit point index + sign
   if ((size_t)ctx->Wd * max_n * K >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;  // positions in the entry list are 32-bit
   HIP_TRY(hipMalloc(&ctx->digits, (size_t)K * ctx->Wd * max_n * sizeof(int32_t)));
@@ -743,6 +746,7 @@ void msm_plan_free(MsmCtx* ctx) {
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->ev_acc0) (void)hipEventDestroy(ctx->ev_acc0);
   if (ctx->ev_acc1) (void)hipEventDestroy(ctx->ev_acc1);
+  if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   memset(ctx, 0, sizeof *ctx);
 }
 
@@ -936,6 +940,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   hipLaunchKernelGGL(k_hilo_combine, dim3(nblk((size_t)W * 4, 64)), dim3(64), 0, st, ctx->sumR[0], W, lo_bits, ctx->win_abi);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ctx->win_host, ctx->win_abi, (size_t)W * 48 * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(ctx->ev_done, st));
   return ZKHIP_OK;
 }
 
@@ -956,7 +961,7 @@ int msm_finish_multi(MsmCtx* ctx, int K, uint64_t* out_jac) {
   if (!ctx->pending || !ctx->merged || K < 1 || K > ctx->K) return ZKHIP_ERR_STATE;
   ctx->pending = false;
   if (ctx->pending_n) {
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev_done));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
     ctx->last_accumulate_ms = ms;
@@ -980,7 +985,7 @@ int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]) {
     inf.X.to_limbs(out_jac); inf.Y.to_limbs(out_jac + 12); inf.Z.to_limbs(out_jac + 24);
     return ZKHIP_OK;
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev_done));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
   ctx->last_accumulate_ms = ms;

@@ -46,6 +46,7 @@ struct ProveState {
   MsmCtx ctx[5];
   bool ready[5] = {false, false, false, false, false};
   hipStream_t st = nullptr;
+  hipEvent_t ev_st = nullptr;      // blocking-sync event for waits on st (the waiting host thread sleeps)
   uint64_t* dz = nullptr;
   size_t dz_cap = 0;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -53,6 +54,7 @@ struct ProveState {
   void release() {
     for (int k = 0; k < 5; k++) if (ready[k]) { msm_plan_free(&ctx[k]); ready[k] = false; }
     if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+    if (ev_st) { (void)hipEventDestroy(ev_st); ev_st = nullptr; }
     if (dz) { (void)hipFree(dz); dz = nullptr; dz_cap = 0; }
   }
 };
@@ -499,6 +501,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     return fail(ZKHIP_ERR_ARG, "the five query vectors of a proving key must share one table window");
   auto t0 = clk::now();
   if (!ps.st) API_HIP(hipStreamCreateWithFlags(&ps.st, hipStreamNonBlocking));
+  if (!ps.ev_st) API_HIP(hipEventCreateWithFlags(&ps.ev_st, hipEventBlockingSync | hipEventDisableTiming));
   if (ps.dz_cap < m) {
     if (ps.dz) { (void)hipFree(ps.dz); ps.dz = nullptr; ps.dz_cap = 0; }
     API_HIP(hipMalloc(&ps.dz, m * 48));
@@ -506,12 +509,14 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   }
   uint64_t* dz = ps.dz;
   API_HIP(hipMemcpyAsync(dz, z, m * 48, hipMemcpyHostToDevice, ps.st));
-  API_HIP(hipStreamSynchronize(ps.st));
+  API_HIP(hipEventRecord(ps.ev_st, ps.st));
+  API_HIP(hipEventSynchronize(ps.ev_st));
   ps.ms[0] = ms_since(t0);
   t0 = clk::now();
   int rc = qap_h_dev(rd, dz, ps.st, t_err, sizeof t_err);
   if (rc != ZKHIP_OK) return rc;
-  API_HIP(hipStreamSynchronize(ps.st));     // the MSM contexts run on their own streams
+  API_HIP(hipEventRecord(ps.ev_st, ps.st));
+  API_HIP(hipEventSynchronize(ps.ev_st));   // the MSM contexts run on their own streams
   ps.ms[1] = ms_since(t0);
   size_t maxlen = a_len > h_len ? a_len : h_len;
   if (maxlen < 1) maxlen = 1;
