@@ -18,15 +18,16 @@ static const uint64_t BLS_U = 0x8508c00000000001ull;
 template <class F> struct G1 { F x, y; };
 template <class F> struct G2 { Fq2<F> x, y; };
 
-template <class F> inline G1<F> g1_add(const G1<F>& p, const G1<F>& q) {       // p != +-q
-  F lam = f_div(q.y - p.y, q.x - p.x);
+// dinv (optional): the inverse of the slope's denominator, when the caller has batched it with others
+template <class F> inline G1<F> g1_add(const G1<F>& p, const G1<F>& q, const HFr* dinv = nullptr) {       // p != +-q
+  F lam = f_div(q.y - p.y, q.x - p.x, dinv);
   F x3 = f_mul_minus(lam, lam, p.x + q.x);
   F y3 = f_mul_minus(lam, p.x - x3, p.y);
   return G1<F>{x3, y3};
 }
-template <class F> inline G1<F> g1_dbl(const G1<F>& p) {
+template <class F> inline G1<F> g1_dbl(const G1<F>& p, const HFr* dinv = nullptr) {
   F xx = p.x * p.x;
-  F lam = f_div(xx + xx + xx, p.y + p.y);
+  F lam = f_div(xx + xx + xx, p.y + p.y, dinv);
   F x3 = f_mul_minus(lam, lam, p.x + p.x);
   F y3 = f_mul_minus(lam, p.x - x3, p.y);
   return G1<F>{x3, y3};
@@ -48,17 +49,17 @@ template <class F> inline Fq12<F> line_eval(const Fq2<F>& lam, const Fq2<F>& xT,
 
 template <class F> struct MillerState { G2<F> T; G2<F> Q; G1<F> P; };
 
-template <class F> inline Fq12<F> miller_dbl_step(MillerState<F>& s) {
+template <class F> inline Fq12<F> miller_dbl_step(MillerState<F>& s, const HFr* den_norm_inv = nullptr) {
   Fq2<F> xx = s.T.x.sqr();
-  Fq2<F> lam = fq2_div(xx + xx + xx, s.T.y + s.T.y);
+  Fq2<F> lam = fq2_div(xx + xx + xx, s.T.y + s.T.y, den_norm_inv);
   Fq12<F> l = line_eval(lam, s.T.x, s.T.y, s.P);
   Fq2<F> x3 = fq2_sqr_minus(lam, s.T.x + s.T.x);
   Fq2<F> y3 = fq2_mul_minus(lam, s.T.x - x3, s.T.y);
   s.T.x = x3; s.T.y = y3;
   return l;
 }
-template <class F> inline Fq12<F> miller_add_step(MillerState<F>& s) {
-  Fq2<F> lam = fq2_div(s.Q.y - s.T.y, s.Q.x - s.T.x);
+template <class F> inline Fq12<F> miller_add_step(MillerState<F>& s, const HFr* den_norm_inv = nullptr) {
+  Fq2<F> lam = fq2_div(s.Q.y - s.T.y, s.Q.x - s.T.x, den_norm_inv);
   Fq12<F> l = line_eval(lam, s.T.x, s.T.y, s.P);
   Fq2<F> x3 = fq2_sqr_minus(lam, s.T.x + s.Q.x);
   Fq2<F> y3 = fq2_mul_minus(lam, s.T.x - x3, s.T.y);
@@ -73,9 +74,17 @@ template <class F> inline Fq12<F> multi_miller_loop(std::vector<MillerState<F>>&
   bool first = true;
   for (int i = 62; i >= 0; i--) {
     if (!first) f = f.sqr();
-    for (auto& s : ps) { Fq12<F> l = miller_dbl_step(s); f = first ? l : fq12_mul_line(f, l); first = false; }
-    if ((BLS_U >> i) & 1)
-      for (auto& s : ps) f = fq12_mul_line(f, miller_add_step(s));
+    // the slopes of the (up to 8) pairings of this step need one Fq2 inversion each, all independent: one field inversion for all
+    HFr ninv[8];
+    const int np = (int)ps.size();
+    for (int k = 0; k < np; k++) ninv[k] = v2_norm(v2_of(ps[k].T.y + ps[k].T.y));
+    batch_inv(ninv, np);
+    for (int k = 0; k < np; k++) { Fq12<F> l = miller_dbl_step(ps[k], &ninv[k]); f = first ? l : fq12_mul_line(f, l); first = false; }
+    if ((BLS_U >> i) & 1) {
+      for (int k = 0; k < np; k++) ninv[k] = v2_norm(v2_of(ps[k].Q.x - ps[k].T.x));
+      batch_inv(ninv, np);
+      for (int k = 0; k < np; k++) f = fq12_mul_line(f, miller_add_step(ps[k], &ninv[k]));
+    }
   }
   return f;
 }
@@ -139,9 +148,12 @@ template <class F> inline G1<F> input_accumulator(const NestedVk<F>& vk, const s
   for (size_t k = 0; k < input_bits.size(); k++) {
     G1<F> pw = vk.abc[k + 1];
     for (size_t j = 0; j < input_bits[k].size(); j++) {
-      G1<F> s = g1_add(acc, pw);
+      const bool more = j + 1 < input_bits[k].size();
+      HFr dinv[2] = {(pw.x - acc.x).value(), (pw.y + pw.y).value()};      // denominators of the addition and of the doubling
+      batch_inv(dinv, more ? 2 : 1);
+      G1<F> s = g1_add(acc, pw, &dinv[0]);
       acc = g1_select(input_bits[k][j], s, acc);
-      if (j + 1 < input_bits[k].size()) pw = g1_dbl(pw);
+      if (more) pw = g1_dbl(pw, &dinv[1]);
     }
   }
   return acc;

@@ -189,8 +189,23 @@ template <class F> inline F f_one() { return F::constant(HFr::one()); }
 // a / b with b != 0 (value 0 if b == 0: the structure pass runs on dummy values): witness q, enforce q b = a
 inline bool f_is_const(const NF&) { return false; }
 inline bool f_is_const(const CV& x) { return x.is_const(); }
-template <class F> inline F f_div(const F& a, const F& b) {
-  HFr bi = b.value().is_zero() ? HFr::zero() : b.value().inv();
+// Witness generation is a chain of field inversions (the slopes of the in-circuit point additions); the ones that do not depend on
+// each other are inverted together: n inverses for one inversion and 3(n-1) multiplications (Montgomery's trick).  Zeros stay zero.
+inline void batch_inv(HFr* v, int n) {
+  HFr pre[8];
+  HFr acc = HFr::one();
+  for (int i = 0; i < n; i++) { pre[i] = acc; if (!v[i].is_zero()) acc = acc * v[i]; }
+  HFr inv = acc.inv();
+  for (int i = n - 1; i >= 0; i--) {
+    if (v[i].is_zero()) continue;
+    HFr vi = inv * pre[i];
+    inv = inv * v[i];
+    v[i] = vi;
+  }
+}
+// binv: the inverse of b's value if the caller already has it (batch_inv), else null
+template <class F> inline F f_div(const F& a, const F& b, const HFr* binv = nullptr) {
+  HFr bi = binv ? *binv : (b.value().is_zero() ? HFr::zero() : b.value().inv());
   if (f_is_const(a) && f_is_const(b)) return F::constant(a.value() * bi);
   F q = F::witness(a.value() * bi);
   F::assert_product(q, b, a);

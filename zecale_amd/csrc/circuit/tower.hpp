@@ -46,10 +46,16 @@ inline V2 v2_mul(const V2& x, const V2& y) {
   HFr v0 = x.a * y.a, v1 = x.b * y.b;
   return V2{v0 - v1 * HFr::from_u64(5), (x.a + x.b) * (y.a + y.b) - v0 - v1};
 }
-inline V2 v2_inv(const V2& x) {
-  HFr n = x.a * x.a + x.b * x.b * HFr::from_u64(5);     // norm a^2 + 5 b^2
-  if (n.is_zero()) return V2{HFr::zero(), HFr::zero()};
-  HFr ni = n.inv();
+inline HFr v2_norm(const V2& x) { return x.a * x.a + x.b * x.b * HFr::from_u64(5); }      // a^2 + 5 b^2
+// ninv: the inverse of the norm if the caller already has it (batch_inv), else null
+inline V2 v2_inv(const V2& x, const HFr* ninv = nullptr) {
+  HFr ni;
+  if (ninv) ni = *ninv;
+  else {
+    HFr n = v2_norm(x);
+    if (n.is_zero()) return V2{HFr::zero(), HFr::zero()};
+    ni = n.inv();
+  }
   return V2{x.a * ni, (x.b * ni).neg()};
 }
 template <class F> inline V2 v2_of(const Fq2<F>& x) { return V2{x.c0.value(), x.c1.value()}; }
@@ -84,8 +90,8 @@ template <class F> inline Fq2<F> fq2_sqr_minus(const Fq2<F>& a, const Fq2<F>& of
 }
 
 // a / b in Fq2: witness q, enforce q b = a   (3 constraints, 3 variables)
-template <class F> inline Fq2<F> fq2_div(const Fq2<F>& a, const Fq2<F>& b) {
-  V2 q = v2_mul(v2_of(a), v2_inv(v2_of(b)));
+template <class F> inline Fq2<F> fq2_div(const Fq2<F>& a, const Fq2<F>& b, const HFr* b_norm_inv = nullptr) {
+  V2 q = v2_mul(v2_of(a), v2_inv(v2_of(b), b_norm_inv));
   if (fq2_is_const(a) && fq2_is_const(b)) return Fq2<F>::constant(q.a, q.b);
   Fq2<F> w = Fq2<F>::witness(q.a, q.b);
   fq2_assert_mul(w, b, a);
