@@ -18,6 +18,8 @@ struct MsmJob {
   size_t n;
   int scalars_mode;              // 0 canonical, 1 Montgomery (ABI), 2 packed device form
   size_t table_stride;           // distance between table levels, in points
+  size_t n_finite;               // upper bound on the bases of this job that are not the point at infinity (0: unknown, use n):
+                                 // sizes the slices of the accumulation to the entries that can actually occur
 };
 
 struct MsmCtx {

@@ -773,16 +773,17 @@ int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, c
 // in flight so that the latency-bound reduction of one MSM overlaps the accumulation of the next).
 int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
                int scalars_montgomery, size_t table_stride) {
-  MsmJob job{d_bases, d_inf_flags, d_scalars, n, scalars_montgomery, table_stride};
+  MsmJob job{d_bases, d_inf_flags, d_scalars, n, scalars_montgomery, table_stride, 0};
   return msm_launch_multi(ctx, 1, &job);
 }
 
 int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   const int c = ctx->c, W = ctx->W, Wd = ctx->Wd, merged = ctx->merged;
   if (K < 1 || K > ctx->K) return ZKHIP_ERR_ARG;
-  size_t n_tot = 0;
+  size_t n_tot = 0, n_eff = 0;
   for (int k = 0; k < K; k++) {
     if (jobs[k].n > ctx->max_n) return ZKHIP_ERR_ARG;
+    n_eff += (jobs[k].n_finite && jobs[k].n_finite < jobs[k].n) ? jobs[k].n_finite : jobs[k].n;
     if (merged && jobs[k].n && (jobs[k].table_stride < jobs[k].n || (size_t)Wd * jobs[k].table_stride >= ((size_t)1 << 31))) return ZKHIP_ERR_ARG;
     n_tot += jobs[k].n;
   }
@@ -819,7 +820,8 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   // slice length for THIS n (the plan's slot array is sized for max_n)
   uint32_t S_run, T_run;
   {
-    const size_t lanes = 131072, m = (size_t)Wd * n_tot;
+    // entries that can occur: a base at infinity never produces one (a sparse B query of a real key is 40 % infinity)
+    const size_t lanes = 131072, m = (size_t)Wd * (n_eff ? n_eff : 1);
     size_t fills = (m + lanes * slice_target() - 1) / (lanes * slice_target());
     if (fills < 1) fills = 1;
     size_t S = (m + lanes * fills - 1) / (lanes * fills);

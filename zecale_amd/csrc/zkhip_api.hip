@@ -21,6 +21,7 @@ struct zkhip_bases {
   uint8_t* d_inf;    // 1 where the base (or its table level) is the point at infinity; same shape as d_pts
   size_t len;
   int table_c;       // 0: plain base set
+  size_t n_finite;   // bases that are not the point at infinity (counted at upload)
 };
 
 struct zkhip_r1cs {
@@ -186,12 +187,17 @@ int zkhip_bases_upload_dev(const void* d_bases_affine, size_t len, zkhip_bases**
   std::lock_guard<std::mutex> lk(g.mu);
   if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!out || (len && !d_bases_affine)) return fail(ZKHIP_ERR_ARG, "null pointer");
-  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len, 0};
+  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len, 0, len};
   if (len) {
     API_HIP(hipMalloc(&b->d_pts, len * sizeof(AffPacked)));
     API_HIP(hipMalloc(&b->d_inf, len));
     int rc = msm_bases_convert((const uint64_t*)d_bases_affine, len, b->d_pts, b->d_inf, t_err, sizeof t_err);
     if (rc != ZKHIP_OK) return rc;
+    std::vector<uint8_t> flags(len);
+    API_HIP(hipMemcpy(flags.data(), b->d_inf, len, hipMemcpyDeviceToHost));
+    size_t inf = 0;
+    for (uint8_t f : flags) inf += f;
+    b->n_finite = len - inf;
   }
   *out = b;
   return ZKHIP_OK;
@@ -529,7 +535,9 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     MsmCtx* cx = &ps.ctx[4];
     if ((rc = ensure_ctx(cx, &ps.ready[4], maxlen, tc, 5)) != ZKHIP_OK) return rc;
     MsmJob mj[5];
-    for (int j = 0; j < 5; j++) mj[j] = MsmJob{jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].b->len};
+    for (int j = 0; j < 5; j++)
+      mj[j] = MsmJob{jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].b->len,
+                     jobs[j].len == jobs[j].b->len ? jobs[j].b->n_finite : 0};
     auto tl0 = clk::now();
     if ((rc = msm_launch_multi(cx, 5, mj)) == ZKHIP_OK) rc = msm_finish_multi(cx, 5, sums);
     if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", cx->errbuf); return rc; }
