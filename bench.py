@@ -255,7 +255,7 @@ def main():
             pk[key] = gen_bases(seed * 7919 + rank, hi - lo).cpu().numpy().view(np.uint64)
         crs = zkhip.crs_from_slice_arrays(consts, pk, m, l, d, a_rng, h_rng, l_rng)
         del pk
-        # witness shaped like the wrapping circuit's: 1.3 % of its 45,958 variables are 0 or 1 (measured on the real
+        # witness shaped like the wrapping circuit's: 1.3 % of its 44,188 variables are 0 or 1 (measured on the real
         # batch-2 witness: 590 zeros, 27 ones - the variables are Fq elements of the in-circuit pairing), the rest uniform
         z = random_fr_canonical(99, m)
         sel = rng.random(m)

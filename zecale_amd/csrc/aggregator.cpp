@@ -40,6 +40,7 @@ extern "C" int zkhip_bls12_377_groth16_verify(const uint64_t vk_alpha_g1[12], co
       for (int j = 0; j < 253; j++) bits[k].push_back(NF::witness_bit((c[j / 64] >> (j % 64)) & 1));
     }
     G1<NF> acc = input_accumulator(vk, bits);
+    vk_precompute(vk);
     *ok = groth16_verify_bit(vk, pr, acc).value().is_zero() ? 0 : 1;
   } catch (const std::exception&) {
     *ok = 0;
@@ -84,13 +85,14 @@ struct NestedData {
   const uint64_t* inputs;    // num_proofs x k x 6
 };
 
-// The circuit in three kinds of sections, allocated in this order:
+// The circuit in four kinds of sections, allocated in this order:
 //   inputs:   primary inputs (vk hash, packed results, nested inputs), then the nested key and proofs
 //   hash:     MiMC of the key's variables                          -> value of primary input 0
+//   key:      the lines of -beta and -delta (vk_precompute), shared by every proof of the batch (aggregator_gadget.tcc:93)
 //   proof p:  253 bits per nested input, accumulator, verification -> result bit p
-// With V = CV one pass emits constraints and the assignment.  With V = WV (assignment only) the hash section and
-// the proof sections only READ the input section's values, so they run on separate host threads, each filling its
-// own slice of the assignment; concatenated in section order they reproduce the circuit's variable numbering.
+// With V = CV one pass emits constraints and the assignment.  With V = WV (assignment only) the sections only READ values
+// of earlier sections, so they run on separate host threads (the proof sections start when the key section is done), each
+// filling its own slice of the assignment; concatenated in section order they reproduce the circuit's variable numbering.
 template <class V>
 struct Inputs {
   V vk_hash, packed;
@@ -158,6 +160,7 @@ void synthesize(Builder& b, size_t num_proofs, size_t k, const NestedData* data)
   alloc_inputs(in, num_proofs, k, data);
   V h = section_hash(in);
   b.z[1] = h.value();
+  vk_precompute(in.vk);
   V packed_lc;
   HFr pow2 = HFr::one();
   for (size_t p = 0; p < num_proofs; p++) {
@@ -177,29 +180,35 @@ void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const Ne
   Inputs<WV> in;
   alloc_inputs(in, num_proofs, k, data);
   current_builder() = nullptr;
-  std::vector<std::vector<HFr>> parts(num_proofs + 1);
-  std::vector<HFr> results(num_proofs + 1);
+  // sections: 0 = hash, 1 = key lines, 2 + p = proof p
+  const size_t ns = num_proofs + 2;
+  std::vector<std::vector<HFr>> parts(ns);
+  std::vector<HFr> results(ns);
+  std::vector<std::exception_ptr> errs(ns);
+  auto run = [&](size_t s) {
+    try {
+      Builder bs;
+      bs.z.clear();                                     // a section holds no constant ONE of its own
+      current_builder() = &bs;
+      if (s == 0) results[s] = section_hash(in).value();
+      else if (s == 1) vk_precompute(in.vk);
+      else results[s] = section_proof(in, s - 2, k).value();
+      current_builder() = nullptr;
+      parts[s] = std::move(bs.z);
+    } catch (...) { errs[s] = std::current_exception(); current_builder() = nullptr; }
+  };
+  std::thread t_hash(run, 0);
+  run(1);                                               // the proof sections read the key's lines
   std::vector<std::thread> th;
-  std::vector<std::exception_ptr> errs(num_proofs + 1);
-  for (size_t s = 0; s <= num_proofs; s++) {
-    th.emplace_back([&, s]() {
-      try {
-        Builder bs;
-        bs.z.clear();                                     // a section holds no constant ONE of its own
-        current_builder() = &bs;
-        results[s] = (s == 0) ? section_hash(in).value() : section_proof(in, s - 1, k).value();
-        current_builder() = nullptr;
-        parts[s] = std::move(bs.z);
-      } catch (...) { errs[s] = std::current_exception(); current_builder() = nullptr; }
-    });
-  }
+  if (!errs[1]) for (size_t s = 2; s < ns; s++) th.emplace_back(run, s);
+  t_hash.join();
   for (auto& t : th) t.join();
   for (auto& e : errs) if (e) std::rethrow_exception(e);
   z = std::move(b0.z);
   for (auto& p : parts) z.insert(z.end(), p.begin(), p.end());
   z[1] = results[0];
   HFr packed = HFr::zero(), pow2 = HFr::one();
-  for (size_t p = 0; p < num_proofs; p++) { packed = packed + results[p + 1] * pow2; pow2 = pow2 + pow2; }
+  for (size_t p = 0; p < num_proofs; p++) { packed = packed + results[p + 2] * pow2; pow2 = pow2 + pow2; }
   z[2] = packed;
 }
 

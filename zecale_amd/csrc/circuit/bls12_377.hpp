@@ -36,54 +36,70 @@ template <class F> inline G1<F> g1_select(const F& bit, const G1<F>& a, const G1
   return G1<F>{f_select(bit, a.x, b.x), f_select(bit, a.y, b.y)};
 }
 
-// Line through psi(T) with slope lambda' w, evaluated at P in G1:  yP - lambda' xP w + (lambda' xT - yT) w^3
-template <class F> inline Fq12<F> line_eval(const Fq2<F>& lam, const Fq2<F>& xT, const Fq2<F>& yT, const G1<F>& P) {
+// ---- Miller loop over precomputed lines ---------------------------------------------------------------------------------
+// The line through psi(T) with slope lambda' w, evaluated at P in G1, is  yP - lambda' xP w + (lambda' xT - yT) w^3.
+// Everything that depends on the G2 argument only - the chain of points T, the slopes, b = lambda' xT - yT - is computed ONCE per
+// G2 point (g2_precompute): 13 of the 15 constraints of a step.  The nested key's beta and delta are shared by all proofs of a
+// batch (the reference precomputes the key the same way: aggregator_gadget.tcc:93), the generator's lines are constants.
+template <class F> struct LineCoeffs { Fq2<F> lam, b; };
+template <class F> using G2Lines = std::vector<LineCoeffs<F>>;          // Miller-schedule order: per bit of u a doubling, then an addition if set
+
+// Walks the schedule for several G2 points in lock-step: the slopes of one step need one Fq2 inversion each, all independent, so they
+// share one field inversion (batch_inv).
+template <class F> inline std::vector<G2Lines<F>> g2_precompute(const std::vector<G2<F>>& Qs) {
+  const int n = (int)Qs.size();
+  std::vector<G2<F>> T = Qs;
+  std::vector<G2Lines<F>> out(n);
+  HFr ninv[8];
+  for (int i = 62; i >= 0; i--) {
+    for (int k = 0; k < n; k++) ninv[k] = v2_norm(v2_of(T[k].y + T[k].y));
+    batch_inv(ninv, n);
+    for (int k = 0; k < n; k++) {
+      Fq2<F> xx = T[k].x.sqr();
+      Fq2<F> lam = fq2_div(xx + xx + xx, T[k].y + T[k].y, &ninv[k]);
+      out[k].push_back(LineCoeffs<F>{lam, lam * T[k].x - T[k].y});
+      Fq2<F> x3 = fq2_sqr_minus(lam, T[k].x + T[k].x);
+      Fq2<F> y3 = fq2_mul_minus(lam, T[k].x - x3, T[k].y);
+      T[k].x = x3; T[k].y = y3;
+    }
+    if ((BLS_U >> i) & 1) {
+      for (int k = 0; k < n; k++) ninv[k] = v2_norm(v2_of(Qs[k].x - T[k].x));
+      batch_inv(ninv, n);
+      for (int k = 0; k < n; k++) {
+        Fq2<F> lam = fq2_div(Qs[k].y - T[k].y, Qs[k].x - T[k].x, &ninv[k]);
+        out[k].push_back(LineCoeffs<F>{lam, lam * T[k].x - T[k].y});
+        Fq2<F> x3 = fq2_sqr_minus(lam, T[k].x + Qs[k].x);
+        Fq2<F> y3 = fq2_mul_minus(lam, T[k].x - x3, T[k].y);
+        T[k].x = x3; T[k].y = y3;
+      }
+    }
+  }
+  return out;
+}
+
+template <class F> inline Fq12<F> line_at(const LineCoeffs<F>& lc, const G1<F>& P) {
   Fq12<F> l;
-  Fq2<F> a = lam.mul_base(P.x).neg();
-  Fq2<F> b = lam * xT - yT;
+  Fq2<F> a = lc.lam.mul_base(P.x).neg();
   l.c[0] = P.y;
   l.c[1] = a.c0; l.c[7] = a.c1;
-  l.c[3] = b.c0; l.c[9] = b.c1;
+  l.c[3] = lc.b.c0; l.c[9] = lc.b.c1;
   return l;
 }
 
-template <class F> struct MillerState { G2<F> T; G2<F> Q; G1<F> P; };
-
-template <class F> inline Fq12<F> miller_dbl_step(MillerState<F>& s, const HFr* den_norm_inv = nullptr) {
-  Fq2<F> xx = s.T.x.sqr();
-  Fq2<F> lam = fq2_div(xx + xx + xx, s.T.y + s.T.y, den_norm_inv);
-  Fq12<F> l = line_eval(lam, s.T.x, s.T.y, s.P);
-  Fq2<F> x3 = fq2_sqr_minus(lam, s.T.x + s.T.x);
-  Fq2<F> y3 = fq2_mul_minus(lam, s.T.x - x3, s.T.y);
-  s.T.x = x3; s.T.y = y3;
-  return l;
-}
-template <class F> inline Fq12<F> miller_add_step(MillerState<F>& s, const HFr* den_norm_inv = nullptr) {
-  Fq2<F> lam = fq2_div(s.Q.y - s.T.y, s.Q.x - s.T.x, den_norm_inv);
-  Fq12<F> l = line_eval(lam, s.T.x, s.T.y, s.P);
-  Fq2<F> x3 = fq2_sqr_minus(lam, s.T.x + s.Q.x);
-  Fq2<F> y3 = fq2_mul_minus(lam, s.T.x - x3, s.T.y);
-  s.T.x = x3; s.T.y = y3;
-  return l;
-}
+template <class F> struct MillerPair { const G2Lines<F>* lines; G1<F> P; };
 
 // prod_i f_{u,Q_i}(P_i): one shared accumulator (one squaring per bit for the whole product)
-template <class F> inline Fq12<F> multi_miller_loop(std::vector<MillerState<F>>& ps) {
+template <class F> inline Fq12<F> multi_miller_loop(const std::vector<MillerPair<F>>& ps) {
   Fq12<F> f = Fq12<F>::one();
-  for (auto& s : ps) s.T = s.Q;
   bool first = true;
+  size_t idx = 0;
   for (int i = 62; i >= 0; i--) {
     if (!first) f = f.sqr();
-    // the slopes of the (up to 8) pairings of this step need one Fq2 inversion each, all independent: one field inversion for all
-    HFr ninv[8];
-    const int np = (int)ps.size();
-    for (int k = 0; k < np; k++) ninv[k] = v2_norm(v2_of(ps[k].T.y + ps[k].T.y));
-    batch_inv(ninv, np);
-    for (int k = 0; k < np; k++) { Fq12<F> l = miller_dbl_step(ps[k], &ninv[k]); f = first ? l : fq12_mul_line(f, l); first = false; }
+    for (const auto& s : ps) { Fq12<F> l = line_at((*s.lines)[idx], s.P); f = first ? l : fq12_mul_line(f, l); first = false; }
+    idx++;
     if ((BLS_U >> i) & 1) {
-      for (int k = 0; k < np; k++) ninv[k] = v2_norm(v2_of(ps[k].Q.x - ps[k].T.x));
-      batch_inv(ninv, np);
-      for (int k = 0; k < np; k++) f = fq12_mul_line(f, miller_add_step(ps[k], &ninv[k]));
+      for (const auto& s : ps) f = fq12_mul_line(f, line_at((*s.lines)[idx], s.P));
+      idx++;
     }
   }
   return f;
@@ -137,7 +153,10 @@ struct BlsG2Gen {
 };
 inline const BlsG2Gen& bls_g2_gen() { static BlsG2Gen g; return g; }
 
-template <class F> struct NestedVk { G1<F> alpha; G2<F> beta, delta; std::vector<G1<F>> abc; };
+template <class F> struct NestedVk {
+  G1<F> alpha; G2<F> beta, delta; std::vector<G1<F>> abc;
+  G2Lines<F> neg_beta_lines, neg_delta_lines;       // vk_precompute: shared by every proof verified under this key
+};
 template <class F> struct NestedProof { G1<F> a; G2<F> b; G1<F> c; };
 
 template <class F> inline G2<F> g2_neg(const G2<F>& p) { return G2<F>{p.x, p.y.neg()}; }
@@ -162,14 +181,19 @@ template <class F> inline G1<F> input_accumulator(const NestedVk<F>& vk, const s
 // 1 / 0 : e(A,B) e(acc,-G2_one) e(alpha,-beta) e(C,-delta) == 1
 // (reference: the check the online verifier gadget performs; result is NOT enforced to be 1:
 //  aggregator_circuit.hpp:51-54)
+// the part of a verification that depends on the key only (libsnark's "processed verification key")
+template <class F> inline void vk_precompute(NestedVk<F>& vk) {
+  std::vector<G2Lines<F>> l = g2_precompute<F>({g2_neg(vk.beta), g2_neg(vk.delta)});
+  vk.neg_beta_lines = std::move(l[0]);
+  vk.neg_delta_lines = std::move(l[1]);
+}
+
 template <class F> inline F groth16_verify_bit(const NestedVk<F>& vk, const NestedProof<F>& pr, const G1<F>& acc) {
+  if (vk.neg_beta_lines.empty()) throw std::runtime_error("vk_precompute has not run");
   const BlsG2Gen& g = bls_g2_gen();
   G2<F> gen{Fq2<F>::constant(g.x0, g.x1), Fq2<F>::constant(g.y0, g.y1)};
-  std::vector<MillerState<F>> ps(4);
-  ps[0].Q = pr.b; ps[0].P = pr.a;
-  ps[1].Q = g2_neg(gen); ps[1].P = acc;
-  ps[2].Q = g2_neg(vk.beta); ps[2].P = vk.alpha;
-  ps[3].Q = g2_neg(vk.delta); ps[3].P = pr.c;
+  std::vector<G2Lines<F>> own = g2_precompute<F>({pr.b, g2_neg(gen)});       // the proof's B; the generator's lines are constants
+  std::vector<MillerPair<F>> ps = {{&own[0], pr.a}, {&own[1], acc}, {&vk.neg_beta_lines, vk.alpha}, {&vk.neg_delta_lines, pr.c}};
   Fq12<F> f = multi_miller_loop(ps);
   return fq12_is_one(final_exponentiation(f));
 }
