@@ -2,7 +2,7 @@
 //   Fq2  = Fq[u]  / (u^2 + 5)
 //   Fq12 = Fq[w]  / (w^12 + 5),  u = w^6       (direct degree-12 extension: -5 is neither a square nor a cube in
 //                                                Fq, q = 1 mod 12, and 5/4 is not a fourth power - checked in
-//                                                tests/test_circuit_host.py against big integers)
+//                                                tests/test_circuit_algebra.py against big integers)
 // The direct representation makes the Frobenius maps coefficient-wise scalings by constants (free in a circuit)
 // and lets a full Fq12 multiplication cost 23 constraints: c(X) = a(X) b(X) has degree 22, so it is pinned by
 // a(x_k) b(x_k) = c(x_k) at 23 points, and the reduction modulo w^12 + 5 is linear.
