@@ -1,0 +1,51 @@
+"""Soak run of the streaming prover on the GPU box: N batches with varying nested proofs, inputs (some bumped -> invalid nested
+proof -> result bit 0) and (r, s); every wrapping proof is verified with the host pairing verifier and its public inputs checked.
+Usage: python tools/soak_pipeline.py [N]"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zecale_amd import encoding as E
+from zecale_amd import zkhip
+import bench
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+zkhip.init(0)
+gold = os.path.join(bench.ROOT, "tests", "golden", "dummy_app")
+load = lambda n: json.load(open(os.path.join(gold, n)))
+nvk = E.nested_verification_key_from_json(load("vk.json"))
+txs = [E.nested_transaction_from_json(load("extproof%d.json" % k)) for k in range(1, 7)]
+_, _, _, trapdoor = bench.aggregator_inputs()
+agg = zkhip.AggregatorCircuit(2, 1)
+kp = zkhip.Keypair(zkhip.r1cs_desc_from_aggregator(agg), *trapdoor)
+vk, crs = kp.vk(), kp.upload_crs()
+pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=6, witness_workers=8)
+rng = np.random.default_rng(1)
+rs = bench.random_fr_canonical(77, 2 * N)
+jobs, bad, t0 = [], 0, time.time()
+for i in range(N):
+    a, b = rng.integers(0, 6, 2)
+    bump = [int(rng.random() < 0.2), int(rng.random() < 0.2)]
+    nin = np.concatenate([txs[a][2], txs[b][2]]).copy()
+    one = np.array(E.fr_from_json("0x" + "0" * 95 + "1"), dtype=np.uint64)
+    expect = 0
+    for p in range(2):
+        if bump[p]:
+            x = int(E.fr_to_json(nin[p]), 16) + 1
+            nin[p] = np.array(E.fr_from_json(hex(x)), dtype=np.uint64)
+        else:
+            expect |= 1 << p
+    jobs.append((pipe.submit(nvk, np.concatenate([txs[a][1], txs[b][1]]), nin, rs[2 * i], rs[2 * i + 1]), expect, nin))
+    if len(jobs) > 32:
+        t, exp, nin_ = jobs.pop(0)
+        prim, proof = pipe.wait(t)
+        ok = zkhip.groth16_verify(vk, prim, proof) and int(E.fr_to_json(prim[1]), 16) == exp and (prim[2:] == nin_.reshape(-1, 6)).all()
+        bad += 0 if ok else 1
+while jobs:
+    t, exp, nin_ = jobs.pop(0)
+    prim, proof = pipe.wait(t)
+    ok = zkhip.groth16_verify(vk, prim, proof) and int(E.fr_to_json(prim[1]), 16) == exp and (prim[2:] == nin_.reshape(-1, 6)).all()
+    bad += 0 if ok else 1
+dt = time.time() - t0
+print(f"soak: {N} wrapping proofs in {dt:.1f} s ({N/dt:.1f} proofs/s including host verification of each), failures: {bad}")
+pipe.free(); crs.free(); kp.free(); agg.free()
+sys.exit(1 if bad else 0)
