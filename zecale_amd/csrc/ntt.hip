@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(tile_threads(LOGK)) k_ntt_tile(TileArgs a) {
       uint32_t gi = b * a.in_b + j * a.in_j;
       FrD v = fr_load12(a.src + (size_t)gi * 12);
       if (a.pre_lo) v = fp_mul(v, pow_tab(a.pre_lo, a.pre_hi, gi));
-      uint32_t rj = __brev(j) >> (32 - LOGK);
+      uint32_t rj = LOGK ? (__brev(j) >> ((32 - LOGK) & 31)) : 0u;     // (LOGK = 0: a transform of size 1)
 #pragma unroll
       for (int i = 0; i < 14; i++) lds[i * K + rj] = v.l[i];
     }
