@@ -111,7 +111,11 @@ int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1) {
   if (*ready && cx->max_n >= n && cx->c == c && cx->merged == merged && cx->K == K) return ZKHIP_OK;
   if (*ready) { msm_plan_free(cx); *ready = false; }
   int rc = msm_plan_init(cx, n, c, merged, K);
-  if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "msm_plan_init: %s", cx->errbuf); return rc; }
+  if (rc != ZKHIP_OK) {
+    snprintf(t_err, sizeof t_err, "msm_plan_init: %s", cx->errbuf);
+    msm_plan_free(cx);          // whatever was allocated before the failure
+    return rc;
+  }
   *ready = true;
   return ZKHIP_OK;
 }
