@@ -136,3 +136,48 @@ def test_key_partitioned_prover_matches_whole_key(zk):
     assert (got == expect).all()
     assert zk.groth16_verify(pk["vk"], zl[1:1 + n_primary], got)
     whole.free(); r1.free()
+
+
+def test_full_size_2_20_key_modes_agree(zk):
+    """BASELINE configs[2] size.  No oracle finishes a 2^20-constraint proof in seconds, so the full-size check is a consistency
+    property: the three key modes (window tables + one launch sequence for the five MSMs, window tables + one launch sequence per
+    MSM, plain base sets) are three different schedules of the same sums and must return the SAME proof, limb for limb; the small
+    circuits above pin each mode against the oracle and the trapdoor closed form."""
+    import bench
+    n = (1 << 20) - 8
+    m, l = n + 5, 4
+    rng = np.random.default_rng(7)
+
+    def rand_csr(terms):
+        cols = rng.integers(0, m, size=(n, terms), dtype=np.uint32).reshape(-1)
+        rp = (np.arange(n + 1, dtype=np.uint32) * terms)
+        return rp, cols, bench.random_fr_canonical(int(rng.integers(1 << 30)), n * terms)
+    csr = (rand_csr(2), rand_csr(2), rand_csr(2))
+    r1 = zk.R1cs(*csr, m, l)
+    d = 1 << r1.log_d
+    assert d == 1 << 20
+    g1 = bench.g1_generator_limbs()
+    consts = dict(alpha_g1=g1, beta_g1=g1, beta_g2=g1, delta_g1=g1, delta_g2=g1)
+    pk = dict(consts)
+    for key, cnt, seed in (("A", m, 1), ("B2", m, 2), ("B1", m, 3), ("H", d - 1, 4), ("L", m - l - 1, 5)):
+        pk[key] = zk.fixed_base_mul(g1, bench.random_fr_canonical(seed * 7919, cnt), montgomery=False)
+    pk["B2"][::3] = 0                                   # a sparse B query, as a real key has
+    pk["B1"][::3] = 0
+    z = bench.random_fr_canonical(99, m)
+    z[::50] = 0
+    z[0] = np.array(bench.zkhip_fr_one(), dtype=np.uint64)
+    r, s = bench.random_fr_canonical(5, 1)[0], bench.random_fr_canonical(6, 1)[0]
+    proofs = {}
+    try:
+        for mode in ("tables+batched", "tables", "plain"):
+            zk.set_crs_precompute(mode != "plain")
+            zk.set_batch_msms(mode == "tables+batched")
+            crs = zk.Crs(pk, m, l, d)
+            proofs[mode] = zk.groth16_prove(crs, r1, z, r, s)
+            crs.free()
+    finally:
+        zk.set_crs_precompute(True)
+        zk.set_batch_msms(True)
+    assert (proofs["tables+batched"] == proofs["tables"]).all() and (proofs["tables"] == proofs["plain"]).all()
+    assert proofs["plain"][:24].any()
+    r1.free()
