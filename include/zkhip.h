@@ -14,7 +14,14 @@
  *   - Jacobian points: X, Y, Z (36 limbs), infinity <=> Z = 0.  Both G1 and G2 of BW6-761 are
  *     over Fq, so every point entry point serves both groups.
  *   - All functions return ZKHIP_OK (0) or a negative error code; no exceptions cross the ABI.
- *   - One context per process; calls are serialised by the caller (not re-entrant).
+ *   - Devices: zkhip_init(device) once per GPU the process uses.  Every handle (base set, proving key, constraint
+ *     system, prover) remembers the GPU it was created on and every entry point binds the CALLING THREAD to that
+ *     GPU first (HIP's current device is per host thread), so handles may be used from any thread.  Entry points
+ *     without a handle run on the calling thread's library device: zkhip_set_device, default = the first GPU
+ *     initialised.  One process can drive all GPUs of a node this way (the reference server is one process:
+ *     aggregator_server/aggregator_server.cpp:390-416).
+ *   - The handle-less entry points and the ones that share the library's own work space are serialised per GPU
+ *     by the library; zkhip_prover / zkhip_pipeline instances run side by side.
  *   - `_dev` variants take DEVICE pointers (e.g. torch tensor data_ptr()); the others take host
  *     pointers and stage through HBM themselves.
  */
@@ -38,6 +45,9 @@ typedef struct zkhip_bases zkhip_bases; /* opaque: a base-point set resident in 
 /* replaces: libff::bw6_761_pp::init_public_params() + device selection
  * (aggregator_server/aggregator_server.cpp:476-477) */
 int zkhip_init(int device);
+/* library device of the calling thread for the entry points that take no handle (the device must be initialised) */
+int zkhip_set_device(int device);
+int zkhip_get_device(void);              /* -1 before the first zkhip_init */
 void zkhip_shutdown(void);
 const char* zkhip_strerror(int code);
 const char* zkhip_last_error(void);
@@ -213,6 +223,12 @@ int zkhip_aggregator_get_r1cs(const zkhip_aggregator* a, zkhip_r1cs_desc* out);
  * z = (1, primary, auxiliary), n_vars x 6 limbs; primary = [vk hash, packed results, nested inputs ...] */
 int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, const uint64_t* nested_proofs,
                              const uint64_t* nested_inputs, uint64_t* z_out);
+/* replaces: the well-formedness checks libsnark applies to a proof before it is used (proof.is_well_formed(); in the circuit:
+ * the G1 / G2 checker gadgets of r1cs_gg_ppzksnark_proof_variable, groth16_verifier_parameters.hpp:16-27): *ok = 1 iff every
+ * point of the nested key and of the nested proofs lies on its curve (BLS12-377 G1: y^2 = x^3 + 1, G2: y^2 = x^3 + 1/u).
+ * zkhip_aggregator_witness itself computes an assignment for ANY input; for an off-curve proof point that assignment violates
+ * the circuit's curve constraints (no wrapping proof exists).  The streaming prover and the C++ mirror call this first. */
+int zkhip_aggregator_check_inputs(const zkhip_aggregator* a, const uint64_t* nested_vk, const uint64_t* nested_proofs, int* ok);
 /* replaces: verification_key_hash_gadget::compute_hash(vk, num_inputs) (verification_key_hash_gadget.tcc:42-59) */
 int zkhip_aggregator_vk_hash(const uint64_t* nested_vk, size_t inputs_per_proof, uint64_t out[6]);
 

@@ -573,3 +573,102 @@ def bls12_377_groth16_verify(vk, proof, inputs):
     return bls12_377_pairing_product_is_one([
         (proof["a"], proof["b"]), (acc, bls_g2_neg(BLS_G2_GEN)),
         (vk["alpha"], bls_g2_neg(vk["beta"])), (proof["c"], bls_g2_neg(vk["delta"]))])
+
+
+# --------------------------------------------------------------------------------------------------
+# MiMC-e17/r93 Miyaguchi-Preneel hash of the nested verification key (primary input 0 of a wrapping proof).
+# Restates libzecale/circuits/verification_key_hash_gadget.tcc:42-59 (compute_hash: mimc_input_hasher over
+# verification_key.get_all_vars()) with the compression function picked by compression_function_selector.hpp:23-31
+# (MiMC_mp_gadget over MiMC_permutation_gadget<Fr, 17, 93>).  libzeth's round constants and IV are not in the reference
+# tree, so the constants are this build's own: SHA-256 chains of fixed strings (stated below).  This is a
+# second, independent implementation (hashlib + Python integers) of what zecale_amd/csrc/circuit/mimc.hpp computes natively
+# and constrains in the circuit; tests compare the two.
+MIMC_ROUNDS = 93
+MIMC_EXPONENT = 17
+
+
+def _mimc_constants():
+    import hashlib
+    d = hashlib.sha256(b"zecale-amd/mimc-e17-r93/round-constants").digest()
+    cs = [0]                                    # MiMC convention: first round constant 0
+    for _ in range(1, MIMC_ROUNDS):
+        d = hashlib.sha256(d).digest()
+        cs.append(int.from_bytes(d, "big") % R_MOD)
+    iv = int.from_bytes(hashlib.sha256(b"zecale-amd/mimc-e17-r93/iv").digest(), "big") % R_MOD
+    return cs, iv
+
+
+MIMC_CONSTANTS, MIMC_IV = _mimc_constants()
+
+
+def mimc_permutation(m, k):
+    """E_k(m): 93 rounds x <- (x + k + c_i)^17, then + k."""
+    x = m % R_MOD
+    for c in MIMC_CONSTANTS:
+        x = pow((x + k + c) % R_MOD, MIMC_EXPONENT, R_MOD)
+    return (x + k) % R_MOD
+
+
+def mimc_mp(m, h):
+    """Miyaguchi-Preneel compression: h' = E_h(m) + h + m."""
+    return (mimc_permutation(m, h) + h + m) % R_MOD
+
+
+def mimc_hash(values):
+    """h_0 = IV; absorb every element; absorb the length last."""
+    h = MIMC_IV
+    for m in values:
+        h = mimc_mp(m % R_MOD, h)
+    return mimc_mp(len(values), h)
+
+
+def nested_vk_all_vars(vk):
+    """verification_key.get_all_vars() order used by the hash (verification_key_hash_gadget.tcc:22-26): alpha (x, y), beta
+    (x.c0, x.c1, y.c0, y.c1), delta (same), ABC_0.. (x, y).  vk as bls12_377_groth16_verify takes it."""
+    v = [vk["alpha"][0], vk["alpha"][1]]
+    for key in ("beta", "delta"):
+        (x0, x1), (y0, y1) = vk[key]
+        v += [x0, x1, y0, y1]
+    for p in vk["ABC"]:
+        v += [p[0], p[1]]
+    return v
+
+
+def nested_vk_hash(vk):
+    return mimc_hash(nested_vk_all_vars(vk))
+
+
+# R1CS-level view of a constraint system in CSR form (row_ptr, col, val as Python ints): row values and, for a mutated
+# assignment, the rows that stop holding.  Used to check the wrapping circuit for variables that no constraint pins.
+def r1cs_row_values(rp, col, val, z):
+    out = []
+    for j in range(len(rp) - 1):
+        acc = 0
+        for k in range(rp[j], rp[j + 1]):
+            acc += val[k] * z[col[k]]
+        out.append(acc % R_MOD)
+    return out
+
+
+def r1cs_column_index(mats, n_vars):
+    """per variable: list of (matrix 0/1/2, row, coefficient)"""
+    idx = [[] for _ in range(n_vars)]
+    for mi, (rp, col, val) in enumerate(mats):
+        for j in range(len(rp) - 1):
+            for k in range(rp[j], rp[j + 1]):
+                idx[col[k]].append((mi, j, val[k]))
+    return idx
+
+
+def r1cs_violations_after_delta(colidx, rows, var, delta):
+    """Rows that are violated after z[var] += delta, given the row values `rows` = (a, b, c) of the unmutated assignment."""
+    touched = {}
+    for mi, j, coeff in colidx[var]:
+        t = touched.setdefault(j, [0, 0, 0])
+        t[mi] = (t[mi] + coeff * delta) % R_MOD
+    bad = []
+    for j, (da, db, dc) in touched.items():
+        a, b, c = rows[0][j] + da, rows[1][j] + db, rows[2][j] + dc
+        if (a * b - c) % R_MOD != 0:
+            bad.append(j)
+    return bad

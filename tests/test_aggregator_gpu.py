@@ -152,3 +152,116 @@ def test_pipeline_submitter_is_not_blocked_by_uncollected_results(zk):
     assert len({bytes(proof) for _, proof in results}) == 12          # different (r, s): different proofs
     pipe.free()
     crs.free(); kp.free(); agg.free()
+
+
+def test_sixteen_batches_of_a_32_proof_round(zk):
+    """BASELINE configs[4] on one GPU: 32 nested proofs = 16 batch-2 wrapping proofs (the server's batch_size is a compile-time 2,
+    aggregator_server.cpp:71) submitted to the streaming prover at once; every wrapping proof verifies, carries the right
+    nested inputs and result bits, and three of the batches hold an invalid nested proof."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    vk = kp.vk()
+    crs = kp.upload_crs()
+    pipe = zk.AggregatorPipeline(agg, crs, gpu_slots=4, witness_workers=4)
+    jobs = []
+    for i in range(16):
+        a, b = (2 * i) % 6, (2 * i + 1 + i // 3) % 6
+        bump_a, bump_b = int(i == 5), int(i in (9, 14))
+        (pa, ia), (pb, ib) = proofs[a], proofs[b]
+        npr = np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)])
+        xs = [ia[0] + bump_a, ib[0] + bump_b]
+        jobs.append((xs, (0 if bump_a else 1) | (0 if bump_b else 2),
+                     pipe.submit(nvk_l, npr, np.array([fr_limbs(x) for x in xs]), fr_limbs(0x5151 + i), fr_limbs(0x7171 + 3 * i))))
+    h = zk.aggregator_vk_hash(nvk_l, 1)
+    for xs, bits, ticket in jobs:
+        prim, proof = pipe.wait(ticket)
+        assert zk.groth16_verify(vk, prim, proof)
+        assert (prim[0] == h).all() and fr_int(prim[1]) == bits and [fr_int(prim[2]), fr_int(prim[3])] == xs
+    pipe.free()
+    crs.free(); kp.free(); agg.free()
+
+
+def test_nine_inputs_per_nested_proof_on_the_gpu(zk):
+    """The Zeth-shaped workload of libzecale/tests/aggregator/aggregator_test.cpp:222-254 (9 primary inputs per nested proof):
+    circuit, trusted setup on the GPU, witness, wrapping proof, wsnark::verify.  No Zeth proofs are in the tree: the nested key is
+    padded with further G1 points of the fixtures, so the nested proofs are INVALID for it and the wrapping proof must carry result
+    bits 0 (aggregator_circuit.hpp:51-54) together with the 18 nested inputs."""
+    k = 9
+    agg = zk.AggregatorCircuit(2, k)
+    assert agg.num_primary_inputs() == 2 + 2 * k
+    desc = zk.r1cs_desc_from_aggregator(agg)
+    kp = zk.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
+    vk = kp.vk()
+    assert vk["ABC"].shape[0] == 2 + 2 * k + 1
+    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
+    nvk, proofs = load_nested_fixtures()
+    nvk9 = dict(nvk)
+    nvk9["ABC"] = list(nvk["ABC"]) + [proofs[i][0]["a"] for i in range(6)] + [proofs[0][0]["c"], proofs[1][0]["c"]]
+    nvk_l = nested_vk_limbs(nvk9)
+    xs = [[1000 * p + j for j in range(k)] for p in range(2)]
+    z = agg.witness(nvk_l, np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])]),
+                    np.array([fr_limbs(x) for row in xs for x in row]))
+    assert r1.is_satisfied(z)
+    proof = zk.groth16_prove(crs, r1, z, fr_limbs(0xabcdef), fr_limbs(0xfedcba))
+    prim = z[1:1 + agg.num_primary_inputs()]
+    assert zk.groth16_verify(vk, prim, proof)
+    assert fr_int(prim[0]) == R.nested_vk_hash(nvk9) and fr_int(prim[1]) == 0
+    assert [fr_int(x) for x in prim[2:]] == xs[0] + xs[1]
+    # the same batch through the streaming prover
+    pipe = zk.AggregatorPipeline(agg, crs, gpu_slots=2, witness_workers=2)
+    t = pipe.submit(nvk_l, np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])]),
+                    np.array([fr_limbs(x) for row in xs for x in row]), fr_limbs(0xabcdef), fr_limbs(0xfedcba))
+    prim2, proof2 = pipe.wait(t)
+    assert (prim2 == prim).all() and (proof2 == proof).all()
+    pipe.free()
+    crs.free(); r1.free(); kp.free(); agg.free()
+
+
+def test_off_curve_nested_proof_fails_its_batch_only(zk):
+    """A nested proof with a point off the curve has no wrapping proof (the circuit's curve constraints cannot be met): the
+    streaming prover reports an error for that ticket and keeps serving the others."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    crs = kp.upload_crs()
+    pipe = zk.AggregatorPipeline(agg, crs, gpu_slots=2, witness_workers=2)
+    (pa, ia), (pb, ib) = proofs[0], proofs[1]
+    good = np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)])
+    bad = good.copy(); bad[48 + 6] ^= np.uint64(1)             # y of the second proof's A
+    nin = np.array([fr_limbs(ia[0]), fr_limbs(ib[0])])
+    t_good = pipe.submit(nvk_l, good, nin, fr_limbs(3), fr_limbs(5))
+    t_bad = pipe.submit(nvk_l, bad, nin, fr_limbs(3), fr_limbs(5))
+    t_good2 = pipe.submit(nvk_l, good, nin, fr_limbs(4), fr_limbs(6))
+    with pytest.raises(zk.ZkhipError):
+        pipe.wait(t_bad)
+    for t in (t_good, t_good2):
+        prim, proof = pipe.wait(t)
+        assert zk.groth16_verify(kp.vk(), prim, proof)
+    pipe.free()
+    crs.free(); kp.free(); agg.free()
+
+
+def test_entry_points_bind_their_device_on_any_thread(zk):
+    """HIP's current device is per host thread: handles carry their device and every entry point binds the calling thread, so a
+    thread that never called zkhip_init (a gRPC handler, a pipeline worker) can prove."""
+    import threading
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
+    (pa, ia), (pb, ib) = proofs[0], proofs[1]
+    z = agg.witness(nvk_l, np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)]), np.array([fr_limbs(ia[0]), fr_limbs(ib[0])]))
+    expect = zk.groth16_prove(crs, r1, z, fr_limbs(7), fr_limbs(9))
+    out = {}
+
+    def worker():
+        try:
+            out["dev"] = zk.get_device()
+            out["proof"] = zk.groth16_prove(crs, r1, z, fr_limbs(7), fr_limbs(9))
+            pr = zk.Prover(crs, desc)
+            out["proof2"] = pr.prove(z, fr_limbs(7), fr_limbs(9))
+            pr.free()
+        except Exception as e:          # noqa: BLE001
+            out["err"] = e
+    t = threading.Thread(target=worker)
+    t.start(); t.join()
+    assert "err" not in out, out.get("err")
+    assert out["dev"] == 0 and (out["proof"] == expect).all() and (out["proof2"] == expect).all()
+    with pytest.raises(zk.ZkhipError):
+        zk.set_device(15)               # never initialised
+    crs.free(); r1.free(); kp.free(); agg.free()

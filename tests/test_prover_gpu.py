@@ -183,35 +183,50 @@ def test_full_size_2_20_key_modes_agree(zk):
     r1.free()
 
 
-def test_full_size_2_20_proof_verifies(zk):
-    """BASELINE configs[2] at full size, end to end: a satisfiable 2^20-constraint system (each constraint multiplies two earlier
-    variables into a new one), trusted setup on the GPU from a known trapdoor, witness, proof, and wsnark::verify == true with the
-    host pairing verifier (aggregator_dummy_test.cpp:61-62); a wrong public input must not verify."""
+def _full_size_proof_verifies(zk, log_n):
     from zecale_amd.encoding import R_MOD
-    n, l = (1 << 20) - 8, 4
+    n, l = (1 << log_n) - 8, 4
     m = n + l + 1
     rng = np.random.default_rng(11)
-    a_idx = np.empty(n, dtype=np.uint32); b_idx = np.empty(n, dtype=np.uint32)
     vals = [1, 3, 5, 7, 11] + [0] * n
     lo = rng.integers(0, 1 << 62, size=n)
+    grow = np.arange(l + 1, l + 1 + n, dtype=np.uint64)      # constraint i may use the l + 1 + i earlier variables
+    a_idx = (lo.astype(np.uint64) % grow).astype(np.uint32)
+    b_idx = ((lo.astype(np.uint64) >> np.uint64(31)) % grow).astype(np.uint32)
+    al, bl = a_idx.tolist(), b_idx.tolist()
     for i in range(n):                                   # earlier variables only: satisfiable by construction
-        a = int(lo[i] % (l + 1 + i)); b = int((lo[i] >> 31) % (l + 1 + i))
-        a_idx[i], b_idx[i] = a, b
-        vals[l + 1 + i] = vals[a] * vals[b] % R_MOD
+        vals[l + 1 + i] = vals[al[i]] * vals[bl[i]] % R_MOD
     shift = 1 << 384
-    z = np.array([[(v * shift % R_MOD >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(6)] for v in vals], dtype=np.uint64)
+    z = np.frombuffer(b"".join((v * shift % R_MOD).to_bytes(48, "little") for v in vals), dtype=np.uint64).reshape(m, 6).copy()
+    del vals
     one = z[0].copy()
     rp = np.arange(n + 1, dtype=np.uint32)
     ones = np.tile(one, (n, 1))
     A = (rp, a_idx, ones); B = (rp, b_idx, ones); C = (rp, np.arange(l + 1, m, dtype=np.uint32), ones)
     desc, keep = zk.make_r1cs_desc(A, B, C, m, l)
     r1 = zk.R1cs(A, B, C, m, l)
-    assert r1.log_d == 20 and r1.is_satisfied(z)
+    assert r1.log_d == log_n and r1.is_satisfied(z)
     kp = zk.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
     crs = kp.upload_crs()
     proof = zk.groth16_prove(crs, r1, z, fr_limbs(0xabcdef), fr_limbs(0xfedcba))
+    print("2^%d constraints:" % log_n, zk.last_prove_timings())
     vk = kp.vk()
     assert zk.groth16_verify(vk, z[1:1 + l], proof)
     bad = z[1:1 + l].copy(); bad[2] = fr_limbs(6)
     assert not zk.groth16_verify(vk, bad, proof)
+    zb = z.copy(); zb[m // 2] = fr_limbs(12345)          # a wrong witness is noticed by the satisfiability check (a6)
+    assert not r1.is_satisfied(zb)
     crs.free(); kp.free(); r1.free()
+
+
+def test_full_size_2_20_proof_verifies(zk):
+    """BASELINE configs[2] at full size, end to end: a satisfiable 2^20-constraint system (each constraint multiplies two earlier
+    variables into a new one), trusted setup on the GPU from a known trapdoor, witness, proof, and wsnark::verify == true with the
+    host pairing verifier (aggregator_dummy_test.cpp:61-62); a wrong public input must not verify."""
+    _full_size_proof_verifies(zk, 20)
+
+
+def test_full_size_2_22_proof_verifies(zk):
+    """BASELINE configs[3]'s size on ONE GPU (the 8-GPU form partitions this key): 2^22 constraints, 4.2 M-point query vectors with
+    their window tables (69 GB of HBM), the same end-to-end check as at 2^20."""
+    _full_size_proof_verifies(zk, 22)

@@ -1,6 +1,6 @@
 """Host-side wrapping circuit under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only: GPU sanitizers are not
 available on the pool).  tools/sanitize/witness_check.cpp builds the batch-2 circuit, generates the witness of the reference
-fixtures twice, checks all 44,157 constraints with the host field arithmetic and the key hash against primary input 0."""
+fixtures twice, checks all 44,183 constraints with the host field arithmetic and the key hash against primary input 0."""
 import os
 import subprocess
 
@@ -21,5 +21,5 @@ def test_witness_generator_is_clean_under_asan_ubsan(tmp_path):
                            os.path.join(ROOT, "zecale_amd", "csrc", "aggregator.cpp"), "-o", str(exe)])
     out = subprocess.run([str(exe), str(inp)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "constraints=44157 vars=44188 unsatisfied=0 hash_matches_input0=1" in out.stdout
+    assert "constraints=44183 vars=44206 unsatisfied=0 hash_matches_input0=1" in out.stdout
     assert "ERROR" not in out.stderr and "runtime error" not in out.stderr

@@ -33,6 +33,9 @@ extern "C" int zkhip_bls12_377_groth16_verify(const uint64_t vk_alpha_g1[12], co
     vk.delta = g2_from<NF>(vk_delta_g2, false);
     for (size_t i = 0; i <= n_inputs; i++) vk.abc.push_back(g1_from<NF>(vk_abc + i * 12, false));
     NestedProof<NF> pr{g1_from<NF>(proof_a, false), g2_from<NF>(proof_b, false), g1_from<NF>(proof_c, false)};
+    proof_assert_well_formed(pr);                     // off-curve points: rejected (libsnark proof.is_well_formed())
+    g1_assert_on_curve(vk.alpha); g2_assert_on_curve(vk.beta); g2_assert_on_curve(vk.delta);
+    for (const auto& q : vk.abc) g1_assert_on_curve(q);
     std::vector<std::vector<NF>> bits(n_inputs);
     for (size_t k = 0; k < n_inputs; k++) {
       uint64_t c[6];
@@ -148,6 +151,7 @@ template <class V> V section_proof(const Inputs<V>& in, size_t p, size_t k) {
     }
     V::assert_eq(sum, in.nin[p][j]);                      // packing (multipacking_gadget in the reference)
   }
+  proof_assert_well_formed(in.proofs[p]);                 // proof_variable_gadget's curve checks (13 constraints per proof)
   G1<V> acc = input_accumulator(in.vk, bits);
   return groth16_verify_bit(in.vk, in.proofs[p], acc);
 }
@@ -275,6 +279,23 @@ int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, con
   }
   if (z.size() != a->n_vars) return ZKHIP_ERR_STATE;
   for (size_t i = 0; i < z.size(); i++) z[i].to_limbs(z_out + i * 6);
+  return ZKHIP_OK;
+}
+
+int zkhip_aggregator_check_inputs(const zkhip_aggregator* a, const uint64_t* nested_vk, const uint64_t* nested_proofs, int* ok) {
+  if (!a || !nested_vk || !nested_proofs || !ok) return ZKHIP_ERR_ARG;
+  *ok = 1;
+  try {
+    g1_assert_on_curve(g1_from<NF>(nested_vk, false));
+    g2_assert_on_curve(g2_from<NF>(nested_vk + 12, false));
+    g2_assert_on_curve(g2_from<NF>(nested_vk + 36, false));
+    for (size_t i = 0; i <= a->inputs_per_proof; i++) g1_assert_on_curve(g1_from<NF>(nested_vk + 60 + i * 12, false));
+    for (size_t p = 0; p < a->num_proofs; p++)
+      proof_assert_well_formed(NestedProof<NF>{g1_from<NF>(nested_proofs + p * 48, false), g2_from<NF>(nested_proofs + p * 48 + 12, false),
+                                               g1_from<NF>(nested_proofs + p * 48 + 36, false)});
+  } catch (const std::exception&) {
+    *ok = 0;
+  }
   return ZKHIP_OK;
 }
 

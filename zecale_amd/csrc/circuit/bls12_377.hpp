@@ -32,6 +32,19 @@ template <class F> inline G1<F> g1_dbl(const G1<F>& p, const HFr* dinv = nullptr
   F y3 = f_mul_minus(lam, p.x - x3, p.y);
   return G1<F>{x3, y3};
 }
+// Curve membership of a witnessed point (the reference's proof variables carry libsnark's G1 / G2 checker gadgets,
+// groth16_verifier_parameters.hpp:16-27 -> r1cs_gg_ppzksnark_proof_variable): without it the chord-and-tangent arithmetic below
+// would run on points of ANOTHER curve y^2 = x^3 + b' (invalid-curve setting) and the result bit would not be bound to a valid
+// nested proof.   G1: y^2 = x^3 + 1  (3 constraints);   G2: y^2 = x^3 + 1/u over Fq2, 1/u = -u/5  (7 constraints).
+template <class F> inline void g1_assert_on_curve(const G1<F>& p) {
+  F xx = p.x * p.x, yy = p.y * p.y;
+  F::assert_product(xx, p.x, yy - f_one<F>());
+}
+template <class F> inline void g2_assert_on_curve(const G2<F>& p) {
+  Fq2<F> xx = p.x.sqr(), yy = p.y.sqr();
+  Fq2<F> b(f_zero<F>(), F::constant(small_consts().fifth_neg));
+  fq2_assert_mul(xx, p.x, yy - b);
+}
 template <class F> inline G1<F> g1_select(const F& bit, const G1<F>& a, const G1<F>& b) {
   return G1<F>{f_select(bit, a.x, b.x), f_select(bit, a.y, b.y)};
 }
@@ -186,6 +199,12 @@ template <class F> inline void vk_precompute(NestedVk<F>& vk) {
   std::vector<G2Lines<F>> l = g2_precompute<F>({g2_neg(vk.beta), g2_neg(vk.delta)});
   vk.neg_beta_lines = std::move(l[0]);
   vk.neg_delta_lines = std::move(l[1]);
+}
+
+template <class F> inline void proof_assert_well_formed(const NestedProof<F>& pr) {
+  g1_assert_on_curve(pr.a);
+  g2_assert_on_curve(pr.b);
+  g1_assert_on_curve(pr.c);
 }
 
 template <class F> inline F groth16_verify_bit(const NestedVk<F>& vk, const NestedProof<F>& pr, const G1<F>& acc) {

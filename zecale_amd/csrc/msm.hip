@@ -790,8 +790,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   const size_t B = ctx->B, nb = B * W;
   hipStream_t st = ctx->stream;
   ctx->pending_n = n_tot;
-  ctx->pending = true;
-  if (n_tot == 0) return ZKHIP_OK;
+  if (n_tot == 0) { ctx->pending = true; return ZKHIP_OK; }
   HIP_TRY(hipMemsetAsync(ctx->counts, 0, nb * 4, st));
   HIP_TRY(hipMemsetAsync(ctx->cursor, 0, nb * 4, st));
   WindowPlan plan;
@@ -943,6 +942,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ctx->win_host, ctx->win_abi, (size_t)W * 48 * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(ctx->ev_done, st));
+  ctx->pending = true;        // only a completely enqueued sequence is collectable; a failed launch leaves the context reusable
   return ZKHIP_OK;
 }
 

@@ -208,7 +208,9 @@ static std::map<int, NttTables>& table_cache() {
 }
 
 static int get_tables(int log_d, int inverse, NttTables** out, char* err, size_t errlen) {
-  int key = log_d * 2 + (inverse ? 1 : 0);
+  int dev = 0;
+  (void)hipGetDevice(&dev);                    // tables live in the memory of the calling thread's current device
+  int key = (dev * 64 + log_d) * 2 + (inverse ? 1 : 0);
   static std::mutex mu;                        // prover instances call in from several host threads
   std::lock_guard<std::mutex> lk(mu);
   auto& c = table_cache();

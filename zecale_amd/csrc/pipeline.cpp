@@ -58,7 +58,10 @@ void witness_loop(zkhip_pipeline* p) {
       p->q_wit.pop_front();
     }
     j->z.resize(p->n_vars * 6);
-    int rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
+    int wf = 0;
+    int rc = zkhip_aggregator_check_inputs(p->agg, j->vk.data(), j->proofs.data(), &wf);      // off-curve points: no proof exists
+    if (rc == ZKHIP_OK && !wf) rc = ZKHIP_ERR_ARG;
+    if (rc == ZKHIP_OK) rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
     std::lock_guard<std::mutex> lk(p->mu);
     if (rc != ZKHIP_OK) {
       j->rc = rc; j->done = true;

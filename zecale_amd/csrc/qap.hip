@@ -115,16 +115,16 @@ static int csr_upload(const uint32_t* row_ptr, const uint32_t* col, const uint64
     Q_HIP(hipMemcpy(out->col, col, nnz * 4, hipMemcpyHostToDevice));
     uint64_t* tmp;
     Q_HIP(hipMalloc(&tmp, nnz * 48));
-    Q_HIP(hipMemcpy(tmp, val, nnz * 48, hipMemcpyHostToDevice));
-    fr_abi_to_dev(tmp, out->val, nnz, 0);
-    Q_HIP(hipDeviceSynchronize());
-    Q_HIP(hipFree(tmp));
+    hipError_t e = hipMemcpy(tmp, val, nnz * 48, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { fr_abi_to_dev(tmp, out->val, nnz, 0); e = hipDeviceSynchronize(); }
+    (void)hipFree(tmp);
+    Q_HIP(e);
   }
   return ZKHIP_OK;
 }
 
+static int r1cs_upload_impl(const zkhip_r1cs_desc* d, R1csDev* r, char* err, size_t errlen);
 int r1cs_upload(const zkhip_r1cs_desc* d, R1csDev** out, char* err, size_t errlen) {
-  using host::HFr;
   if (!d || !out || d->n_vars < d->n_primary + 1) { snprintf(err, errlen, "r1cs_upload: bad descriptor"); return ZKHIP_ERR_ARG; }
   for (size_t k = 0; k < 3; k++) {
     const uint32_t* rp = k == 0 ? d->a_row_ptr : k == 1 ? d->b_row_ptr : d->c_row_ptr;
@@ -136,11 +136,19 @@ int r1cs_upload(const zkhip_r1cs_desc* d, R1csDev** out, char* err, size_t errle
       if (cl[j] >= d->n_vars) { snprintf(err, errlen, "r1cs_upload: column index out of range"); return ZKHIP_ERR_ARG; }
   }
   R1csDev* r = new R1csDev();
+  int rc = r1cs_upload_impl(d, r, err, errlen);
+  if (rc != ZKHIP_OK) { r1cs_free(r); return rc; }        // frees what was uploaded before the failure
+  *out = r;
+  return ZKHIP_OK;
+}
+
+static int r1cs_upload_impl(const zkhip_r1cs_desc* d, R1csDev* r, char* err, size_t errlen) {
+  using host::HFr;
   r->n_constraints = d->n_constraints; r->n_vars = d->n_vars; r->n_primary = d->n_primary;
   size_t need = d->n_constraints + d->n_primary + 1;
   int lg = 0;
   while (((size_t)1 << lg) < need) lg++;
-  if (lg > 22) { delete r; snprintf(err, errlen, "r1cs_upload: domain larger than 2^22"); return ZKHIP_ERR_ARG; }
+  if (lg > 22) { snprintf(err, errlen, "r1cs_upload: domain larger than 2^22"); return ZKHIP_ERR_ARG; }
   r->log_d = lg;
   size_t dd = (size_t)1 << lg;
   int rc;
@@ -158,7 +166,6 @@ int r1cs_upload(const zkhip_r1cs_desc* d, R1csDev** out, char* err, size_t errle
   FrD zd = fp_cond_sub_p(fp_from_abi<FrParams>(l));
   Q_HIP(hipMalloc(&r->zinv, 14 * 4));
   Q_HIP(hipMemcpy(r->zinv, zd.l, 14 * 4, hipMemcpyHostToDevice));
-  *out = r;
   return ZKHIP_OK;
 }
 

@@ -22,16 +22,19 @@ struct zkhip_bases {
   size_t len;
   int table_c;       // 0: plain base set
   size_t n_finite;   // bases that are not the point at infinity (counted at upload)
+  int device;        // the GPU that holds them
 };
 
 struct zkhip_r1cs {
   R1csDev* dev;
+  int device;
 };
 
 struct zkhip_crs {
   size_t n_vars, n_primary, domain_size;
   zkhip_bases *A, *B2, *B1, *H, *L;
   uint64_t alpha_g1[24], beta_g1[24], beta_g2[24], delta_g1[24], delta_g2[24];
+  int device;
 };
 
 struct zkhip_keypair {
@@ -60,21 +63,47 @@ struct ProveState {
   }
 };
 
-struct Lib {
+// One of these per GPU the process has initialised (zkhip_init(device), once per device).  HIP's current device is a
+// property of the calling HOST THREAD, so every entry point that touches the device binds its thread first: to the device of
+// the handle it is given (bases, key, constraint system, prover), or - for the entry points without a handle - to the
+// thread's current library device (zkhip_set_device; defaults to the first initialised device).
+constexpr int ZK_MAX_DEVICES = 16;
+struct DevState {
   bool inited = false;
-  int device = -1;
+  ProveState ps;            // work space of the plain (handle-less / library-serialised) entry points on this device
+  std::mutex mu;            // serialises them
+};
+struct Lib {
+  DevState dev[ZK_MAX_DEVICES];
+  int default_device = -1;
   int forced_c = 0;
   int crs_tables = 1;       // zkhip_crs_upload builds window tables (zkhip_set_crs_precompute)
   int batch_msms = 1;       // table-backed keys: the five MSMs of a proof in one launch sequence
-  ProveState ps;
-  std::mutex mu;
+  std::mutex mu;            // guards inited / default_device
 } g;
 thread_local char t_err[512] = {0};   // zkhip_last_error(): the calling thread's last failure
+thread_local int t_dev = -1;          // this thread's library device (-1: the default device)
 
 int fail(int code, const char* msg) {
   snprintf(t_err, sizeof t_err, "%s", msg);
   return code;
 }
+int cur_dev() { return t_dev >= 0 ? t_dev : g.default_device; }
+// bind the calling thread to device d (it must have been initialised)
+int bind_dev(int d) {
+  if (d < 0 || d >= ZK_MAX_DEVICES || !g.dev[d].inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called (for this device)");
+  hipError_t e = hipSetDevice(d);
+  if (e != hipSuccess) { snprintf(t_err, sizeof t_err, "hipSetDevice(%d): %s", d, hipGetErrorString(e)); return ZKHIP_ERR_HIP; }
+  return ZKHIP_OK;
+}
+#define BIND_CUR()  do { int rc_ = bind_dev(cur_dev()); if (rc_ != ZKHIP_OK) return rc_; } while (0)
+#define BIND(h)     do { int rc_ = bind_dev((h)->device); if (rc_ != ZKHIP_OK) return rc_; } while (0)
+// frees device / host allocations of an entry point on every exit path
+struct Scratch {
+  std::vector<void*> dev;
+  ~Scratch() { for (void* p : dev) if (p) (void)hipFree(p); }
+  hipError_t alloc(void** out, size_t bytes) { hipError_t e = hipMalloc(out, bytes ? bytes : 1); if (e == hipSuccess) dev.push_back(*out); return e; }
+};
 #define API_HIP(x)                                                                           \
   do {                                                                                       \
     hipError_t e_ = (x);                                                                     \
@@ -119,7 +148,6 @@ int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1) {
   *ready = true;
   return ZKHIP_OK;
 }
-int ensure_msm(size_t n, int table_c = 0) { return ensure_ctx(&g.ps.ctx[0], &g.ps.ready[0], n, table_c); }
 }  // namespace
 
 extern "C" {
@@ -129,7 +157,7 @@ int zkhip_init(int device) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0) return fail(ZKHIP_ERR_NO_DEVICE, "no HIP device (the gfx950 kernels are the only compute path)");
-  if (device < 0 || device >= count) return fail(ZKHIP_ERR_ARG, "device index out of range");
+  if (device < 0 || device >= count || device >= ZK_MAX_DEVICES) return fail(ZKHIP_ERR_ARG, "device index out of range");
   API_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   API_HIP(hipGetDeviceProperties(&prop, device));
@@ -137,15 +165,29 @@ int zkhip_init(int device) {
     snprintf(t_err, sizeof t_err, "device %d is %s, this library contains gfx950 code only", device, prop.gcnArchName);
     return ZKHIP_ERR_NO_DEVICE;
   }
-  g.device = device;
-  g.inited = true;
+  g.dev[device].inited = true;
+  if (g.default_device < 0) g.default_device = device;
+  t_dev = device;
   return ZKHIP_OK;
 }
 
+int zkhip_set_device(int device) {
+  int rc = bind_dev(device);
+  if (rc == ZKHIP_OK) t_dev = device;
+  return rc;
+}
+int zkhip_get_device(void) { return cur_dev(); }
+
 void zkhip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g.mu);
-  g.ps.release();
-  g.inited = false;
+  for (int d = 0; d < ZK_MAX_DEVICES; d++) {
+    if (!g.dev[d].inited) continue;
+    std::lock_guard<std::mutex> lkd(g.dev[d].mu);
+    if (hipSetDevice(d) == hipSuccess) g.dev[d].ps.release();
+    g.dev[d].inited = false;
+  }
+  g.default_device = -1;
+  t_dev = -1;
 }
 
 const char* zkhip_strerror(int code) {
@@ -168,7 +210,7 @@ int zkhip_set_msm_window(int c) {
 
 // device memory for callers without a HIP runtime of their own (the *_dev entry points take such pointers)
 int zkhip_device_alloc(size_t bytes, void** out) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
   if (!out) return fail(ZKHIP_ERR_ARG, "null pointer");
   API_HIP(hipMalloc(out, bytes ? bytes : 1));
   return ZKHIP_OK;
@@ -178,7 +220,7 @@ int zkhip_device_free(void* p) {
   return ZKHIP_OK;
 }
 int zkhip_device_copy_in(void* dst, const void* src, size_t bytes) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
   if (bytes && (!dst || !src)) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (bytes) {
     API_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
@@ -187,37 +229,42 @@ int zkhip_device_copy_in(void* dst, const void* src, size_t bytes) {
   return ZKHIP_OK;
 }
 
+static int bases_upload_dev_impl(const void* d_bases_affine, size_t len, zkhip_bases* b) {
+  if (!len) return ZKHIP_OK;
+  API_HIP(hipMalloc(&b->d_pts, len * sizeof(AffPacked)));
+  API_HIP(hipMalloc(&b->d_inf, len));
+  int rc = msm_bases_convert((const uint64_t*)d_bases_affine, len, b->d_pts, b->d_inf, t_err, sizeof t_err);
+  if (rc != ZKHIP_OK) return rc;
+  std::vector<uint8_t> flags(len);
+  API_HIP(hipMemcpy(flags.data(), b->d_inf, len, hipMemcpyDeviceToHost));
+  size_t inf = 0;
+  for (uint8_t f : flags) inf += f;
+  b->n_finite = len - inf;
+  return ZKHIP_OK;
+}
+
 int zkhip_bases_upload_dev(const void* d_bases_affine, size_t len, zkhip_bases** out) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
   if (!out || (len && !d_bases_affine)) return fail(ZKHIP_ERR_ARG, "null pointer");
-  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len, 0, len};
-  if (len) {
-    API_HIP(hipMalloc(&b->d_pts, len * sizeof(AffPacked)));
-    API_HIP(hipMalloc(&b->d_inf, len));
-    int rc = msm_bases_convert((const uint64_t*)d_bases_affine, len, b->d_pts, b->d_inf, t_err, sizeof t_err);
-    if (rc != ZKHIP_OK) return rc;
-    std::vector<uint8_t> flags(len);
-    API_HIP(hipMemcpy(flags.data(), b->d_inf, len, hipMemcpyDeviceToHost));
-    size_t inf = 0;
-    for (uint8_t f : flags) inf += f;
-    b->n_finite = len - inf;
-  }
+  const int dev = cur_dev();
+  std::lock_guard<std::mutex> lk(g.dev[dev].mu);
+  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len, 0, len, dev};
+  int rc = bases_upload_dev_impl(d_bases_affine, len, b);
+  if (rc != ZKHIP_OK) { zkhip_bases_free(b); return rc; }      // whatever was allocated before the failure
   *out = b;
   return ZKHIP_OK;
 }
 
 int zkhip_bases_upload(const uint64_t* bases_affine, size_t len, zkhip_bases** out) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
   if (!out || (len && !bases_affine)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  Scratch sc;
   void* d = nullptr;
   if (len) {
-    API_HIP(hipMalloc(&d, len * 192));
+    API_HIP(sc.alloc(&d, len * 192));
     API_HIP(hipMemcpy(d, bases_affine, len * 192, hipMemcpyHostToDevice));
   }
-  int rc = zkhip_bases_upload_dev(d, len, out);
-  if (d) (void)hipFree(d);
-  return rc;
+  return zkhip_bases_upload_dev(d, len, out);
 }
 
 size_t zkhip_bases_len(const zkhip_bases* b) { return b ? b->len : 0; }
@@ -226,9 +273,9 @@ int zkhip_set_crs_precompute(int on) { g.crs_tables = on ? 1 : 0; return ZKHIP_O
 int zkhip_set_batch_msms(int on) { g.batch_msms = on ? 1 : 0; return ZKHIP_OK; }
 
 int zkhip_bases_precompute(zkhip_bases* b, int c) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!b) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(b);
+  std::lock_guard<std::mutex> lk(g.dev[b->device].mu);
   if (b->table_c) return fail(ZKHIP_ERR_STATE, "base set already has a window table");
   if (c == 0) c = auto_table_window(b->len);
   if (c < 4 || c > 22) return fail(ZKHIP_ERR_ARG, "table window must be 0 (automatic) or in [4, 22]");
@@ -253,6 +300,7 @@ int zkhip_bases_table_window(const zkhip_bases* b) { return b ? b->table_c : 0; 
 
 void zkhip_bases_free(zkhip_bases* b) {
   if (!b) return;
+  (void)bind_dev(b->device);
   if (b->d_pts) (void)hipFree(b->d_pts);
   if (b->d_inf) (void)hipFree(b->d_inf);
   delete b;
@@ -260,30 +308,33 @@ void zkhip_bases_free(zkhip_bases* b) {
 
 int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery,
                   uint64_t out_jac[36]) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!bases || !out_jac || (len && !d_scalars)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(bases);
+  ProveState& ps = g.dev[bases->device].ps;
+  std::lock_guard<std::mutex> lk(g.dev[bases->device].mu);
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
-  int rc = ensure_msm(len ? len : 1, bases->table_c);
+  int rc = ensure_ctx(&ps.ctx[0], &ps.ready[0], len ? len : 1, bases->table_c);
   if (rc != ZKHIP_OK) return rc;
-  rc = msm_run(&g.ps.ctx[0], bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
+  rc = msm_run(&ps.ctx[0], bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                scalars_montgomery, bases->len, out_jac);
-  if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", g.ps.ctx[0].errbuf);
-  else g.ps.last_accumulate_ms = g.ps.ctx[0].last_accumulate_ms;
+  if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", ps.ctx[0].errbuf);
+  else ps.last_accumulate_ms = ps.ctx[0].last_accumulate_ms;
   return rc;
 }
 
 // Asynchronous form: enqueue on one of the library's MSM contexts and return; collect later.  Two MSMs in flight overlap
 // the latency-bound bucket reduction of one with the accumulation of the other (what the prover does between its own MSMs).
 int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery, int slot) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!bases || (len && !d_scalars)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(bases);
+  t_dev = bases->device;                     // zkhip_msm_collect(slot) has no handle: it collects on this thread's device
+  ProveState& ps = g.dev[bases->device].ps;
+  std::lock_guard<std::mutex> lk(g.dev[bases->device].mu);
   if (slot < 0 || slot > 3) return fail(ZKHIP_ERR_ARG, "slot must be in [0, 3]");
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
-  MsmCtx* cx = &g.ps.ctx[slot];
-  if (g.ps.ready[slot] && cx->pending) return fail(ZKHIP_ERR_STATE, "slot busy: collect its result first");
-  int rc = ensure_ctx(cx, &g.ps.ready[slot], len ? len : 1, bases->table_c);
+  MsmCtx* cx = &ps.ctx[slot];
+  if (ps.ready[slot] && cx->pending) return fail(ZKHIP_ERR_STATE, "slot busy: collect its result first");
+  int rc = ensure_ctx(cx, &ps.ready[slot], len ? len : 1, bases->table_c);
   if (rc != ZKHIP_OK) return rc;
   rc = msm_launch(cx, bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                   scalars_montgomery, bases->len);
@@ -292,30 +343,30 @@ int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scal
 }
 
 int zkhip_msm_collect(int slot, uint64_t out_jac[36]) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
+  ProveState& ps = g.dev[cur_dev()].ps;
+  std::lock_guard<std::mutex> lk(g.dev[cur_dev()].mu);
   if (slot < 0 || slot > 3 || !out_jac) return fail(ZKHIP_ERR_ARG, "bad slot or null pointer");
-  MsmCtx* cx = &g.ps.ctx[slot];
-  if (!g.ps.ready[slot] || !cx->pending) return fail(ZKHIP_ERR_STATE, "nothing submitted on this slot");
+  MsmCtx* cx = &ps.ctx[slot];
+  if (!ps.ready[slot] || !cx->pending) return fail(ZKHIP_ERR_STATE, "nothing submitted on this slot");
   int rc = msm_finish(cx, out_jac);
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", cx->errbuf);
-  else g.ps.last_accumulate_ms = cx->last_accumulate_ms;
+  else ps.last_accumulate_ms = cx->last_accumulate_ms;
   return rc;
 }
 
 int zkhip_msm(const zkhip_bases* bases, size_t offset, const uint64_t* scalars, size_t len, int scalars_montgomery,
               uint64_t out_jac[36]) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
-  if (len && !scalars) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (!bases || (len && !scalars)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(bases);
+  Scratch sc;
   void* d = nullptr;
   if (len) {
-    API_HIP(hipMalloc(&d, len * 48));
+    API_HIP(sc.alloc(&d, len * 48));
     API_HIP(hipMemcpy(d, scalars, len * 48, hipMemcpyHostToDevice));
     API_HIP(hipStreamSynchronize(0));     // the MSM streams are not ordered against the null stream
   }
-  int rc = zkhip_msm_dev(bases, offset, d, len, scalars_montgomery, out_jac);
-  if (d) (void)hipFree(d);
-  return rc;
+  return zkhip_msm_dev(bases, offset, d, len, scalars_montgomery, out_jac);
 }
 
 int zkhip_msm_raw(const uint64_t* bases_affine, const uint64_t* scalars, size_t len, int scalars_montgomery,
@@ -330,8 +381,8 @@ int zkhip_msm_raw(const uint64_t* bases_affine, const uint64_t* scalars, size_t 
 
 int zkhip_fixed_base_mul_dev(const uint64_t base_affine[24], const void* d_scalars, size_t len, int scalars_montgomery,
                              void* d_out_affine) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
+  std::lock_guard<std::mutex> lk(g.dev[cur_dev()].mu);
   if (!base_affine || (len && (!d_scalars || !d_out_affine))) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (len == 0) return ZKHIP_OK;
   return fixed_base_mul(base_affine, (const uint64_t*)d_scalars, len, scalars_montgomery, (uint64_t*)d_out_affine, t_err, sizeof t_err);
@@ -339,54 +390,55 @@ int zkhip_fixed_base_mul_dev(const uint64_t base_affine[24], const void* d_scala
 
 int zkhip_fixed_base_mul(const uint64_t base_affine[24], const uint64_t* scalars, size_t len, int scalars_montgomery,
                          uint64_t* out_affine) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
   if (len && (!scalars || !out_affine)) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (len == 0) return ZKHIP_OK;
+  Scratch sc;
   void *ds = nullptr, *dp = nullptr;
-  API_HIP(hipMalloc(&ds, len * 48));
-  API_HIP(hipMalloc(&dp, len * 192));
+  API_HIP(sc.alloc(&ds, len * 48));
+  API_HIP(sc.alloc(&dp, len * 192));
   API_HIP(hipMemcpy(ds, scalars, len * 48, hipMemcpyHostToDevice));
   int rc = zkhip_fixed_base_mul_dev(base_affine, ds, len, scalars_montgomery, dp);
   if (rc == ZKHIP_OK) API_HIP(hipMemcpy(out_affine, dp, len * 192, hipMemcpyDeviceToHost));
-  (void)hipFree(ds); (void)hipFree(dp);
   return rc;
 }
 
 int zkhip_ntt_dev(void* d_data, unsigned log_d, int dir, int coset) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
+  std::lock_guard<std::mutex> lk(g.dev[cur_dev()].mu);
   if (!d_data) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (log_d > 22) return fail(ZKHIP_ERR_ARG, "log_d must be <= 22");
   return ntt_dev_abi((uint64_t*)d_data, (int)log_d, dir != 0, coset != 0, t_err, sizeof t_err);
 }
 
 int zkhip_ntt(uint64_t* data, unsigned log_d, int dir, int coset) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
   if (!data) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (log_d > 22) return fail(ZKHIP_ERR_ARG, "log_d must be <= 22");
   size_t bytes = ((size_t)48) << log_d;
+  Scratch sc;
   void* d = nullptr;
-  API_HIP(hipMalloc(&d, bytes));
+  API_HIP(sc.alloc(&d, bytes));
   API_HIP(hipMemcpy(d, data, bytes, hipMemcpyHostToDevice));
   int rc = zkhip_ntt_dev(d, log_d, dir, coset);
   if (rc == ZKHIP_OK) API_HIP(hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost));
-  (void)hipFree(d);
   return rc;
 }
 
 int zkhip_r1cs_upload(const zkhip_r1cs_desc* d, zkhip_r1cs** out) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
+  std::lock_guard<std::mutex> lk(g.dev[cur_dev()].mu);
   if (!d || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
   R1csDev* dev = nullptr;
   int rc = r1cs_upload(d, &dev, t_err, sizeof t_err);
   if (rc != ZKHIP_OK) return rc;
-  *out = new zkhip_r1cs{dev};
+  *out = new zkhip_r1cs{dev, cur_dev()};
   return ZKHIP_OK;
 }
 
 void zkhip_r1cs_free(zkhip_r1cs* r) {
   if (!r) return;
+  (void)bind_dev(r->device);
   r1cs_free(r->dev);
   delete r;
 }
@@ -394,32 +446,31 @@ void zkhip_r1cs_free(zkhip_r1cs* r) {
 unsigned zkhip_r1cs_log_domain(const zkhip_r1cs* r) { return r ? (unsigned)r->dev->log_d : 0; }
 
 int zkhip_r1cs_is_satisfied(zkhip_r1cs* r, const uint64_t* z, int* ok) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!r || !z || !ok) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(r);
+  std::lock_guard<std::mutex> lk(g.dev[r->device].mu);
+  Scratch sc;
   uint64_t* dz = nullptr;
-  API_HIP(hipMalloc(&dz, r->dev->n_vars * 48));
+  API_HIP(sc.alloc((void**)&dz, r->dev->n_vars * 48));
   API_HIP(hipMemcpy(dz, z, r->dev->n_vars * 48, hipMemcpyHostToDevice));
-  int rc = r1cs_is_satisfied_dev(r->dev, dz, 0, ok, t_err, sizeof t_err);
-  (void)hipFree(dz);
-  return rc;
+  return r1cs_is_satisfied_dev(r->dev, dz, 0, ok, t_err, sizeof t_err);
 }
 
 int zkhip_qap_h(zkhip_r1cs* r, const uint64_t* z, uint64_t* h_out) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!r || !z || !h_out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(r);
+  std::lock_guard<std::mutex> lk(g.dev[r->device].mu);
   size_t d = (size_t)1 << r->dev->log_d;
+  Scratch sc;
   uint64_t *dz = nullptr, *dh = nullptr;
-  API_HIP(hipMalloc(&dz, r->dev->n_vars * 48));
-  API_HIP(hipMalloc(&dh, d * 48));
+  API_HIP(sc.alloc((void**)&dz, r->dev->n_vars * 48));
+  API_HIP(sc.alloc((void**)&dh, d * 48));
   API_HIP(hipMemcpy(dz, z, r->dev->n_vars * 48, hipMemcpyHostToDevice));
   int rc = qap_h_dev(r->dev, dz, 0, t_err, sizeof t_err);
   if (rc == ZKHIP_OK) {
     fr_dev_to_abi(r->dev->bufA, dh, d, 0);
     API_HIP(hipMemcpy(h_out, dh, d * 48, hipMemcpyDeviceToHost));
   }
-  (void)hipFree(dz); (void)hipFree(dh);
   return rc;
 }
 
@@ -437,11 +488,12 @@ static int crs_build_tables(zkhip_crs* c) {
 }
 
 int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
   if (!d || !out || !d->alpha_g1 || !d->beta_g1 || !d->beta_g2 || !d->delta_g1 || !d->delta_g2)
     return fail(ZKHIP_ERR_ARG, "null pointer");
   if (d->n_vars < d->n_primary + 1 || d->domain_size < 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
   zkhip_crs* c = new zkhip_crs();
+  c->device = cur_dev();
   c->n_vars = d->n_vars; c->n_primary = d->n_primary; c->domain_size = d->domain_size;
   memcpy(c->alpha_g1, d->alpha_g1, 192); memcpy(c->beta_g1, d->beta_g1, 192); memcpy(c->beta_g2, d->beta_g2, 192);
   memcpy(c->delta_g1, d->delta_g1, 192); memcpy(c->delta_g2, d->delta_g2, 192);
@@ -459,11 +511,12 @@ int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) {
 
 int zkhip_crs_upload_slice(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, size_t h_lo, size_t h_len, size_t l_lo, size_t l_len,
                            zkhip_crs** out) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
   if (!d || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (a_lo + a_len > d->n_vars || h_lo + h_len > d->domain_size - 1 || l_lo + l_len > d->n_vars - d->n_primary - 1)
     return fail(ZKHIP_ERR_ARG, "slice out of range");
   zkhip_crs* c = new zkhip_crs();
+  c->device = cur_dev();
   c->n_vars = d->n_vars; c->n_primary = d->n_primary; c->domain_size = d->domain_size;
   memcpy(c->alpha_g1, d->alpha_g1, 192); memcpy(c->beta_g1, d->beta_g1, 192); memcpy(c->beta_g2, d->beta_g2, 192);
   memcpy(c->delta_g1, d->delta_g1, 192); memcpy(c->delta_g2, d->delta_g2, 192);
@@ -483,13 +536,14 @@ int zkhip_crs_table_window(const zkhip_crs* c) { return (c && c->A) ? c->A->tabl
 
 void zkhip_crs_free(zkhip_crs* c) {
   if (!c) return;
+  (void)bind_dev(c->device);
   zkhip_bases_free(c->A); zkhip_bases_free(c->B2); zkhip_bases_free(c->B1); zkhip_bases_free(c->H); zkhip_bases_free(c->L);
   delete c;
 }
 
 int zkhip_last_prove_timings(double out_ms[8]) {
-  if (!out_ms) return ZKHIP_ERR_ARG;
-  memcpy(out_ms, g.ps.ms, sizeof g.ps.ms);
+  if (!out_ms || cur_dev() < 0) return ZKHIP_ERR_ARG;
+  memcpy(out_ms, g.dev[cur_dev()].ps.ms, sizeof g.dev[0].ps.ms);
   return ZKHIP_OK;
 }
 
@@ -581,10 +635,11 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
 
 int zkhip_groth16_prove_partial(const zkhip_crs* crs_slice, zkhip_r1cs* r1cs, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
                                 uint64_t sums_jac[180]) {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!crs_slice || !r1cs || !z || !sums_jac) return fail(ZKHIP_ERR_ARG, "null pointer");
-  return prove_partial(g.ps, crs_slice, r1cs->dev, z, a_lo, h_lo, l_lo, sums_jac);
+  if (crs_slice->device != r1cs->device) return fail(ZKHIP_ERR_ARG, "proving key and constraint system live on different devices");
+  BIND(crs_slice);
+  std::lock_guard<std::mutex> lk(g.dev[crs_slice->device].mu);
+  return prove_partial(g.dev[crs_slice->device].ps, crs_slice, r1cs->dev, z, a_lo, h_lo, l_lo, sums_jac);
 }
 
 // tail: A = alpha + evA + r delta1;  B = beta + evB + s delta;  C = evH + evL + s A + r B1 - rs delta1
@@ -622,26 +677,29 @@ static int finish_impl(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], 
 int zkhip_groth16_finish(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
                          const uint64_t delta_g2[24], const uint64_t sums_jac[180], const uint64_t r_m[6], const uint64_t s_m[6],
                          uint64_t proof_affine[72]) {
-  return finish_impl(alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, sums_jac, r_m, s_m, proof_affine, &g.ps.ms[7]);
+  return finish_impl(alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, sums_jac, r_m, s_m, proof_affine, cur_dev() >= 0 ? &g.dev[cur_dev()].ps.ms[7] : nullptr);
 }
 
 int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6],
                         uint64_t proof_affine[72]) {
   uint64_t sums[180];
+  if (!crs || !r1cs || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (crs->device != r1cs->device) return fail(ZKHIP_ERR_ARG, "proving key and constraint system live on different devices");
+  BIND(crs);
   {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
-    if (!crs || !r1cs || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(g.dev[crs->device].mu);
     const size_t m = r1cs->dev->n_vars, l = r1cs->dev->n_primary, d = (size_t)1 << r1cs->dev->log_d;
     if (crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
-    int rc = prove_partial(g.ps, crs, r1cs->dev, z, 0, 0, 0, sums);
+    int rc = prove_partial(g.dev[crs->device].ps, crs, r1cs->dev, z, 0, 0, 0, sums);
     if (rc != ZKHIP_OK) return rc;
   }
+  t_dev = crs->device;      // zkhip_last_prove_timings reads this thread's device
   return zkhip_groth16_finish(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine);
 }
 
 // ---- prover instances: one proof in flight each, several instances per GPU -------------------------------------------
 struct zkhip_prover {
+  int device;
   const zkhip_crs* crs;
   R1csDev* rd;          // own copy of the constraint system + QAP work buffers
   ProveState ps;
@@ -649,11 +707,11 @@ struct zkhip_prover {
 };
 
 int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prover** out) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!crs || !cs || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(crs);
   R1csDev* rd = nullptr;
   {
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<std::mutex> lk(g.dev[crs->device].mu);
     int rc = r1cs_upload(cs, &rd, t_err, sizeof t_err);
     if (rc != ZKHIP_OK) return rc;
   }
@@ -663,6 +721,7 @@ int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prov
     return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
   }
   zkhip_prover* p = new zkhip_prover();
+  p->device = crs->device;
   p->crs = crs; p->rd = rd;
   *out = p;
   return ZKHIP_OK;
@@ -670,14 +729,15 @@ int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prov
 
 void zkhip_prover_free(zkhip_prover* p) {
   if (!p) return;
+  (void)bind_dev(p->device);
   p->ps.release();
   r1cs_free(p->rd);
   delete p;
 }
 
 int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]) {
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
   if (!p || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(p);                                    // called from pipeline / application threads that never ran zkhip_init
   std::lock_guard<std::mutex> lk(p->mu);
   uint64_t sums[180];
   int rc = prove_partial(p->ps, p->crs, p->rd, z, 0, 0, 0, sums);
@@ -706,6 +766,19 @@ int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_
   if (!vk_alpha_g1 || !vk_beta_g2 || !vk_delta_g2 || !vk_abc || !proof_affine || !ok || (n_inputs && !inputs))
     return fail(ZKHIP_ERR_ARG, "null pointer");
   auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
+  // well-formedness first (libsnark: proof.is_well_formed()): G1 is y^2 = x^3 - 1, G2 is y^2 = x^3 + 4, both over Fq;
+  // the all-zero encoding of the point at infinity passes.  An off-curve point would put the pairing in an invalid-curve setting.
+  auto on_curve = [](const uint64_t* p, bool g2) {
+    HFq x = HFq::from_limbs(p), y = HFq::from_limbs(p + 12);
+    if (x.is_zero() && y.is_zero()) return true;
+    HFq four = HFq::one().dbl().dbl();
+    HFq rhs = x.sqr() * x + (g2 ? four : HFq::one().neg());
+    return y.sqr() == rhs;
+  };
+  bool wf = on_curve(proof_affine, false) && on_curve(proof_affine + 24, true) && on_curve(proof_affine + 48, false) &&
+            on_curve(vk_alpha_g1, false) && on_curve(vk_beta_g2, true) && on_curve(vk_delta_g2, true);
+  for (size_t i = 0; i <= n_inputs && wf; i++) wf = on_curve(vk_abc + i * 24, false);
+  if (!wf) { *ok = 0; return ZKHIP_OK; }
   // acc = ABC_0 + sum x_i ABC_i
   HJac acc = aff(vk_abc);
   for (size_t i = 0; i < n_inputs; i++) {
@@ -734,7 +807,7 @@ int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_
 int zkhip_groth16_setup(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], const uint64_t alpha_m[6], const uint64_t beta_m[6],
                         const uint64_t delta_m[6], zkhip_keypair** out) {
   using namespace host;
-  if (!g.inited) return fail(ZKHIP_ERR_STATE, "zkhip_init not called");
+  BIND_CUR();
   if (!cs || !tau_m || !alpha_m || !beta_m || !delta_m || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
   const size_t n = cs->n_constraints, m = cs->n_vars, l = cs->n_primary;
   if (m < l + 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
@@ -862,8 +935,18 @@ int zkhip_keypair_read(const char* path, zkhip_keypair** out) {
   uint64_t hdr[8];
   if (fread(hdr, 8, 8, f) != 8 || memcmp(&hdr[0], KP_MAGIC, 8) != 0) { fclose(f); return fail(ZKHIP_ERR_ARG, "not a keypair file (bad magic)"); }
   const uint64_t m = hdr[1], l = hdr[2], d = hdr[3];
-  if (m < l + 1 || d < 1 || (d & (d - 1)) || m > ((uint64_t)1 << 28) || d > ((uint64_t)1 << 28)) { fclose(f); return fail(ZKHIP_ERR_ARG, "keypair file: implausible sizes"); }
-  zkhip_keypair* kp = new zkhip_keypair();
+  // the prover's domains stop at 2^22 points; a key has at most that many variables (one constraint defines at most one)
+  if (m < l + 1 || d < 1 || (d & (d - 1)) || m > ((uint64_t)1 << 23) || d > ((uint64_t)1 << 22)) { fclose(f); return fail(ZKHIP_ERR_ARG, "keypair file: implausible sizes"); }
+  // the header fixes the file's length: check it before any allocation is sized by it
+  {
+    const uint64_t pts = 5 + 3 * m + (d - 1) + (m - l - 1) + (l + 1), want = 64 + 8 * 24 * pts + 8;
+    long here = ftell(f);
+    bool okl = here == 64 && fseek(f, 0, SEEK_END) == 0 && (uint64_t)ftell(f) == want && fseek(f, here, SEEK_SET) == 0;
+    if (!okl) { fclose(f); return fail(ZKHIP_ERR_ARG, "keypair file truncated or corrupted (length does not match its header)"); }
+  }
+  zkhip_keypair* kp = nullptr;
+  try {
+  kp = new zkhip_keypair();
   kp->n_vars = m; kp->n_primary = l; kp->domain_size = d;
   struct { std::vector<uint64_t>* v; size_t pts; } parts[] = {{&kp->alpha_g1, 1}, {&kp->beta_g1, 1}, {&kp->beta_g2, 1}, {&kp->delta_g1, 1}, {&kp->delta_g2, 1},
                                                               {&kp->A, m}, {&kp->B2, m}, {&kp->B1, m}, {&kp->H, d - 1}, {&kp->L, m - l - 1}, {&kp->ABC, l + 1}};
@@ -880,11 +963,17 @@ int zkhip_keypair_read(const char* path, zkhip_keypair** out) {
   if (!ok) { delete kp; return fail(ZKHIP_ERR_ARG, "keypair file truncated or corrupted (checksum)"); }
   *out = kp;
   return ZKHIP_OK;
+  } catch (const std::exception& e) {       // std::bad_alloc: no exception crosses the C ABI
+    fclose(f);
+    delete kp;
+    snprintf(t_err, sizeof t_err, "keypair file: %s", e.what());
+    return ZKHIP_ERR_ARG;
+  }
 }
 
 void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 
-float zkhip_last_accumulate_ms(void) { return g.ps.last_accumulate_ms; }
+float zkhip_last_accumulate_ms(void) { return cur_dev() >= 0 ? g.dev[cur_dev()].ps.last_accumulate_ms : 0.f; }
 
 int zkhip_to_canonical(int which, const uint64_t* in, uint64_t* out) {
   using namespace host;

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkhip.so")
 
 EXPORTS = [
-    "zkhip_init", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window",
+    "zkhip_init", "zkhip_set_device", "zkhip_get_device", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window",
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
     "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window", "zkhip_set_batch_msms",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_msm_submit", "zkhip_msm_collect",
@@ -22,7 +22,7 @@ EXPORTS = [
     "zkhip_crs_upload_slice", "zkhip_groth16_prove_partial", "zkhip_groth16_finish",
     "zkhip_bls12_377_groth16_verify", "zkhip_aggregator_new", "zkhip_aggregator_free", "zkhip_aggregator_num_constraints",
     "zkhip_aggregator_num_variables", "zkhip_aggregator_num_primary_inputs", "zkhip_aggregator_get_r1cs",
-    "zkhip_aggregator_witness", "zkhip_aggregator_vk_hash", "zkhip_aggregator_num_proofs", "zkhip_aggregator_inputs_per_proof",
+    "zkhip_aggregator_witness", "zkhip_aggregator_check_inputs", "zkhip_aggregator_vk_hash", "zkhip_aggregator_num_proofs", "zkhip_aggregator_inputs_per_proof",
     "zkhip_prover_new", "zkhip_prover_prove", "zkhip_prover_timings", "zkhip_prover_free", "zkhip_prover_last_accumulate_ms",
     "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
@@ -64,6 +64,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     c_u64p = ctypes.POINTER(ctypes.c_uint64)
     lib.zkhip_init.argtypes = [ctypes.c_int]
+    lib.zkhip_set_device.argtypes = [ctypes.c_int]
     lib.zkhip_strerror.restype = ctypes.c_char_p
     lib.zkhip_strerror.argtypes = [ctypes.c_int]
     lib.zkhip_last_error.restype = ctypes.c_char_p
@@ -134,6 +135,15 @@ def _p(a):
 
 def init(device=0):
     _check(load().zkhip_init(device))
+
+
+def set_device(device):
+    """Library device of the calling thread for the entry points without a handle (handles carry their own device)."""
+    _check(load().zkhip_set_device(device))
+
+
+def get_device():
+    return load().zkhip_get_device()
 
 
 def set_msm_window(c):
@@ -487,6 +497,13 @@ class AggregatorCircuit:
         z = np.zeros((self.num_variables, 6), dtype=np.uint64)
         _check(load().zkhip_aggregator_witness(self.handle, _p(vk), _p(pr), _p(inp), _p(z)))
         return z
+
+    def check_inputs(self, nested_vk, nested_proofs):
+        """True iff every point of the nested key and proofs is on its curve (proof.is_well_formed() in the reference's stack)."""
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+        ok = ctypes.c_int(0)
+        _check(load().zkhip_aggregator_check_inputs(self.handle, _p(c(nested_vk)), _p(c(nested_proofs)), ctypes.byref(ok)))
+        return bool(ok.value)
 
     def free(self):
         if self.handle:
