@@ -54,6 +54,9 @@ const char* zkhip_last_error(void);
 
 /* Window size (bits) of the bucket method; 0 = automatic from len. */
 int zkhip_set_msm_window(int c);
+/* Bucket accumulation: number of batched-affine levels (pairwise sums inside the buckets, one shared inversion per lane) that
+ * run before the XYZZ accumulation; -1 = automatic from the size (0 for small inputs).  Results do not depend on it. */
+int zkhip_set_affine_levels(int levels);
 
 /* replaces: holding r1cs_gg_ppzksnark_proving_key query vectors in host memory
  * (aggregator_server/aggregator_server.cpp:483-514 loads the keypair once).

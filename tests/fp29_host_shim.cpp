@@ -2,6 +2,7 @@
 // through a C ABI so tests/test_fp29_host.py can compare it with Python big integers.
 // Test infrastructure only.
 #include "../zecale_amd/csrc/fp29.cuh"
+#include "../zecale_amd/csrc/fp_inv.cuh"
 using namespace zkhip;
 extern "C" {
 #define SHIM(F, PR, N64)                                                                       \
@@ -12,6 +13,7 @@ extern "C" {
     fp_to_abi<PR>(fp_add(fp_from_abi<PR>(a), fp_from_abi<PR>(b)), r); }                        \
   void F##_sub(const uint64_t* a, const uint64_t* b, uint64_t* r) {                            \
     fp_to_abi<PR>(fp_sub<PR, 2>(fp_from_abi<PR>(a), fp_from_abi<PR>(b)), r); }                 \
+  void F##_inv(const uint64_t* a, uint64_t* r) { fp_to_abi<PR>(fp_inv<PR>(fp_from_abi<PR>(a)), r); }               \
   void F##_roundtrip(const uint64_t* a, uint64_t* r) { fp_to_abi<PR>(fp_from_abi<PR>(a), r); } \
   void F##_canon_words(const uint64_t* a, uint32_t* w) { fp_abi_to_canonical_words<PR>(a, w); } \
   /* a long lazy chain: ((a+b)*(a-b+8p) + 16p - b)^2 ... exercising the documented bounds */  \

@@ -18,8 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def shim():
     so = os.path.join(HERE, "libfp29_host_shim.so")
     src = os.path.join(HERE, "fp29_host_shim.cpp")
-    hdr = os.path.join(HERE, "..", "zecale_amd", "csrc", "fp29.cuh")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(HERE, "..", "zecale_amd", "csrc", h) for h in ("fp29.cuh", "fp_inv.cuh", "bw6_params.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
     return ctypes.CDLL(so)
 
@@ -54,3 +54,24 @@ def test_fp29_against_golden_and_random(shim, name, p, n):
         w = (ctypes.c_uint32 * (2 * n))()
         getattr(shim, name + "_canon_words")(_arr(tm(a), n), w)
         assert sum(int(w[i]) << (32 * i) for i in range(2 * n)) == a
+
+
+@pytest.mark.parametrize("name,p,n", [("fq", R.Q_MOD, 12), ("fr", R.R_MOD, 6)])
+def test_safegcd_inversion(shim, name, p, n):
+    """fp_inv (zecale_amd/csrc/fp_inv.cuh: Bernstein-Yang division steps in batches of 29) against pow(a, -1, p): random values and
+    the values that stress the step count (powers of two, p - 2^k, small numbers, 0 -> 0)."""
+    Rm = 1 << (64 * n)
+    tm = lambda x: x * Rm % p
+    fm = lambda X: X * pow(Rm, -1, p) % p
+    out = (ctypes.c_uint64 * n)()
+    rng = random.Random(5)
+    vals = [1, 2, 3, p - 1, p - 2, (p + 1) // 2, (p - 1) // 2, 0]
+    vals += [1 << k for k in range(1, p.bit_length() - 1, 37)] + [p - (1 << k) for k in range(1, p.bit_length() - 1, 41)]
+    vals += [rng.randrange(1, 1 << rng.randrange(1, p.bit_length())) % p for _ in range(200)]
+    vals += [rng.randrange(p) for _ in range(800)]
+    for a in vals:
+        # the shim feeds fp_inv the device Montgomery form of a; every representative the kernels produce is covered by
+        # fp_from_abi's output range [0, 2p)
+        getattr(shim, name + "_inv")(_arr(tm(a), n), out)
+        got = fm(R.limbs_to_int(out))
+        assert got == (pow(a, -1, p) if a else 0), hex(a)

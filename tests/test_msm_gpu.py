@@ -11,6 +11,18 @@ from tests.helpers import aff_limbs, aff_point, fr_array, golden, h2i, pt_from_j
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[-1, 1, 3], ids=["auto", "affine1", "affine3"])
+def affine_levels(request, zk):
+    """Every case runs with the default accumulation (XYZZ mixed additions only) and with one and three batched-affine levels
+    forced in front of it (pairwise affine sums inside the buckets, one shared inversion per lane: the same group element)."""
+    big = any(t in request.node.name for t in ("2_22", "full_size", "closed_form"))
+    if big and request.param == 1:
+        pytest.skip("full-size cases: default and three levels")
+    zk.set_affine_levels(request.param)
+    yield request.param
+    zk.set_affine_levels(-1)
+
+
 def _msm_aff(zk, bases, scal, montgomery=True, window=0):
     zk.set_msm_window(window)
     return zk.jac_to_affine(zk.msm_raw(bases, scal, montgomery=montgomery))

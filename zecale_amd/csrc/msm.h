@@ -10,6 +10,7 @@ namespace zkhip {
 
 struct AffPacked;
 
+#define MSM_MAX_AFF_LEVELS 4
 #define MSM_MAX_JOBS 5   // MSMs sharing one launch sequence (the five query vectors of a proof)
 struct MsmJob {
   const AffPacked* bases;        // table-backed base set (level 0 at bases[0 .. n))
@@ -37,12 +38,24 @@ struct MsmCtx {
   uint32_t *counts, *offsets, *cursor, *block_tot, *entries;
   uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels, *colS[2], *hilo;
   uint64_t *win_abi, *win_host;
+  // batched-affine levels in front of the XYZZ accumulation (k_affine_level): per level the bucket counts / offsets of its output,
+  // two point buffers used alternately, the prefix-product scratch of one launch
+  int aff_levels;                    // 0: every entry goes straight to k_accumulate
+  int aff_forced;                    // the msm_forced_aff_levels() this plan was made under
+  uint32_t aff_m, aff_lanes;         // outputs per lane; lanes per launch (the scratch holds aff_m * 27 * aff_lanes words)
+  uint32_t *lcnt[MSM_MAX_AFF_LEVELS], *loff[MSM_MAX_AFF_LEVELS];
+  AffPacked* pbuf[2];
+  uint32_t* aff_scratch;
+  size_t m_acc_max;                  // upper bound on the entries that reach k_accumulate (sizes S, T and the slot array)
   float last_accumulate_ms;
   bool pending;       // an MSM has been enqueued by msm_launch and not yet collected by msm_finish
   size_t pending_n;
   char errbuf[256];
 };
 
+// tuning / test knob: number of batched-affine levels of the plans made from now on (-1: automatic)
+void msm_force_aff_levels(int levels);
+int msm_forced_aff_levels();
 int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K);
 void msm_plan_free(MsmCtx* ctx);
 int msm_bases_convert(const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags, char* errbuf, size_t errlen);

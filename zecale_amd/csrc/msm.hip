@@ -22,7 +22,7 @@
 #include <string.h>
 #include <vector>
 
-#include "ec_mem.cuh"
+#include "ec_affine.cuh"
 #include "host_field.hpp"
 #include "msm.h"
 
@@ -237,6 +237,8 @@ template <int NJ> __device__ __forceinline__ const AffPacked* base_of(const Base
   return r;
 }
 
+// entries == nullptr: the sorted list IS the dense point array bp.p[0] (the output of the batched-affine levels, k_affine_level):
+// entry k is point k, never negated; a point may be the level encoding of infinity (skipped).
 template <int NJ>
 __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, const uint32_t* __restrict__ entries,
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
@@ -264,7 +266,8 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
 #if ZK_ACC_REGY
   Fq ty = fp_zero<FqParams>();     // Y of the running accumulator, carried in registers across the additions of a run
 #endif
-  uint32_t e_next = entries[pos0];
+  const bool dense = entries == nullptr;
+  uint32_t e_next = dense ? pos0 : entries[pos0];
   for (uint32_t k = pos0; k < pos1; k++) {
     if (k == bend) {
       if (!first) {
@@ -285,9 +288,10 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
       inf = true;
     }
     uint32_t e = e_next;
-    if (k + 1 < pos1) e_next = entries[k + 1];        // fetched a whole addition ahead of its use
-    const AffPacked* p = base_of<NJ>(bp, b >> bshift) + (e & 0x7fffffffu);
+    if (k + 1 < pos1) e_next = dense ? k + 1 : entries[k + 1];        // fetched a whole addition ahead of its use
+    const AffPacked* p = (dense ? bp.p[0] : base_of<NJ>(bp, b >> bshift)) + (e & 0x7fffffffu);
     bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_scalar_digits drops them)
+    if (dense && p->x[23] == ZK_AFF_INF_WORD) continue;        // a pair of the levels below cancelled
     if (inf) {
 #pragma unroll
       for (int i = 0; i < 24; i++) xs[i * ZK_LDS_STRIDE] = p->x[i];       // packed words straight into LDS
@@ -315,6 +319,202 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   }
   // a run that cancelled to infinity leaves ZZ = 0 in its slot: madd_same_x wrote the zeros, or the slot
   // was never written (zero-filled array)
+}
+
+// ---- batched-affine levels ------------------------------------------------------------------------------------------------
+// The bucket-sorted entry list is summed PAIRWISE inside every bucket, level by level: a bucket of n points becomes ceil(n/2)
+// points (floor(n/2) sums and, for odd n, its last point passed through), written densely in bucket order.  All additions of a
+// level are independent, so a lane that produces m consecutive outputs shares one field inversion among them (ec_affine.cuh):
+//   forward   d_j = x2 - x1 of pair j;  scratch[j] = d_0 ... d_(j-1);  acc = d_0 ... d_(m-1)
+//   inv = 1 / acc                                       (fp_inv: division steps, all 64 lanes at once)
+//   backward  1/d_j = inv * scratch[j];  inv *= d_j;  lambda, x3, y3;  store
+// 5 M + 1 S per addition (+ ~30 M / m for the inversion) instead of the 8 M + 2 S of a mixed addition into an XYZZ accumulator.
+// After a few levels (the buckets are down to a handful of points) k_accumulate sums what is left, in its dense mode.
+__global__ void __launch_bounds__(256) k_half_counts(const uint32_t* __restrict__ in_cnt, uint32_t* __restrict__ out_cnt, size_t nb) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb) out_cnt[i] = (in_cnt[i] + 1) >> 1;
+}
+
+struct LevelArgs {
+  BasePtrs bp;                 // first level: the base tables, by job
+  int bshift;
+  const uint32_t* entries;     // first level: bucket-sorted (index | sign << 31)
+  const AffPacked* src;        // later levels: the previous level's dense points
+  const uint32_t* in_off;      // [nb] start of every bucket in the input level
+  const uint32_t* in_cnt;      // [nb]
+  const uint32_t* out_off;     // [nb] start of every bucket in the output level (counts: ceil(in_cnt / 2))
+  uint32_t nb, m, lane0, lanes;  // outputs per lane; first lane of this launch; lanes of this launch (row length of `scratch`)
+  AffPacked* dst;
+  uint32_t* scratch;           // prefix products, limb-major: word (j * 27 + k) of lane t at scratch[(j * 27 + k) * lanes + t]
+};
+
+struct LevelWalk {             // the bucket that holds output j, and where its inputs start
+  uint32_t b, ooff, oend, ioff, icnt;
+};
+__device__ __forceinline__ void walk_fwd(LevelWalk& w, uint32_t j, const uint32_t* __restrict__ in_off, const uint32_t* __restrict__ in_cnt) {
+  while (j >= w.oend) {
+    w.b++;
+    const uint32_t c = in_cnt[w.b];
+    if (!c) continue;
+    w.ooff = w.oend; w.icnt = c; w.ioff = in_off[w.b]; w.oend = w.ooff + ((c + 1) >> 1);
+  }
+}
+__device__ __forceinline__ void walk_bwd(LevelWalk& w, uint32_t j, const uint32_t* __restrict__ in_off, const uint32_t* __restrict__ in_cnt) {
+  while (j < w.ooff) {
+    w.b--;
+    const uint32_t c = in_cnt[w.b];
+    if (!c) continue;
+    w.oend = w.ooff; w.icnt = c; w.ioff = in_off[w.b]; w.ooff = w.oend - ((c + 1) >> 1);
+  }
+}
+template <int NJ, bool FIRST>
+__device__ __forceinline__ PairRef level_pair(const LevelArgs& a, const LevelWalk& w, uint32_t j) {
+  const uint32_t i = j - w.ooff, p0 = w.ioff + 2 * i;
+  const bool has2 = 2 * i + 1 < w.icnt;
+  PairRef pr;
+  if constexpr (FIRST) {
+    const AffPacked* base = base_of<NJ>(a.bp, w.b >> a.bshift);
+    const uint32_t e0 = a.entries[p0], e1 = has2 ? a.entries[p0 + 1] : 0u;
+    pr.p1 = base + (e0 & 0x7fffffffu); pr.neg1 = (e0 >> 31) != 0;
+    pr.p2 = has2 ? base + (e1 & 0x7fffffffu) : nullptr; pr.neg2 = (e1 >> 31) != 0;
+  } else {
+    pr.p1 = a.src + p0; pr.neg1 = false;
+    pr.p2 = has2 ? a.src + p0 + 1 : nullptr; pr.neg2 = false;
+  }
+  return pr;
+}
+__device__ __forceinline__ void pair_ld_x(const PairRef& pr, uint32_t* wx1, uint32_t* wx2) {
+  aff_ld_words(pr.p1->x, wx1);
+  if (pr.p2) aff_ld_words(pr.p2->x, wx2);
+}
+
+template <int NJ, bool FIRST>
+__global__ void __launch_bounds__(256, 2) k_affine_level(LevelArgs a) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t M_out = a.out_off[a.nb - 1] + ((a.in_cnt[a.nb - 1] + 1) >> 1);
+  const uint64_t j0_64 = (uint64_t)(a.lane0 + t) * a.m;
+  if (t >= a.lanes || j0_64 >= M_out) return;
+  const uint32_t j0 = (uint32_t)j0_64, cnt = min(a.m, M_out - j0);
+  const zk_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.scratch, 0, (int)((size_t)a.m * 27u * a.lanes * 4u), 0x00020000);
+  const uint32_t voff = t * 4u, row_b = a.lanes * 4u;
+  LevelWalk w;
+  w.b = bucket_of(a.out_off, a.nb, j0);
+  w.icnt = a.in_cnt[w.b]; w.ioff = a.in_off[w.b]; w.ooff = a.out_off[w.b]; w.oend = w.ooff + ((w.icnt + 1) >> 1);
+  // Memory: every operand is fetched ONE multiplication ahead of its use (a gather from a multi-gigabyte table costs about as
+  // much as a sixth of a multiplication, and with two waves per SIMD a stalled wave is half the SIMD's throughput lost): the
+  // words wait in 48 registers (`pw`) carried around the loops, and the pair of the next output is located while the current
+  // one computes.
+  // ---- forward: prefix products of the slope denominators
+  Fq acc = fp_one<FqParams>();
+  {
+    uint32_t pw[48];
+    walk_fwd(w, j0, a.in_off, a.in_cnt);
+    PairRef pr = level_pair<NJ, FIRST>(a, w, j0);
+    pair_ld_x(pr, pw, pw + 24);
+#pragma unroll 1
+    for (uint32_t jj = 0; jj < cnt; jj++) {
+      const uint32_t kind = pair_kind(pr, pw, pw + 24);
+      const Fq d = pair_denominator(pr, kind, pw, pw + 24);
+      if (jj + 1 < cnt) {                                            // the next pair's x coordinates travel under this multiplication
+        walk_fwd(w, j0 + jj + 1, a.in_off, a.in_cnt);
+        pr = level_pair<NJ, FIRST>(a, w, j0 + jj + 1);
+        pair_ld_x(pr, pw, pw + 24);
+      }
+#pragma unroll
+      for (int k = 0; k < 27; k++) __builtin_amdgcn_raw_buffer_store_b32(acc.l[k], rs, voff, (jj * 27u + (uint32_t)k) * row_b, 0);
+      acc = fp_mul(acc, d);
+    }
+  }
+  Fq inv = fp_inv<FqParams>(acc);
+  // ---- backward: one addition per output.  A rolled micro-program (one multiplier body and one squaring body in the loop, as
+  // in ec_mem.cuh); three field elements are carried from step to step: inv, T0 (1/d, then x3), T1 (3 x1^2, then lambda).
+  PairRef pr = level_pair<NJ, FIRST>(a, w, j0 + cnt - 1);           // (the forward pass left w on the last output)
+#pragma unroll 1
+  for (uint32_t jj = a.m; jj-- > 0;) {               // (a wave-uniform counter: it is the scalar row offset of the scratch loads)
+    if (jj >= cnt) continue;
+    const uint32_t j = j0 + jj;
+    PairRef pr_next = pr;
+    uint32_t kind = PK_FIRST;
+    bool any_dbl = false;
+    Fq T0 = fp_zero<FqParams>(), T1 = T0;
+    uint32_t pw[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) pw[k] = 0;
+#pragma unroll 1
+    for (int step = 0; step < 6; step++) {
+      if (step == 2 && !any_dbl) continue;
+      Fq A, B;
+      switch (step) {
+        case 0:                                                     // 1/d = inv * (d_0 ... d_(j-1))
+          A = inv;
+#pragma unroll
+          for (int k = 0; k < 27; k++) B.l[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (jj * 27u + (uint32_t)k) * row_b, 0);
+          pair_ld_x(pr, pw, pw + 24);                               // for step 1
+          break;
+        case 1: {                                                   // inv <- inv * d
+          kind = pair_kind(pr, pw, pw + 24);
+          A = inv; B = pair_denominator(pr, kind, pw, pw + 24);
+          aff_ld_words(pr.p1->y, pw);                               // for step 3
+          if (pr.p2) aff_ld_words(pr.p2->y, pw + 24);
+          break;
+        }
+        case 2: { uint32_t wx1[24]; aff_ld_words(pr.p1->x, wx1); A = fp_unpack32<FqParams>(wx1); B = A; break; }   // x1^2 (doublings)
+        case 3: {                                                   // lambda = numerator / d
+          if (kind == PK_ADD) A = fp_sub<FqParams, 2>(aff_y_eff(pw + 24, pr.neg2), aff_y_eff(pw, pr.neg1));      // [4]
+          else A = T1;                                              // 3 x1^2 [6] (or unused)
+          B = T0;
+          pair_ld_x(pr, pw, pw + 24);                               // for the end of step 4
+          break;
+        }
+        case 4: A = T1; B = T1; break;                              // lambda^2
+        default: {                                                  // lambda (x1 - x3)
+          A = T1; B = fp_sub<FqParams, 2>(fp_unpack32<FqParams>(pw), T0);                   // [3]
+          if (jj > 0) {                                             // locate the pair of the next output under this multiplication
+            walk_bwd(w, j - 1, a.in_off, a.in_cnt);
+            pr_next = level_pair<NJ, FIRST>(a, w, j - 1);
+          }
+          break;
+        }
+      }
+      const Fq r = (step == 2 || step == 4) ? fp_sqr(A) : fp_mul(A, B);
+      switch (step) {
+        case 0: T0 = r; break;
+        case 1: inv = r; any_dbl = __any(kind == PK_DBL); break;
+        case 2: T1 = fp_add(fp_dbl(r), r); break;                   // [6]
+        case 3: T1 = r; break;
+        case 4: {                                                   // x3 = lambda^2 - x1 - x2  (stored at once; kept in T0 for y3)
+          Fq x1 = fp_unpack32<FqParams>(pw), x2 = x1;
+          if (kind == PK_ADD) x2 = fp_unpack32<FqParams>(pw + 24);
+          T0 = fp_canon_4p(fp_sub<FqParams, 2>(r, fp_add(x1, x2)));
+          uint32_t ox[24];
+          fp_pack32<FqParams>(T0, ox);
+          aff_st_words(a.dst[j].x, ox);
+          aff_ld_words(pr.p1->y, pw + 24);                          // y1 for the end of step 5 (x1 stays in pw[0 .. 24))
+          break;
+        }
+        default: {                                                  // y3 = lambda (x1 - x3) - y1
+          uint32_t oy[24];
+          fp_pack32<FqParams>(fp_canon_4p(fp_sub<FqParams, 2>(r, aff_y_eff(pw + 24, pr.neg1))), oy);
+          aff_st_words(a.dst[j].y, oy);
+          break;
+        }
+      }
+    }
+    if (kind > PK_DBL) {                                            // no sum: overwrite what the program above stored for this output
+      uint32_t ox[24], oy[24];
+      if (kind == PK_INF) {
+#pragma unroll
+        for (int k = 0; k < 24; k++) { ox[k] = ZK_AFF_INF_WORD; oy[k] = 0; }
+      } else {                                                      // the pair's finite point passes through (sign applied)
+        const AffPacked* q = (kind == PK_FIRST) ? pr.p1 : pr.p2;
+        const bool neg = (kind == PK_FIRST) ? pr.neg1 : pr.neg2;
+        aff_ld_words(q->x, ox); aff_ld_words(q->y, oy);
+        if (neg) fp_pack32<FqParams>(fp_canon_4p(aff_y_eff(oy, true)), oy);
+      }
+      aff_st_words(a.dst[j].x, ox); aff_st_words(a.dst[j].y, oy);
+    }
+    pr = pr_next;
+  }
 }
 
 // Point operations on memory accumulators executed by one lane (QUAD = false: throughput-bound
@@ -671,6 +871,28 @@ static size_t slice_target() {
   return v;
 }
 
+static int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = getenv(name);
+  if (!e) return dflt;
+  int v = atoi(e);
+  return (v < lo || v > hi) ? dflt : v;
+}
+// upper bound on the size of level l+1 given a bound on level l: ceil(n/2) summed over at most min(nb, m) non-empty buckets
+static size_t level_bound(size_t m, size_t nb) { return (m + (m < nb ? m : nb)) / 2; }
+static int g_aff_forced = -2;      // -2: not set (environment, then automatic); -1: automatic; >= 0: that many levels
+void msm_force_aff_levels(int levels) { g_aff_forced = levels < -1 ? -1 : (levels > MSM_MAX_AFF_LEVELS ? MSM_MAX_AFF_LEVELS : levels); }
+int msm_forced_aff_levels() { return g_aff_forced == -2 ? env_int("ZKHIP_AFF_LEVELS", -1, 0, MSM_MAX_AFF_LEVELS) : g_aff_forced; }
+// How many batched-affine levels run before the XYZZ accumulation.  Automatic = NONE: measured on gfx950 (DESIGN.md section 5,
+// profiles/r02_affine_*), one level over the 10.2 M pairs of a 2^20-term MSM takes 7.3 ms where the XYZZ kernel spends 6.1 ms on
+// the same additions - 25 % fewer VALU instructions per addition, but 3.6 x the memory instructions (every operand is gathered
+// in the forward AND the backward pass) at two waves per SIMD.  The levels stay available (zkhip_set_affine_levels,
+// ZKHIP_AFF_LEVELS) and tested: they compute the same group element.
+static int choose_aff_levels(size_t m_entries, size_t nb) {
+  (void)m_entries; (void)nb;
+  int forced = msm_forced_aff_levels();
+  return forced >= 0 ? forced : 0;
+}
+
 int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   memset(ctx, 0, sizeof *ctx);
   if (K < 1 || K > MSM_MAX_JOBS || (!merged && K != 1)) return ZKHIP_ERR_ARG;
@@ -705,10 +927,35 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   HIP_TRY(hipMalloc(&ctx->cursor, nb * 4));
   HIP_TRY(hipMalloc(&ctx->block_tot, (nb / 1024 + 2) * 4));
   HIP_TRY(hipMalloc(&ctx->entries, (size_t)K * ctx->Wd * max_n * 4));
+  // batched-affine levels: bounds on the level sizes, the buffers of their outputs
+  {
+    size_t m = (size_t)K * ctx->Wd * max_n;
+    ctx->aff_levels = choose_aff_levels(m, nb);
+    ctx->aff_forced = msm_forced_aff_levels();
+    ctx->aff_m = (uint32_t)env_int("ZKHIP_AFF_M", 64, 4, 512);
+    ctx->aff_lanes = 1u << 18;                                           // lanes per launch: 2^18 * aff_m * 108 B of scratch
+    const size_t m_cap = (size_t)ctx->aff_m * 3 / 2;                      // a launch may use up to 1.5 aff_m outputs per lane (whole fills)
+    while ((size_t)ctx->aff_lanes * m_cap * 108 >= ((size_t)1 << 32)) ctx->aff_lanes >>= 1;         // one buffer descriptor
+    size_t bound[MSM_MAX_AFF_LEVELS + 1];
+    bound[0] = m;
+    for (int l = 0; l < ctx->aff_levels; l++) {
+      bound[l + 1] = level_bound(bound[l], nb);
+      HIP_TRY(hipMalloc(&ctx->lcnt[l], nb * 4));
+      HIP_TRY(hipMalloc(&ctx->loff[l], nb * 4));
+    }
+    if (ctx->aff_levels > 0) {
+      HIP_TRY(hipMalloc(&ctx->pbuf[0], (bound[1] + 1) * sizeof(AffPacked)));
+      if (ctx->aff_levels > 1) HIP_TRY(hipMalloc(&ctx->pbuf[1], (bound[2] + 1) * sizeof(AffPacked)));
+      size_t lanes = (bound[1] + ctx->aff_m - 1) / ctx->aff_m;
+      if (lanes < ctx->aff_lanes) ctx->aff_lanes = (uint32_t)((lanes + 255) & ~(size_t)255);
+      HIP_TRY(hipMalloc(&ctx->aff_scratch, (size_t)ctx->aff_lanes * m_cap * 108));
+    }
+    ctx->m_acc_max = bound[ctx->aff_levels];
+  }
   // slice length: every lane gets the same number of point operations; aim at a whole number of
   // machine fills (256 CUs x 8 waves x 64 lanes at two waves per SIMD)
   {
-    const size_t lanes = 131072, m_max = (size_t)K * ctx->Wd * max_n;
+    const size_t lanes = 131072, m_max = ctx->m_acc_max;
     size_t fills = (m_max + lanes * slice_target() - 1) / (lanes * slice_target());     // ~48 entries per lane and fill
     if (fills < 1) fills = 1;
     size_t S = (m_max + lanes * fills - 1) / (lanes * fills);
@@ -737,7 +984,8 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
 void msm_plan_free(MsmCtx* ctx) {
   void* ptrs[] = {ctx->digits, ctx->counts, ctx->offsets, ctx->cursor, ctx->block_tot, ctx->entries, ctx->buckets,
                   ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi,
-                  ctx->colS[0], ctx->colS[1], ctx->hilo};
+                  ctx->colS[0], ctx->colS[1], ctx->hilo, ctx->pbuf[0], ctx->pbuf[1], ctx->aff_scratch,
+                  ctx->lcnt[0], ctx->lcnt[1], ctx->lcnt[2], ctx->lcnt[3], ctx->loff[0], ctx->loff[1], ctx->loff[2], ctx->loff[3]};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->win_host) (void)hipHostFree(ctx->win_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -815,12 +1063,51 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
                        jb.table_stride, (uint32_t)(k * B), ctx->offsets, ctx->cursor, ctx->entries);
   }
   const int bshift = merged ? c - 1 : 31;     // bucket -> job
-  HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 4, st));   // block_tot[0] is reused as the max-span cell (scan is done)
+  HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
+  // ---- batched-affine levels: the sorted list is summed pairwise inside every bucket, ctx->aff_levels times
+  const uint32_t *cur_off = ctx->offsets, *cur_cnt = ctx->counts;
+  size_t m_cur = (size_t)Wd * (n_eff ? n_eff : 1);       // entries that can occur: a base at infinity never produces one
+  for (int l = 0; l < ctx->aff_levels; l++) {
+    const size_t m_out = level_bound(m_cur, nb);
+    hipLaunchKernelGGL(k_half_counts, dim3(nblk(nb, 256)), dim3(256), 0, st, cur_cnt, ctx->lcnt[l], nb);
+    hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->lcnt[l], ctx->loff[l], ctx->block_tot, nb);
+    hipLaunchKernelGGL(k_scan_tot, dim3(1), dim3(1024), 0, st, ctx->block_tot, (size_t)sb);
+    hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, ctx->loff[l], ctx->block_tot, nb);
+    LevelArgs la;
+    la.bp = bp; la.bshift = bshift; la.entries = ctx->entries; la.src = l ? ctx->pbuf[(l - 1) & 1] : nullptr;
+    la.in_off = cur_off; la.in_cnt = cur_cnt; la.out_off = ctx->loff[l];
+    la.nb = (uint32_t)nb; la.m = ctx->aff_m; la.dst = ctx->pbuf[l & 1]; la.scratch = ctx->aff_scratch;
+    // outputs per lane: as close to aff_m as a whole number of machine fills allows (131072 lanes are resident at two waves per
+    // SIMD; a partial last fill runs at a fraction of the chip)
+    {
+      const size_t fill = 131072;
+      size_t rounds = (m_out + fill * ctx->aff_m / 2) / (fill * ctx->aff_m);
+      if (rounds >= 1) {
+        size_t mm = (m_out + fill * rounds - 1) / (fill * rounds);
+        la.m = (uint32_t)(mm > ctx->aff_m * 3 / 2 ? ctx->aff_m * 3 / 2 : mm);
+      }
+    }
+    const size_t lanes_tot = (m_out + la.m - 1) / la.m;
+    for (size_t lane0 = 0; lane0 < lanes_tot; lane0 += ctx->aff_lanes) {
+      const size_t ln = lanes_tot - lane0 < ctx->aff_lanes ? lanes_tot - lane0 : ctx->aff_lanes;
+      la.lane0 = (uint32_t)lane0; la.lanes = ctx->aff_lanes;       // row length of the scratch: fixed; lanes beyond ln do not exist
+      const dim3 grid(nblk(ln, 256));
+      if (l == 0) {
+        if (ctx->K == 1) hipLaunchKernelGGL((k_affine_level<1, true>), grid, dim3(256), 0, st, la);
+        else hipLaunchKernelGGL((k_affine_level<MSM_MAX_JOBS, true>), grid, dim3(256), 0, st, la);
+      } else {
+        hipLaunchKernelGGL((k_affine_level<1, false>), grid, dim3(256), 0, st, la);
+      }
+    }
+    cur_off = ctx->loff[l]; cur_cnt = ctx->lcnt[l]; m_cur = m_out;
+  }
+  const bool dense = ctx->aff_levels > 0;
+  if (dense) bp.p[0] = ctx->pbuf[(ctx->aff_levels - 1) & 1];
+  HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 4, st));   // block_tot[0] is reused as the max-span cell (scans are done)
   // slice length for THIS n (the plan's slot array is sized for max_n)
   uint32_t S_run, T_run;
   {
-    // entries that can occur: a base at infinity never produces one (a sparse B query of a real key is 40 % infinity)
-    const size_t lanes = 131072, m = (size_t)Wd * (n_eff ? n_eff : 1);
+    const size_t lanes = 131072, m = m_cur;
     size_t fills = (m + lanes * slice_target() - 1) / (lanes * slice_target());
     if (fills < 1) fills = 1;
     size_t S = (m + lanes * fills - 1) / (lanes * fills);
@@ -829,25 +1116,25 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     S_run = (uint32_t)S; T_run = (uint32_t)((m + S - 1) / S);
   }
   HIP_TRY(hipMemsetAsync(ctx->buckets, 0, (size_t)ctx->slot_stride * 108 * 4, st));
-  HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
-  if (ctx->K == 1)
-    hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, ctx->entries, ctx->offsets, ctx->counts,
+  const uint32_t* acc_entries = dense ? nullptr : ctx->entries;
+  if (ctx->K == 1 || dense)
+    hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off, cur_cnt,
                        (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
   else
-    hipLaunchKernelGGL(k_accumulate<MSM_MAX_JOBS>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, ctx->entries, ctx->offsets,
-                       ctx->counts, (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
+    hipLaunchKernelGGL(k_accumulate<MSM_MAX_JOBS>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off,
+                       cur_cnt, (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
   for (uint32_t d = 1; d < T_run; d <<= 1) {
     // d = 1 touches up to every slice (throughput-bound: one lane per addition); later rounds only serve
     // oversized buckets and are latency-bound (a quad per addition)
     if (d == 1)
-      hipLaunchKernelGGL(k_fixup_round<false>, dim3(nblk(T_run, 256)), dim3(256), 0, st, ctx->offsets, ctx->counts, (uint32_t)nb, S_run, T_run,
+      hipLaunchKernelGGL(k_fixup_round<false>, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, T_run,
                          d, ctx->block_tot + 0, ctx->buckets, ctx->slot_stride);
     else
-      hipLaunchKernelGGL(k_fixup_round<true>, dim3(nblk((size_t)T_run * 4, 256)), dim3(256), 0, st, ctx->offsets, ctx->counts, (uint32_t)nb, S_run,
+      hipLaunchKernelGGL(k_fixup_round<true>, dim3(nblk((size_t)T_run * 4, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run,
                          T_run, d, ctx->block_tot + 0, ctx->buckets, ctx->slot_stride);
   }
-  hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, ctx->offsets, ctx->counts, (uint32_t)nb, S_run, T_run,
+  hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, T_run,
                      ctx->buckets, ctx->slot_stride);
   HIP_TRY(hipGetLastError());
 

@@ -137,7 +137,7 @@ int auto_table_window(size_t n) {
 int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1) {
   const int c = table_c ? table_c : auto_window(n), merged = table_c ? 1 : 0;
   if (*ready && cx->pending) return fail(ZKHIP_ERR_STATE, "an MSM submitted on this context has not been collected (zkhip_msm_collect)");
-  if (*ready && cx->max_n >= n && cx->c == c && cx->merged == merged && cx->K == K) return ZKHIP_OK;
+  if (*ready && cx->max_n >= n && cx->c == c && cx->merged == merged && cx->K == K && cx->aff_forced == msm_forced_aff_levels()) return ZKHIP_OK;
   if (*ready) { msm_plan_free(cx); *ready = false; }
   int rc = msm_plan_init(cx, n, c, merged, K);
   if (rc != ZKHIP_OK) {
@@ -269,6 +269,11 @@ int zkhip_bases_upload(const uint64_t* bases_affine, size_t len, zkhip_bases** o
 
 size_t zkhip_bases_len(const zkhip_bases* b) { return b ? b->len : 0; }
 
+int zkhip_set_affine_levels(int levels) {
+  if (levels < -1 || levels > MSM_MAX_AFF_LEVELS) return fail(ZKHIP_ERR_ARG, "levels must be -1 (automatic) or in [0, 4]");
+  msm_force_aff_levels(levels);
+  return ZKHIP_OK;
+}
 int zkhip_set_crs_precompute(int on) { g.crs_tables = on ? 1 : 0; return ZKHIP_OK; }
 int zkhip_set_batch_msms(int on) { g.batch_msms = on ? 1 : 0; return ZKHIP_OK; }
 

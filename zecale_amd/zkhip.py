@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkhip.so")
 
 EXPORTS = [
-    "zkhip_init", "zkhip_set_device", "zkhip_get_device", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window",
+    "zkhip_init", "zkhip_set_device", "zkhip_get_device", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window", "zkhip_set_affine_levels",
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
     "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window", "zkhip_set_batch_msms",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_msm_submit", "zkhip_msm_collect",
@@ -148,6 +148,11 @@ def get_device():
 
 def set_msm_window(c):
     _check(load().zkhip_set_msm_window(c))
+
+
+def set_affine_levels(levels):
+    """Batched-affine levels in front of the XYZZ bucket accumulation: -1 automatic, 0 none, up to 4."""
+    _check(load().zkhip_set_affine_levels(int(levels)))
 
 
 def set_batch_msms(on):
