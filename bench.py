@@ -10,10 +10,15 @@ independent units: rank r owns its own 2^20-term slice of an N * 2^2
 scaling); the only exchange is an all-gather of the N partial sums (288 B each) over RCCL and
 N - 1 group additions on every rank (zecale_amd/dist.py).
 
-`--workload prover` times BASELINE configs[2] instead (full Groth16 prover: SpMV + 7 NTT + 5 MSM +
-tail at 2^log_n constraints, synthetic R1CS and proving key of that shape).
-`--workload aggregator` times the real wrapping circuit (batch of 2 nested BLS12-377 Groth16 proofs verified
-in-circuit, 51k constraints): witness generation on the host + proof on the GPU, end to end.
+The default line also carries, measured after the timed region on rank 0 (N = 1):
+  `plain_path`       the same MSM on a base set WITHOUT window tables (one-shot keys)
+  `prover_2_20`      BASELINE configs[2] at the size `metric` quotes: a satisfiable 2^20-constraint system, trusted setup on
+                     the GPU, proofs through two prover instances, the last proof verified with the host pairing check
+  `wrapping_prover`  the real batch-2 aggregator circuit (44,183 constraints) through the streaming prover, witness generation
+                     included, with its own `roofline` (k_accumulate<5>) and `cpu_baseline` (the C restatement proving the same batch)
+
+`--workload prover` times configs[2] as the main metric (`--gpus N`: ONE proof per step over a key partitioned N ways),
+`--workload aggregator` the wrapping circuit (`--gpus N`: replicas).
 
 Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` and `cpu_baseline`.
 """
@@ -33,17 +38,47 @@ ALG_BYTES_PER_TERM = 240      # 192 B affine base + 48 B scalar, each read once 
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md (spec; 6.29 TB/s measured copy)
 FQ_MUL_PEAK_PER_S = 19.5e9    # chip-wide peak of the Fq Montgomery multiplier, measured (tools/ubench/fqmul_bench.hip)
 MULS_PER_MIXED_ADD = 10       # madd-2008-s: 8 M + 2 S, every one through the same multiplier
+R_MOD = 0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001
 
 
-def random_fr_canonical(seed, n):
-    """n x 6 limbs of canonical scalars < 2^376 < r from a splitmix64 stream."""
-    x = (np.arange(1, n * 6 + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)).astype(np.uint64)
+def _splitmix(seed, count):
+    x = (np.arange(1, count + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)).astype(np.uint64)
     x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
     x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
     x ^= x >> np.uint64(31)
-    a = x.reshape(n, 6)
+    return x
+
+
+def random_fr_canonical(seed, n):
+    """n x 6 limbs of canonical scalars < 2^376 < r from a splitmix64 stream (key generation, test inputs)."""
+    a = _splitmix(seed, n * 6).reshape(n, 6)
     a[:, 5] &= np.uint64((1 << 56) - 1)
     return a
+
+
+_R_LIMBS = [(R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]
+
+
+def random_fr_uniform(seed, n):
+    """n x 6 limbs UNIFORM in [0, r): 377-bit draws from a splitmix64 stream, rejected when >= r (16 % are)."""
+    a = _splitmix(seed, n * 6).reshape(n, 6)
+    a[:, 5] &= np.uint64((1 << 57) - 1)
+    rnd = 0
+    while True:
+        ge = np.zeros(n, dtype=bool)          # lexicographic a >= r from the top limb down
+        undecided = np.ones(n, dtype=bool)
+        for k in range(5, -1, -1):
+            rk = np.uint64(_R_LIMBS[k])
+            ge |= undecided & (a[:, k] > rk)
+            undecided &= a[:, k] == rk
+        ge |= undecided
+        bad = np.nonzero(ge)[0]
+        if bad.size == 0:
+            return a
+        rnd += 1
+        fresh = _splitmix(seed ^ (0xD1B54A32D192ED03 * rnd & 0xFFFFFFFFFFFFFFFF), bad.size * 6).reshape(bad.size, 6)
+        fresh[:, 5] &= np.uint64((1 << 57) - 1)
+        a[bad] = fresh
 
 
 def g1_generator_limbs():
@@ -58,6 +93,15 @@ def g1_generator_limbs():
     return np.array(out, dtype=np.uint64)
 
 
+def fr_mont(x):
+    m = (x << 384) % R_MOD
+    return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)], dtype=np.uint64)
+
+
+def zkhip_fr_one():
+    return [int(v) for v in fr_mont(1)]
+
+
 def measured_traffic():
     """HBM bytes per k_accumulate launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -67,6 +111,40 @@ def measured_traffic():
         except Exception:
             return None
     return None
+
+
+def host_threads():
+    """Host cores this process may actually use: the GPU box caps a one-GPU job with a cgroup CPU quota (16 of its 256 hardware
+    threads); OpenMP would otherwise start one thread per hardware thread and split an MSM into that many tiny chunks."""
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    avail = len(os.sched_getaffinity(0))
+    return min(avail, quota) if quota else avail
+
+
+def chain_system(log_n, seed=11):
+    """A satisfiable system with 2^log_n - 8 constraints, 4 primary inputs (the wrapping circuit's count): constraint i multiplies two
+    earlier variables into a new one.  Returns (A, B, C) CSR triples, z (Montgomery limbs), m, l."""
+    n, l = (1 << log_n) - 8, 4
+    m = n + l + 1
+    rng = np.random.default_rng(seed)
+    vals = [1, 3, 5, 7, 11] + [0] * n
+    lo = rng.integers(0, 1 << 62, size=n)
+    grow = np.arange(l + 1, l + 1 + n, dtype=np.uint64)
+    a_idx = (lo.astype(np.uint64) % grow).astype(np.uint32)
+    b_idx = ((lo.astype(np.uint64) >> np.uint64(31)) % grow).astype(np.uint32)
+    al, bl = a_idx.tolist(), b_idx.tolist()
+    for i in range(n):
+        vals[l + 1 + i] = vals[al[i]] * vals[bl[i]] % R_MOD
+    shift = 1 << 384
+    z = np.frombuffer(b"".join((v * shift % R_MOD).to_bytes(48, "little") for v in vals), dtype=np.uint64).reshape(m, 6).copy()
+    rp = np.arange(n + 1, dtype=np.uint32)
+    ones = np.tile(z[0], (n, 1))
+    return (rp, a_idx, ones), (rp, b_idx, ones), (rp, np.arange(l + 1, m, dtype=np.uint32), ones), z, m, l
 
 
 def main():
@@ -84,7 +162,7 @@ def main():
     ap.add_argument("--gpu-slots", type=int, default=6, help="aggregator pipeline: proofs in flight on the GPU")
     ap.add_argument("--witness-workers", type=int, default=8, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
     ap.add_argument("--cpu-sample-log", type=int, default=20)
-    ap.add_argument("--no-secondary", action="store_true", help="msm workload: skip the wrapping-proofs/s measurement after the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="msm workload: skip the measurements that follow the timed region")
     args = ap.parse_args()
 
     # the aggregator pipeline keeps several proofs in flight, each on its own streams: give the HIP runtime more than its
@@ -128,21 +206,25 @@ def main():
         torch.cuda.synchronize()
 
     extra = {}
+    collected = []            # msm workload: (index of the scalar vector, result) of MSMs finished inside the timed region
     if args.workload == "msm":
         bases_dev = gen_bases(0x5EED + 1000 * rank, n)
         bases = zkhip.Bases.upload_dev(bases_dev.data_ptr(), n)
         if not args.no_table:
             bases.precompute()          # setup-time, like loading the proving key: not part of a step
         extra["table_window"] = bases.table_window
-        scal_dev = [torch.from_numpy(random_fr_canonical(0xABC0 + 17 * i + 1000 * rank, n).view(np.int64)).to(dev)
-                    for i in range(min(args.steps + args.warmup, 4))]
+        # scalars: uniform in [0, r), as libff holds them (Montgomery residues: the ABI's form, include/zkhip.h)
+        n_sets = min(args.steps + args.warmup, 4)
+        scal_dev = [torch.from_numpy(random_fr_uniform(0xABC0 + 17 * i + 1000 * rank, n).view(np.int64)).to(dev) for i in range(n_sets)]
         torch.cuda.synchronize()
 
         combine = (lambda part: zdist.combine_partial_sums(part, device=dev)) if (world > 1 or force_dist) else (lambda part: part)
         if args.serial:
             def step(i):
-                s = scal_dev[i % len(scal_dev)]
-                return combine(bases.msm_dev(s.data_ptr(), n, montgomery=False))
+                s = scal_dev[i % n_sets]
+                part = bases.msm_dev(s.data_ptr(), n, montgomery=True)
+                collected.append((i % n_sets, part))
+                return combine(part)
         else:
             # a stream of MSMs on the resident bases, two in flight (zkhip_msm_submit / zkhip_msm_collect): step i enqueues
             # MSM i and collects MSM i-1; drain() inside the timed region collects the last one.  Every step is one full MSM.
@@ -152,7 +234,7 @@ def main():
             inflight, exchanging = [], []
             distributed = world > 1 or force_dist
             for slot in (0, 1):       # set-up: allocate both slots' work space once (like any buffer allocation, not part of a step)
-                bases.msm_submit(scal_dev[0].data_ptr(), n, slot=slot, montgomery=False)
+                bases.msm_submit(scal_dev[0].data_ptr(), n, slot=slot, montgomery=True)
                 zkhip.msm_collect(slot)
 
             def settle(keep):
@@ -161,12 +243,18 @@ def main():
                     out = exchanging.pop(0).result()
                 return out
 
+            def collect_oldest():
+                slot, which = inflight.pop(0)
+                part = zkhip.msm_collect(slot)
+                collected.append((which, part))
+                return part
+
             def step(i):
-                s = scal_dev[i % len(scal_dev)]
-                bases.msm_submit(s.data_ptr(), n, slot=i % 2, montgomery=False)
-                inflight.append(i % 2)
+                s = scal_dev[i % n_sets]
+                bases.msm_submit(s.data_ptr(), n, slot=i % 2, montgomery=True)
+                inflight.append((i % 2, i % n_sets))
                 if len(inflight) > 1:
-                    part = zkhip.msm_collect(inflight.pop(0))
+                    part = collect_oldest()
                     if not distributed:
                         return part
                     out = settle(0)
@@ -176,7 +264,7 @@ def main():
             def drain():
                 out = None
                 while inflight:
-                    part = zkhip.msm_collect(inflight.pop(0))
+                    part = collect_oldest()
                     if distributed:
                         exchanging.append(zdist.combine_partial_sums_async(part, device=dev))
                     else:
@@ -192,7 +280,7 @@ def main():
         desc = zkhip.r1cs_desc_from_aggregator(agg)
         kp = zkhip.Keypair(desc, *trapdoor)
         crs, r1 = kp.upload_crs(), zkhip.r1cs_from_desc(desc)
-        rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
+        rr, ss = random_fr_uniform(5, 1)[0], random_fr_uniform(6, 1)[0]
         wit_ms = []
         if args.serial:
             # two-stage overlap only: a host thread generates the witness of batch i+1 (ctypes releases the GIL) while
@@ -234,67 +322,28 @@ def main():
         units_per_step = world
         n = agg.num_constraints
     else:
-        # synthetic R1CS of the wrapping circuit's shape: n constraints, n + 5 variables, 4 primary inputs, <= 3 terms per row
-        rng = np.random.default_rng(1234)               # the circuit and the witness are the same on every rank
-        n = n - 8                    # n + l + 1 <= 2^log_n: the QAP domain (and the H query) has exactly 2^log_n points
-        m, l = n + 5, 4
-        def rand_csr(terms):
-            cols = rng.integers(0, m, size=(n, terms), dtype=np.uint32).reshape(-1)
-            rp = (np.arange(n + 1, dtype=np.uint32) * terms)
-            vals = random_fr_canonical(int(rng.integers(1 << 30)), n * terms)
-            return rp, cols, vals
-        csr = (rand_csr(2), rand_csr(2), rand_csr(2))
-        r1 = zkhip.R1cs(*csr, m, l)
-        d = 1 << r1.log_d
-        consts = dict(alpha_g1=g1, beta_g1=g1, beta_g2=g1, delta_g1=g1, delta_g2=g1)
-        # N > 1: ONE proof per step, the proving key partitioned over the ranks (strong scaling, BASELINE configs[3]):
-        # every rank holds a 1/N slice of each query vector and the ranks exchange 5 x 288 bytes per proof.
-        a_rng, h_rng, l_rng = zdist.key_slices(m, l, d, world, rank)
-        pk = {}
-        for key, (lo, hi), seed in (("A", a_rng, 1), ("B2", a_rng, 2), ("B1", a_rng, 3), ("H", h_rng, 4), ("L", l_rng, 5)):
-            pk[key] = gen_bases(seed * 7919 + rank, hi - lo).cpu().numpy().view(np.uint64)
-        crs = zkhip.crs_from_slice_arrays(consts, pk, m, l, d, a_rng, h_rng, l_rng)
-        del pk
-        # witness shaped like the wrapping circuit's: 1.3 % of its 44,188 variables are 0 or 1 (measured on the real
-        # batch-2 witness: 590 zeros, 27 ones - the variables are Fq elements of the in-circuit pairing), the rest uniform
-        z = random_fr_canonical(99, m)
-        sel = rng.random(m)
-        one_m = np.array(zkhip_fr_one(), dtype=np.uint64)
-        z[sel < 0.0128] = 0
-        z[(sel >= 0.0128) & (sel < 0.0134)] = one_m
-        z[0] = one_m
-        rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
-
+        # BASELINE configs[2] / [3]: a satisfiable system of 2^log_n - 8 constraints (4 primary inputs, the wrapping circuit's count;
+        # about a third of its B query is the point at infinity, as in a real key), trusted setup on the GPU from a fixed trapdoor,
+        # so that the proofs VERIFY.  The circuit, the key and the witness are the same on every rank.
+        fs = FullSizeProver(zkhip, args.log_n, world, rank)
+        n, crs, r1 = fs.n, fs.crs, fs.r1
+        a_rng, h_rng, l_rng = fs.ranges
+        z, rr, ss = fs.z, fs.rr, fs.ss
         if world > 1 or force_dist or args.serial:
             def step(i):
                 if world > 1 or force_dist:
-                    return zdist.prove_distributed(crs, r1, consts, z, rr, ss, device=dev)
-                return zkhip.groth16_finish(consts, zkhip.groth16_prove_partial(crs, r1, z), rr, ss)
+                    fs.last = zdist.prove_distributed(crs, r1, fs.consts, z, rr, ss, device=dev)
+                else:
+                    fs.last = zkhip.groth16_finish(fs.consts, zkhip.groth16_prove_partial(crs, r1, z), rr, ss)
+                return fs.last
         else:
             # one GPU, whole key: two prover instances (zkhip_prover: own streams and work space), one host thread each, keep two
             # proofs in flight - the upload, the QAP map, the latency-bound end of the bucket reduction and the host tail of one
             # proof run under the accumulation of the other.  Every step is one full proof; drain() collects inside the timed region.
-            from concurrent.futures import ThreadPoolExecutor
-            desc, keep_csr = zkhip.make_r1cs_desc(*csr, m, l)
-            provers = [zkhip.Prover(crs, desc) for _ in range(2)]
-            for p_ in provers:          # set-up: every instance allocates its work space on its first proof
-                p_.prove(z, rr, ss)
-            pool2 = ThreadPoolExecutor(max_workers=2)
-            futs = []
-
-            def step(i):
-                futs.append(pool2.submit(provers[i % 2].prove, z, rr, ss))
-                if len(futs) > 1:
-                    return futs.pop(0).result()
-
-            def drain():
-                out = None
-                while futs:
-                    out = futs.pop(0).result()
-                return out
+            step, drain = fs.two_in_flight()
             extra["drain"] = drain
             extra["proofs_in_flight"] = 2
-            extra["accumulate_ms"] = lambda: max(p.last_accumulate_ms() for p in provers)
+            extra["accumulate_ms"] = lambda: max(p.last_accumulate_ms() for p in fs.provers)
         units_per_step = 1
         extra["scaling_override"] = "strong"
 
@@ -305,6 +354,7 @@ def main():
         step(i)
     drain()
     barrier()
+    del collected[:]
     kernel_ms, phase = [], []
     cpu0 = os.times()
     t0 = time.time()
@@ -347,17 +397,18 @@ def main():
         else:
             value, unit = units_per_step * args.steps / dt, "proofs/s"
             metric = "wrapping proofs/sec (Groth16 over BW6_761, 2^%d constraints)" % args.log_n
-            workload = ("BASELINE configs[2]: full Groth16 BW6_761 prover (SpMV + 7 NTT + 5 MSM), synthetic R1CS 2^%d constraints, "
-                        "4 primary inputs, random proving key of that shape" % args.log_n)
+            workload = ("BASELINE configs[2]: full Groth16 BW6_761 prover (SpMV + 7 NTT + 5 MSM), satisfiable R1CS of 2^%d - 8 constraints, "
+                        "4 primary inputs, trusted setup on the GPU; the last proof is verified (host pairing check)" % args.log_n)
             # one accumulation launch serves all five MSMs of a proof (table-backed key), else the last MSM of a proof is L
             al, hl, ll = a_rng[1] - a_rng[0], h_rng[1] - h_rng[0], l_rng[1] - l_rng[0]      # this rank's slice of the key
             terms_in_kernel = (3 * al + hl + ll) if tw_batched(extra, args) else ll
             if phase:
                 extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
+            extra["last_proof_verifies"] = fs.verify_last()
         tw_batched_flag = tw_batched(extra, args)
         tw = extra.pop("table_window", None)
         digits = -(-378 // tw) if tw else 24 if terms_in_kernel > (1 << 18) else None
-        timed = k_ms > 0        # the prover replays captured hipGraphs: no per-kernel events there (profiles/ has the kernel traces)
+        timed = k_ms > 0
         if not timed:
             k_ms = float("nan")
         achieved = ALG_BYTES_PER_TERM * terms_in_kernel / (k_ms * 1e-3) / 1e9 if timed else None
@@ -366,31 +417,25 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "terms_per_gpu": n,
+                       "scalars": "uniform in [0, r), Montgomery residues as libff holds them" if args.workload == "msm" else "the circuit's witness",
                        "bases": ("resident in HBM (proving key) with window tables: 2^(%d w) P_i for the %d window positions, built at "
                                  "key-load time, %d x the key's memory" % (tw, digits, digits)) if tw else "resident in HBM (proving key)",
                        "arithmetic": "761-bit Montgomery integers as 27 x 29-bit limbs in u32, products via v_mad_u64_u32",
                        "parallelism": "point-partitioned x%d, RCCL all-gather of 288-byte partial sums" % world},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3) if timed else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6) if timed else None, "traffic": measured_traffic() if (timed and args.workload == "msm") else None,
-                         "kernel": "zkhip::k_accumulate<1>" if args.workload == "msm" else ("zkhip::k_accumulate<5>" if tw_batched_flag else "zkhip::k_accumulate<1>"), "kernel_ms": round(k_ms, 3) if timed else None,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_TERM * terms_in_kernel,
-                         "note": "this path is integer-multiply bound, not HBM bound (SURVEY 0.5): fq_mul_frac = Fq "
-                                 "multiplications per second in the kernel / measured chip peak of the multiplier",
-                         "fq_mul_frac": round(terms_in_kernel * digits * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4) if (timed and digits) else None,   # upper bound when some scalars are 0
-                         "mixed_additions_per_term": digits},
+            "roofline": roofline_obj("zkhip::k_accumulate<1>" if (args.workload == "msm" or not tw_batched_flag) else "zkhip::k_accumulate<5>",
+                                     terms_in_kernel, digits, k_ms if timed else None,
+                                     measured_traffic() if (timed and args.workload == "msm") else None),
         }
         if args.workload == "msm" and not args.serial and timed and digits:
             # the timed region streams two MSMs at a time, so its k_accumulate shares the chip with the reduction tail of the
             # previous MSM; for the kernel on its own, two more MSMs one at a time (outside the timed region)
             alone = []
             for i in range(2):
-                bases.msm_dev(scal_dev[i % len(scal_dev)].data_ptr(), n, montgomery=False)
+                bases.msm_dev(scal_dev[i % n_sets].data_ptr(), n, montgomery=True)
                 alone.append(zkhip.last_accumulate_ms())
             ka = float(np.mean(alone))
             out["roofline"]["kernel_ms_alone"] = round(ka, 3)
             out["roofline"]["fq_mul_frac_alone"] = round(terms_in_kernel * digits * MULS_PER_MIXED_ADD / (ka * 1e-3) / FQ_MUL_PEAK_PER_S, 4)
-        if args.workload == "msm" and world == 1 and not force_dist and not args.no_secondary:
-            out["wrapping_prover"] = wrapping_prover_secondary(zkhip, args)
         if "scaling_override" in extra:
             out["scaling"] = extra.pop("scaling_override")
             out["config"]["parallelism"] = "proving key partitioned x%d, RCCL all-gather of 5 x 288-byte partial sums per proof" % world
@@ -399,42 +444,152 @@ def main():
         extra.pop("accumulate_ms", None)
         out.update(extra)
         if not args.no_cpu_baseline:
-            # host cores this process may actually use: the GPU box caps a one-GPU job with a cgroup CPU quota (16 of its 256 hardware
-            # threads); OpenMP would otherwise start one thread per hardware thread and split the MSM into that many tiny chunks
-            quota = None
-            try:
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-                quota = None if q == "max" else max(1, int(int(q) / int(per)))
-            except Exception:
-                pass
-            avail = len(os.sched_getaffinity(0))
             from oracle import oracle as O
             O.load()
-            O.set_threads(min(avail, quota) if quota else avail)
-            ns = 1 << min(args.cpu_sample_log, args.log_n)
-            bs = gen_bases(0x5EED, ns).cpu().numpy().view(np.uint64)
-            ss_ = random_fr_canonical(0xABC0, ns)
+            threads = host_threads()
+            O.set_threads(threads)
             threads = O.max_threads()
-            t, ct = time.time(), os.times()
-            cpu_out = O.msm(bs, ss_, chunks=threads, with_mixed=True)   # canonical words used as Montgomery residues on both sides
-            cpu_dt = time.time() - t
-            ct2 = os.times()
-            busy = ((ct2.user + ct2.system) - (ct.user + ct.system)) / cpu_dt    # cores actually kept busy (a container may cap them)
-            b2 = zkhip.Bases.upload(bs)
-            parity = bool((zkhip.jac_to_affine(b2.msm(ss_, montgomery=True)) == O.jac_to_affine(cpu_out)).all())
-            b2.free()
-            cpu_val = ns / cpu_dt / 1e6
-            out["cpu_baseline"] = {
-                "value": round(cpu_val if args.workload == "msm" else cpu_val * 1e6 / (5.0 * n), 6), "unit": unit, "cores": threads, "kind": "port",
-                "sample": "one 2^%d-term G1 MSM, CPU restatement of libff multi_exp (BDLO12, %d OpenMP chunks, -O2), %.1f s wall, "
-                          "%.1f cores busy on average (process CPU time / wall); "
-                          "not libsnark itself (its sources are absent from the reference tree)%s"
-                          % (ns.bit_length() - 1, threads, cpu_dt, busy,
-                             "" if args.workload == "msm" else "; proofs/s extrapolated as 5 MSMs of 2^%d terms per proof" % args.log_n),
-                "parity_with_gpu_on_sample": parity}
+            if args.workload == "msm":
+                # the SAME bases and the SAME scalar vector 0 as the timed loop (seeds above), so the oracle's output checks a
+                # result that the timed, table-backed submit / collect path produced
+                ns = 1 << min(args.cpu_sample_log, args.log_n)
+                bs = gen_bases(0x5EED, ns).cpu().numpy().view(np.uint64)
+                ss_ = random_fr_uniform(0xABC0, ns)
+                t, ct = time.time(), os.times()
+                cpu_out = O.msm(bs, ss_, chunks=threads, with_mixed=True)
+                cpu_dt = time.time() - t
+                ct2 = os.times()
+                busy = ((ct2.user + ct2.system) - (ct.user + ct.system)) / cpu_dt    # cores actually kept busy (a container may cap them)
+                cpu_aff = O.jac_to_affine(cpu_out)
+                timed_hits = [part for which, part in collected if which == 0] if ns == n else []
+                checked = "a result of the timed loop (scalar vector 0)"
+                if not timed_hits:                                   # too few steps (or a smaller CPU sample): same path, one more MSM
+                    bsub = bases if ns == n else None
+                    if bsub is not None:
+                        bsub.msm_submit(scal_dev[0].data_ptr(), n, slot=0, montgomery=True)
+                        timed_hits = [zkhip.msm_collect(0)]
+                        checked = "one more submit / collect on the timed path (no timed step used scalar vector 0)"
+                    else:
+                        b3 = zkhip.Bases.upload(bs)
+                        if not args.no_table:
+                            b3.precompute()
+                        sd = torch.from_numpy(ss_.view(np.int64)).to(dev)
+                        torch.cuda.synchronize()
+                        b3.msm_submit(sd.data_ptr(), ns, slot=0, montgomery=True)
+                        timed_hits = [zkhip.msm_collect(0)]
+                        b3.free()
+                        checked = "the table-backed submit / collect path on the CPU sample's 2^%d terms" % (ns.bit_length() - 1)
+                parity = all(bool((zkhip.jac_to_affine(p) == cpu_aff).all()) for p in timed_hits)
+                # the plain path (no window table) on the same input: parity and its own rate
+                b2 = zkhip.Bases.upload(bs)
+                plain_ok = bool((zkhip.jac_to_affine(b2.msm(ss_, montgomery=True)) == cpu_aff).all())
+                if ns == n and not args.no_secondary:
+                    sd = scal_dev[0]
+                    ts = []
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        t = time.time()
+                        b2.msm_dev(sd.data_ptr(), n, montgomery=True)
+                        ts.append(time.time() - t)
+                    out["plain_path"] = {"value": round(n / min(ts[1:]) / 1e6, 3), "unit": "Mscalar/s", "ms_per_msm": round(min(ts[1:]) * 1e3, 3),
+                                         "note": "same MSM on a base set without window tables (24 digit positions, one at a time), parity with the oracle checked"}
+                b2.free()
+                cpu_val = ns / cpu_dt / 1e6
+                out["cpu_baseline"] = {
+                    "value": round(cpu_val, 6), "unit": unit, "cores": threads, "kind": "port",
+                    "sample": "one 2^%d-term G1 MSM, CPU restatement of libff multi_exp (BDLO12, %d OpenMP chunks, -O2), %.1f s wall, "
+                              "%.1f cores busy on average (process CPU time / wall); not libsnark itself (its sources are absent from the "
+                              "reference tree)" % (ns.bit_length() - 1, threads, cpu_dt, busy),
+                    "parity_with_gpu_on_sample": bool(parity and plain_ok), "gpu_result_checked": checked,
+                    "timed_results_checked": len(timed_hits)}
+            else:
+                # proofs/s of the C restatement extrapolated from one timed MSM (a whole 2^20 proof takes a minute on these cores)
+                ns = 1 << min(args.cpu_sample_log, 18)
+                bs = gen_bases(0x5EED, ns).cpu().numpy().view(np.uint64)
+                ss_ = random_fr_uniform(0xABC0, ns)
+                t = time.time()
+                O.msm(bs, ss_, chunks=threads, with_mixed=True)
+                cpu_dt = time.time() - t
+                terms = 5.0 * n
+                out["cpu_baseline"] = {"value": round(ns / cpu_dt / terms, 6), "unit": unit, "cores": threads, "kind": "port",
+                                       "sample": "one 2^%d-term G1 MSM of the C restatement (%.1f s); proofs/s extrapolated as 5 MSMs of %d "
+                                                 "terms per proof" % (ns.bit_length() - 1, cpu_dt, n)}
+        if args.workload == "msm" and world == 1 and not force_dist and not args.no_secondary:
+            bases.free()
+            out["prover_2_20"] = prover_secondary(zkhip, args)
+            out["wrapping_prover"] = wrapping_prover_secondary(zkhip, args, cpu=not args.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def roofline_obj(kernel, terms, digits, k_ms, traffic):
+    timed = k_ms is not None and k_ms > 0
+    achieved = ALG_BYTES_PER_TERM * terms / (k_ms * 1e-3) / 1e9 if timed else None
+    return {"bound": "hbm", "achieved": round(achieved, 3) if timed else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 6) if timed else None, "traffic": traffic,
+            "kernel": kernel, "kernel_ms": round(k_ms, 3) if timed else None,
+            "algorithmic_bytes_per_launch": ALG_BYTES_PER_TERM * terms,
+            "note": "this path is integer-multiply bound, not HBM bound (SURVEY 0.5): fq_mul_frac = Fq "
+                    "multiplications per second in the kernel / measured chip peak of the multiplier",
+            "fq_mul_frac": round(terms * digits * MULS_PER_MIXED_ADD / (k_ms * 1e-3) / FQ_MUL_PEAK_PER_S, 4) if (timed and digits) else None,   # upper bound when some scalars are 0
+            "mixed_additions_per_term": digits}
+
+
+class FullSizeProver:
+    """BASELINE configs[2]: satisfiable system, GPU trusted setup, this rank's slice of the key, the witness."""
+
+    def __init__(self, zkhip, log_n, world=1, rank=0):
+        from zecale_amd import dist as zdist
+        self.zk = zkhip
+        A, B, C, self.z, self.m, self.l = chain_system(log_n)
+        self.n = len(A[0]) - 1
+        self.csr = (A, B, C)
+        self.desc, self._keep = zkhip.make_r1cs_desc(A, B, C, self.m, self.l)
+        self.r1 = zkhip.R1cs(A, B, C, self.m, self.l)
+        d = 1 << self.r1.log_d
+        self.kp = zkhip.Keypair(self.desc, fr_mont(0x1234567), fr_mont(0x2345678), fr_mont(0x3456789), fr_mont(0x456789a))
+        self.vk = self.kp.vk()
+        self.ranges = zdist.key_slices(self.m, self.l, d, world, rank)
+        self.consts = self.kp.consts()
+        if world == 1:
+            self.crs = self.kp.upload_crs()
+            self.crs.ranges = self.ranges                       # the whole key is the slice (0, n)
+        else:
+            pk, m, l, dom = self.kp.pk_arrays()
+            self.crs = zkhip.Crs.upload_slice(pk, m, l, dom, *self.ranges)
+            del pk
+        self.rr, self.ss = random_fr_uniform(5, 1)[0], random_fr_uniform(6, 1)[0]
+        self.provers, self.last = [], None
+
+    def two_in_flight(self):
+        from concurrent.futures import ThreadPoolExecutor
+        zk = self.zk
+        self.provers = [zk.Prover(self.crs, self.desc) for _ in range(2)]
+        for p_ in self.provers:          # set-up: every instance allocates its work space on its first proof
+            p_.prove(self.z, self.rr, self.ss)
+        pool2 = ThreadPoolExecutor(max_workers=2)
+        futs = []
+
+        def step(i):
+            futs.append(pool2.submit(self.provers[i % 2].prove, self.z, self.rr, self.ss))
+            if len(futs) > 1:
+                self.last = futs.pop(0).result()
+                return self.last
+
+        def drain():
+            while futs:
+                self.last = futs.pop(0).result()
+            return self.last
+        return step, drain
+
+    def verify_last(self):
+        return bool(self.last is not None and self.zk.groth16_verify(self.vk, self.z[1:1 + self.l], self.last))
+
+    def free(self):
+        for p_ in self.provers:
+            p_.free()
+        self.crs.free(); self.kp.free(); self.r1.free()
 
 
 def aggregator_inputs():
@@ -452,16 +607,55 @@ def aggregator_inputs():
     return nvk_l, npr, nin, trapdoor
 
 
-def wrapping_prover_secondary(zkhip, args, steps=60, warmup=8):
+def prover_secondary(zkhip, args, steps=6, warmup=1):
+    """BASELINE configs[2] at the size `metric` quotes, in the same run after the MSM's timed region (N = 1 only): the
+    `--workload prover` loop - a satisfiable 2^20-constraint system, trusted setup on the GPU, two prover instances in flight -
+    with the last proof verified by the host pairing check before the number is reported."""
+    t_setup = time.time()
+    fs = FullSizeProver(zkhip, LOG_N)
+    setup_s = time.time() - t_setup
+    step, drain = fs.two_in_flight()
+    for i in range(warmup):
+        step(i)
+    drain()
+    t0 = time.time()
+    for i in range(steps):
+        step(warmup + i)
+    drain()
+    dt = time.time() - t0
+    acc_ms = max(p.last_accumulate_ms() for p in fs.provers)
+    # one proof alone for the phase timings
+    proof = zkhip.groth16_prove(fs.crs, fs.r1, fs.z, fs.rr, fs.ss)
+    phases = zkhip.last_prove_timings()
+    same = bool((proof == fs.last).all())
+    ok = fs.verify_last()
+    bad = fs.z[1:1 + fs.l].copy(); bad[2] = fr_mont(6)
+    rejects = not zkhip.groth16_verify(fs.vk, bad, fs.last)
+    al, hl, ll = (b - a for a, b in fs.ranges)
+    tw = fs.crs.table_window
+    digits = -(-378 // tw) if tw else 24
+    out = {"metric": "wrapping proofs/sec (Groth16 over BW6_761, 2^%d constraints): BASELINE configs[2], same run, after the timed region" % LOG_N,
+           "value": round(steps / dt, 3), "unit": "proofs/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+           "constraints": fs.n, "proofs_in_flight": 2, "last_proof_verifies": ok, "wrong_input_rejected": rejects,
+           "serial_proof_identical": same, "setup_s": round(setup_s, 2),
+           "phase_ms_one_proof_alone": {k: round(v, 3) for k, v in phases.items()},
+           "roofline": roofline_obj("zkhip::k_accumulate<5>", 3 * al + hl + ll, digits, acc_ms, None)}
+    fs.free()
+    return out
+
+
+def wrapping_prover_secondary(zkhip, args, steps=60, warmup=8, cpu=True):
     """The other half of BASELINE.json's metric, measured in the same run after the MSM's timed region (N = 1 only): wrapping
     proofs/s of the real batch-2 aggregator circuit through the streaming prover, witness generation included, nothing cached.
-    The same loop as `--workload aggregator`; the last proof is verified (host pairing check) before the number is reported."""
+    The same loop as `--workload aggregator`; the last proof is verified (host pairing check) before the number is reported.
+    `roofline`: k_accumulate<5> of one proof on its own.  `cpu_baseline`: the C restatement proving the IDENTICAL batch (host
+    witness + QAP map + five MSMs + tail) on the host cores, its proof compared limb for limb with the GPU's."""
     nvk_l, npr, nin, trapdoor = aggregator_inputs()
     agg = zkhip.AggregatorCircuit(2, 1)
     desc = zkhip.r1cs_desc_from_aggregator(agg)
     kp = zkhip.Keypair(desc, *trapdoor)
     crs = kp.upload_crs()
-    rr, ss = random_fr_canonical(5, 1)[0], random_fr_canonical(6, 1)[0]
+    rr, ss = random_fr_uniform(5, 1)[0], random_fr_uniform(6, 1)[0]
     pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers)
     depth = args.gpu_slots + args.witness_workers + 2
 
@@ -475,27 +669,61 @@ def wrapping_prover_secondary(zkhip, args, steps=60, warmup=8):
             last = pipe.wait(tickets.pop(0))
         return last
     run(warmup)
-    t0 = time.time()
+    c0, t0 = os.times(), time.time()
     prim, proof = run(steps)
     dt = time.time() - t0
+    c1 = os.times()
     ok = bool(zkhip.groth16_verify(kp.vk(), prim, proof))
     out = {"metric": "wrapping proofs/sec (batch-2 BLS12_377 -> BW6_761 aggregation, %d constraints), same run, after the timed region"
                      % agg.num_constraints,
            "value": round(steps / dt, 3), "unit": "proofs/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
            "last_proof_verifies": ok, "gpu_slots": args.gpu_slots, "witness_workers": args.witness_workers,
+           "host_cores_busy": round(((c1.user + c1.system) - (c0.user + c0.system)) / dt, 2),
            "includes": "host witness generation + QAP + 5 MSMs + host tail per proof, reference dummy_app fixtures, nothing cached"}
-    pipe.free(); crs.free(); kp.free(); agg.free()
+    pipe.free()
+    # one proof on its own: the accumulation kernel's time and the terms it processed
+    r1 = zkhip.r1cs_from_desc(desc)
+    t = time.time()
+    z = agg.witness(nvk_l, npr, nin)
+    wit_ms = (time.time() - t) * 1e3
+    zkhip.groth16_prove(crs, r1, z, rr, ss)
+    one = zkhip.groth16_prove(crs, r1, z, rr, ss)
+    acc_ms = zkhip.last_accumulate_ms()
+    phases = zkhip.last_prove_timings()
+    pk, m, l, dom = kp.pk_arrays()
+    finite = lambda a: int(np.count_nonzero(a.reshape(-1, 24).any(axis=1)))
+    terms = sum(finite(pk[k]) for k in ("A", "B2", "B1", "H", "L"))
+    tw = crs.table_window
+    digits = -(-378 // tw) if tw else 24
+    out["roofline"] = roofline_obj("zkhip::k_accumulate<5>", terms, digits, acc_ms, None)
+    out["roofline"]["terms"] = "the finite bases of the five query vectors of this key (a base at infinity produces no entry)"
+    out["one_proof_alone_ms"] = {"witness_host": round(wit_ms, 3), **{k: round(v, 3) for k, v in phases.items()}}
+    same = bool((one == proof).all())
+    if cpu:
+        from oracle import oracle as O
+        O.load()
+        threads = host_threads()
+        O.set_threads(threads)
+        threads = O.max_threads()
+        A, B, C = agg.get_constraint_system()
+        t, ct = time.time(), os.times()
+        z_cpu = agg.witness(nvk_l, npr, nin)                      # the host witness generator is the product's (rows a2-a5 are host code)
+        h = O.qap_h(A, B, C, z_cpu, agg.num_constraints, l)
+        cpu_proof = O.groth16_prove(pk, z_cpu, l, h, rr, ss, chunks=threads)
+        cpu_dt = time.time() - t
+        ct2 = os.times()
+        out["cpu_baseline"] = {"value": round(1.0 / cpu_dt, 4), "unit": "proofs/s", "cores": threads, "kind": "port",
+                               "sample": "ONE wrapping proof of the identical batch by the C restatement (r1cs_to_qap_witness_map + r1cs_gg_ppzksnark_prover: "
+                                         "7 FFTs, 5 BDLO12 multi_exps in %d OpenMP chunks) after the product's host witness generator, %.2f s wall, "
+                                         "%.1f cores busy" % (threads, cpu_dt, ((ct2.user + ct2.system) - (ct.user + ct.system)) / cpu_dt),
+                               "parity_with_gpu_on_sample": bool((cpu_proof == one).all())}
+    out["pipeline_proof_equals_serial_proof"] = same
+    crs.free(); kp.free(); agg.free(); r1.free()
     return out
 
 
 def tw_batched(extra, args):
     return bool(extra.get("table_window")) and not args.no_batch_msms
-
-
-def zkhip_fr_one():
-    r = 0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001
-    m = (1 << 384) % r
-    return [(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]
 
 
 if __name__ == "__main__":

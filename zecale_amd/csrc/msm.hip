@@ -1063,7 +1063,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
                        jb.table_stride, (uint32_t)(k * B), ctx->offsets, ctx->cursor, ctx->entries);
   }
   const int bshift = merged ? c - 1 : 31;     // bucket -> job
-  HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
+  if (ctx->aff_levels > 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));     // the timed accumulation includes the affine levels
   // ---- batched-affine levels: the sorted list is summed pairwise inside every bucket, ctx->aff_levels times
   const uint32_t *cur_off = ctx->offsets, *cur_cnt = ctx->counts;
   size_t m_cur = (size_t)Wd * (n_eff ? n_eff : 1);       // entries that can occur: a base at infinity never produces one
@@ -1116,6 +1116,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     S_run = (uint32_t)S; T_run = (uint32_t)((m + S - 1) / S);
   }
   HIP_TRY(hipMemsetAsync(ctx->buckets, 0, (size_t)ctx->slot_stride * 108 * 4, st));
+  if (ctx->aff_levels == 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
   const uint32_t* acc_entries = dense ? nullptr : ctx->entries;
   if (ctx->K == 1 || dense)
     hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off, cur_cnt,

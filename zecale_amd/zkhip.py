@@ -608,6 +608,23 @@ class Keypair:
         crs.handle = h
         return crs
 
+    def consts(self):
+        """alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2 of the proving key (24 limbs each): what zkhip_groth16_finish takes."""
+        d = CrsDesc()
+        _check(load().zkhip_keypair_crs_desc(self.handle, ctypes.byref(d)))
+        return {k: np.ctypeslib.as_array(ctypes.cast(getattr(d, k), c_u64p_t), (24,)).copy()
+                for k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2")}
+
+    def pk_arrays(self):
+        """Host copies of the proving half (dict in the layout Crs / the test oracle take) plus n_vars, n_primary, domain_size."""
+        d = CrsDesc()
+        _check(load().zkhip_keypair_crs_desc(self.handle, ctypes.byref(d)))
+        m, l, dom = d.n_vars, d.n_primary, d.domain_size
+        arr = lambda ptr, n: (np.ctypeslib.as_array(ctypes.cast(ptr, c_u64p_t), (n, 24)).copy() if n else np.zeros((0, 24), dtype=np.uint64))
+        pk = {k: arr(getattr(d, k), 1).reshape(24) for k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2")}
+        pk.update(A=arr(d.a_query, m), B2=arr(d.b_g2_query, m), B1=arr(d.b_g1_query, m), H=arr(d.h_query, dom - 1), L=arr(d.l_query, m - l - 1))
+        return pk, m, l, dom
+
     def vk(self):
         a, b, dl = (np.zeros(24, dtype=np.uint64) for _ in range(3))
         abc = c_u64p_t()
