@@ -12,7 +12,6 @@
 #include <array>
 #include <cstdio>
 #include <memory>
-#include <random>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -86,6 +85,18 @@ class keypair {                            // wsnarkT::keypair: pk (HBM-resident
   const zkhip_crs* pk() const { return crs_; }
   // vk: alpha (G1), beta, delta (G2), ABC; `vk_abc_size() == num_primary_inputs() + 1` is the server's sanity check (aggregator_server.cpp:490)
   size_t vk_abc_size() const { uint64_t a[24], b[24], d[24]; const uint64_t* abc; return zkhip_keypair_vk(kp_, a, b, d, &abc); }
+  // wsnarkT::verification_key_write_json (aggregator_server.cpp:185,223): the shape of testdata/dummy_app/aggregator_vk.json
+  std::string verification_key_to_json() const {
+    uint64_t a[24], b[24], d[24];
+    const uint64_t* abc;
+    const size_t n = zkhip_keypair_vk(kp_, a, b, d, &abc);
+    auto pt = [](const uint64_t* p) { return "[\"" + extended_proof::hex_be(0, p) + "\", \"" + extended_proof::hex_be(0, p + 12) + "\"]"; };
+    std::ostringstream o;
+    o << "{\"alpha\": " << pt(a) << ", \"beta\": " << pt(b) << ", \"delta\": " << pt(d) << ", \"ABC\": [";
+    for (size_t i = 0; i < n; i++) o << (i ? ", " : "") << pt(abc + i * 24);
+    o << "]}";
+    return o.str();
+  }
   bool verify(const extended_proof& ep) const {      // wsnarkT::verify(inputs, proof, vk)
     uint64_t a[24], b[24], d[24];
     const uint64_t* abc;
@@ -118,11 +129,10 @@ class aggregator_circuit {
   size_t num_primary_inputs() const { return zkhip_aggregator_num_primary_inputs(agg_); }
   const zkhip_r1cs_desc& get_constraint_system() const { return cs_; }
 
-  // needs a device (the batch exponentiations run on the GPU); fresh toxic waste from the OS, discarded on return
+  // needs a device (the batch exponentiations run on the GPU); fresh toxic waste, uniform in Fr, from the OS, discarded on return
   std::unique_ptr<keypair> generate_trusted_setup() const {
-    std::random_device rd;
     uint64_t t[4][6];
-    for (auto& s : t) { for (auto& l : s) l = ((uint64_t)rd() << 32) | rd(); s[5] &= (1ull << 56) - 1; }   // < 2^376 < r: valid residues
+    for (auto& s : t) zk_check(zkhip_fr_random(s), "zkhip_fr_random");
     zkhip_keypair* kp = nullptr;
     zk_check(zkhip_groth16_setup(&cs_, t[0], t[1], t[2], t[3], &kp), "zkhip_groth16_setup");
     return std::unique_ptr<keypair>(new keypair(kp));
@@ -174,6 +184,9 @@ class aggregator_circuit {
                        const std::array<const nested_extended_proof*, NumProofs>& nested_proofs, const keypair& kp) {
     std::vector<uint64_t> vk, proofs, inputs, z(cs_.n_vars * 6);
     flatten(nested_vk, nested_proofs, vk, proofs, inputs);
+    int well_formed = 0;                   // libsnark: proof.is_well_formed(); in the circuit: the proof variables' curve checks
+    zk_check(zkhip_aggregator_check_inputs(agg_, vk.data(), proofs.data(), &well_formed), "zkhip_aggregator_check_inputs");
+    if (!well_formed) throw std::runtime_error("nested proof or verification key has a point that is not on its curve");
     zk_check(zkhip_aggregator_witness(agg_, vk.data(), proofs.data(), inputs.data(), z.data()), "zkhip_aggregator_witness");
     if (!r1cs_) zk_check(zkhip_r1cs_upload(&cs_, &r1cs_), "zkhip_r1cs_upload");
     uint64_t r[6], s[6];
@@ -197,7 +210,7 @@ class aggregator_circuit {
     for (size_t i = 0; i < NumProofs; i++) {
       const auto& in = nested_proofs[i]->get_primary_inputs();
       if (in.size() != inputs_per_nested_proof_)
-        throw std::runtime_error("unexpected number of inputs in nested proof " + std::to_string(i));   // tcc:138-141
+        throw std::runtime_error("attempt to aggregate proof with invalid number of inputs");            // tcc:138-141, same text
       const nested_proof& p = nested_proofs[i]->get_proof();
       proofs.insert(proofs.end(), p.a.begin(), p.a.end());
       proofs.insert(proofs.end(), p.b.begin(), p.b.end());
@@ -207,10 +220,9 @@ class aggregator_circuit {
     if (nested_vk.abc_g1.size() != inputs_per_nested_proof_ + 1) throw std::runtime_error("nested verification key has the wrong size");
     vk = nested_vk.flat();
   }
-  static void random_scalars(uint64_t r[6], uint64_t s[6]) {      // < 2^376 < r: valid residues
-    std::random_device rd;
-    for (int i = 0; i < 6; i++) { r[i] = ((uint64_t)rd() << 32) | rd(); s[i] = ((uint64_t)rd() << 32) | rd(); }
-    r[5] &= (1ull << 56) - 1; s[5] &= (1ull << 56) - 1;
+  static void random_scalars(uint64_t r[6], uint64_t s[6]) {      // uniform in Fr (libff::Fr::random_element())
+    zk_check(zkhip_fr_random(r), "zkhip_fr_random");
+    zk_check(zkhip_fr_random(s), "zkhip_fr_random");
   }
   size_t inputs_per_nested_proof_;
   zkhip_aggregator* agg_ = nullptr;

@@ -48,6 +48,7 @@ int zkhip_init(int device);
 /* library device of the calling thread for the entry points that take no handle (the device must be initialised) */
 int zkhip_set_device(int device);
 int zkhip_get_device(void);              /* -1 before the first zkhip_init */
+int zkhip_device_count(void);            /* GPUs visible to the process (0 without a HIP runtime) */
 void zkhip_shutdown(void);
 const char* zkhip_strerror(int code);
 const char* zkhip_last_error(void);
@@ -272,6 +273,11 @@ void zkhip_keypair_free(zkhip_keypair* kp);
 
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
+
+/* replaces: libff::Fr<wppT>::random_element() as r1cs_gg_ppzksnark_prover draws the proof's randomisers r, s (reached from
+ * aggregator_circuit.tcc:168) and the generator its toxic waste: one field element uniform in Fr, 6 Montgomery limbs, from the
+ * operating system's entropy source.  Host code. */
+int zkhip_fr_random(uint64_t out[6]);
 
 /* Montgomery limbs -> canonical integer limbs (little-endian), for the JSON / EVM encodings of the reference
  * (SURVEY App. A.2, A.3): which = 0 for Fq (12 limbs), 1 for Fr (6 limbs).  Host code. */

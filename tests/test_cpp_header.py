@@ -73,5 +73,5 @@ def test_aggregator_circuit_mirror_compiles_and_runs_host_part(tmp_path):
                            "-L", os.path.join(ROOT, "zecale_amd"), "-lzkhip", "-Wl,-rpath," + os.path.join(ROOT, "zecale_amd")])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "primary=4" in out.stdout and "caught: unexpected number of inputs in nested proof 0" in out.stdout
+    assert "primary=4" in out.stdout and "caught: attempt to aggregate proof with invalid number of inputs" in out.stdout
     assert '{"proof": {"a": ["0x' in out.stdout

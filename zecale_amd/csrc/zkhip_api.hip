@@ -980,6 +980,30 @@ void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 
 float zkhip_last_accumulate_ms(void) { return cur_dev() >= 0 ? g.dev[cur_dev()].ps.last_accumulate_ms : 0.f; }
 
+int zkhip_device_count(void) {
+  int count = 0;
+  return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
+// uniform in [0, r): 377-bit draws from the OS, rejected when >= r (a value in [0, r) read as a Montgomery residue is a uniform
+// field element either way)
+int zkhip_fr_random(uint64_t out[6]) {
+  if (!out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  FILE* f = fopen("/dev/urandom", "rb");
+  if (!f) return fail(ZKHIP_ERR_STATE, "cannot open /dev/urandom");
+  for (;;) {
+    if (fread(out, 8, 6, f) != 6) { fclose(f); return fail(ZKHIP_ERR_STATE, "short read from /dev/urandom"); }
+    out[5] &= ((uint64_t)1 << 57) - 1;               // r has 377 bits
+    bool less = false;
+    for (int i = 5; i >= 0; i--) {
+      if (out[i] != FrParams::P64[i]) { less = out[i] < FrParams::P64[i]; break; }
+    }
+    if (less) break;
+  }
+  fclose(f);
+  return ZKHIP_OK;
+}
+
 int zkhip_to_canonical(int which, const uint64_t* in, uint64_t* out) {
   using namespace host;
   if (!in || !out) return ZKHIP_ERR_ARG;

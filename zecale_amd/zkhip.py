@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkhip.so")
 
 EXPORTS = [
-    "zkhip_init", "zkhip_set_device", "zkhip_get_device", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window", "zkhip_set_affine_levels",
+    "zkhip_init", "zkhip_set_device", "zkhip_get_device", "zkhip_device_count", "zkhip_fr_random", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window", "zkhip_set_affine_levels",
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
     "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window", "zkhip_set_batch_msms",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_msm_submit", "zkhip_msm_collect",
@@ -144,6 +144,17 @@ def set_device(device):
 
 def get_device():
     return load().zkhip_get_device()
+
+
+def device_count():
+    return load().zkhip_device_count()
+
+
+def fr_random():
+    """One uniform element of Fr (6 Montgomery limbs) from the OS entropy source."""
+    out = np.zeros(6, dtype=np.uint64)
+    _check(load().zkhip_fr_random(_p(out)))
+    return out
 
 
 def set_msm_window(c):
