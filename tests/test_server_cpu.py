@@ -1,0 +1,151 @@
+"""The gRPC surface (zecale_amd/server.py) replaying the reference's end-to-end client script against a live server on the
+loopback interface, with a stubbed prover (no GPU here): scripts/test-client:41-96 - register the dummy application, a second
+registration fails, four nested transactions go in (fees 12, 11, 10, 9), two batches come out in fee order with their parameters,
+a third request fails.  Handler semantics: aggregator_server/aggregator_server.cpp:130-348; pool: application_pool.tcc:49-63."""
+import json
+
+import grpc
+import numpy as np
+import pytest
+
+from oracle import pyref as R
+from tests.helpers import golden
+from zecale_amd import encoding as E
+from zecale_amd import server as S
+
+
+class StubProver:
+    """Returns the reference's own wrapping proof fixture with the batch's nested inputs patched in: enough to check the
+    service's plumbing (ordering, parameters, encodings) without a device."""
+    snark_name = "GROTH16"
+
+    def __init__(self):
+        self.calls = []
+        self.vk_json = golden("dummy_app/aggregator_vk.json")
+
+    def verification_key_json(self):
+        return self.vk_json
+
+    def nested_vk_hash(self, limbs):
+        from zecale_amd import zkhip
+        return zkhip.aggregator_vk_hash(limbs, 1)          # host code: no device needed
+
+    def prove(self, nested_vk_limbs, proofs, inputs):
+        self.calls.append((nested_vk_limbs, proofs, inputs))
+        ep = json.loads(json.dumps(golden("dummy_app/batch1.json")["ext_proof"]))
+        ep["inputs"] = ep["inputs"][:2] + [E.fr_to_json(x.reshape(6)) for x in inputs]
+        return ep
+
+
+@pytest.fixture()
+def live():
+    prover = StubProver()
+    server, port, service = S.serve(prover, "127.0.0.1:0", max_workers=4)
+    yield S.AggregatorClient("127.0.0.1:%d" % port), prover, service
+    server.stop(0)
+
+
+def _details(excinfo):
+    return excinfo.value.code(), excinfo.value.details()
+
+
+def test_descriptors_match_the_reference_proto():
+    """Service, method and message names and the zecale field numbers as in proto/zecale/api/aggregator.proto:9-79."""
+    svc = S.POOL.FindServiceByName("zecale_proto.Aggregator")
+    assert [m.name for m in svc.methods] == ["GetConfiguration", "GetVerificationKey", "GetNestedVerificationKeyHash", "RegisterApplication",
+                                             "SubmitNestedTransaction", "GenerateAggregatedTransaction"]
+    assert svc.methods_by_name["GenerateAggregatedTransaction"].input_type.full_name == "zecale_proto.AggregatedTransactionRequest"
+    assert svc.methods_by_name["RegisterApplication"].output_type.full_name == "zecale_proto.VerificationKeyHash"
+    nt = S.POOL.FindMessageTypeByName("zecale_proto.NestedTransaction")
+    assert {f.name: f.number for f in nt.fields} == {"application_name": 1, "extended_proof": 2, "parameters": 3, "fee_in_wei": 4}
+    at = S.POOL.FindMessageTypeByName("zecale_proto.AggregatedTransaction")
+    assert {f.name: f.number for f in at.fields} == {"application_name": 1, "extended_proof": 2, "nested_parameters": 3}
+    assert at.fields_by_name["nested_parameters"].is_repeated
+    cfg = S.POOL.FindMessageTypeByName("zecale_proto.AggregatorConfiguration")
+    assert [f.name for f in cfg.fields] == ["nested_snark_name", "wrapper_snark_name", "nested_pairing_parameters", "wrapper_pairing_parameters"]
+
+
+def test_configuration_and_keys(live):
+    client, prover, _ = live
+    cfg = client.get_configuration()
+    assert cfg["nested_snark_name"] == cfg["wrapper_snark_name"] == "GROTH16"
+    assert cfg["wrapper_pairing_parameters"]["name"] == "bw6-761" and int(cfg["wrapper_pairing_parameters"]["r"], 16) == R.R_MOD
+    assert int(cfg["wrapper_pairing_parameters"]["q"], 16) == R.Q_MOD and int(cfg["nested_pairing_parameters"]["q"], 16) == R.BLS_Q
+    assert int(cfg["nested_pairing_parameters"]["r"], 16) == R.BLS_R
+    g1 = tuple(int(c, 16) for c in cfg["wrapper_pairing_parameters"]["generator_g1"])
+    g2 = tuple(int(c, 16) for c in cfg["wrapper_pairing_parameters"]["generator_g2"])
+    assert g1 == R.G1_GEN and g2 == R.G2_GEN
+    n1 = tuple(int(c, 16) for c in cfg["nested_pairing_parameters"]["generator_g1"])
+    assert (n1[1] ** 2 - n1[0] ** 3 - 1) % R.BLS_Q == 0 and R.ec_mul(R.BLS_R, n1, R.BLS_Q) is None
+    (x1, x0), (y1, y0) = cfg["nested_pairing_parameters"]["generator_g2"]            # c1 first, as in the fixtures
+    assert ((int(x0, 16), int(x1, 16)), (int(y0, 16), int(y1, 16))) == R.BLS_G2_GEN
+    assert client.get_verification_key() == prover.vk_json
+
+
+def test_client_script_flow(live):
+    client, prover, service = live
+    app_vk = golden("dummy_app/vk.json")
+    h = client.get_nested_verification_key_hash(app_vk)
+    assert int(h, 16) == int(E.fr_to_json(prover.nested_vk_hash(E.nested_verification_key_from_json(app_vk))), 16)
+    assert client.register_application(app_vk, "dummy_app") == h
+    with pytest.raises(grpc.RpcError) as e:                        # scripts/test-client:53-55: re-registration fails
+        client.register_application(app_vk, "dummy_app")
+    assert _details(e) == (grpc.StatusCode.INVALID_ARGUMENT, "application already registered")
+    with pytest.raises(grpc.RpcError) as e:
+        client.get_aggregated_transaction("dummy_app")
+    assert _details(e) == (grpc.StatusCode.INVALID_ARGUMENT, "insufficient entries in pool")
+    txs = [golden("dummy_app/extproof%d.json" % k) for k in (3, 1, 4, 2)]      # submitted out of fee order
+    for tx in txs:
+        client.submit_nested_transaction(tx)
+    assert service.pools["dummy_app"].tx_pool_size() == 4
+    by_fee = sorted(txs, key=lambda t: -t["fee_in_wei"])
+    for b in range(2):
+        batch = client.get_aggregated_transaction("dummy_app")
+        assert batch["app_name"] == "dummy_app"
+        want = by_fee[2 * b:2 * b + 2]                                # fees 12, 11 then 10, 9 (nested_transaction.tcc:78-83)
+        norm = lambda h_: h_[2:] if h_.startswith("0x") else h_
+        assert batch["nested_parameters"] == [norm(t["parameters"]).rjust(len(norm(t["parameters"])) + len(norm(t["parameters"])) % 2, "0") for t in want]
+        assert [int(x, 16) for x in batch["ext_proof"]["inputs"][2:]] == [int(t["extended_proof"]["inputs"][0], 16) for t in want]
+        vk_limbs, proofs, inputs = prover.calls[b]
+        assert (vk_limbs == E.nested_verification_key_from_json(app_vk)).all()
+        for got, t in zip(proofs, want):
+            assert (got == E.nested_extended_proof_from_json(t["extended_proof"])[0]).all()
+        # the response decodes with the aggregated-transaction codec of the client side
+        name, proof, inp, params = E.aggregated_transaction_from_json(batch)
+        assert name == "dummy_app" and proof.shape == (72,) and len(params) == 2
+    with pytest.raises(grpc.RpcError) as e:                        # scripts/test-client:94-96: no third batch
+        client.get_aggregated_transaction("dummy_app")
+    assert _details(e) == (grpc.StatusCode.INVALID_ARGUMENT, "insufficient entries in pool")
+
+
+def test_error_paths(live):
+    client, _, _ = live
+    tx = golden("dummy_app/extproof1.json")
+    with pytest.raises(grpc.RpcError) as e:                        # unknown application: std::map::at throws (aggregator_server.cpp:248)
+        client.submit_nested_transaction(tx)
+    assert e.value.code() == grpc.StatusCode.INVALID_ARGUMENT
+    client.register_application(golden("dummy_app/vk.json"), "dummy_app")
+    bad = json.loads(json.dumps(tx))
+    bad["extended_proof"]["inputs"] = bad["extended_proof"]["inputs"] * 2
+    with pytest.raises(grpc.RpcError) as e:
+        client.submit_nested_transaction(bad)
+    assert _details(e) == (grpc.StatusCode.INVALID_ARGUMENT, "invalid number of inputs")
+    short_vk = json.loads(json.dumps(golden("dummy_app/vk.json")))
+    short_vk["ABC"] = short_vk["ABC"][:1]
+    with pytest.raises(grpc.RpcError) as e:
+        client.register_application(short_vk, "other")
+    assert e.value.code() == grpc.StatusCode.INVALID_ARGUMENT
+    one = json.loads(json.dumps(tx))
+    client.submit_nested_transaction(one)                          # a single queued transaction is not a batch
+    with pytest.raises(grpc.RpcError) as e:
+        client.get_aggregated_transaction("dummy_app")
+    assert e.value.details() == "insufficient entries in pool"
+
+
+def test_pool_orders_by_fee_and_only_returns_whole_batches():
+    pool = S.ApplicationPool("app", golden("dummy_app/vk.json"))
+    assert pool.get_next_batch() == []
+    for fee in (3, 9, 1):
+        pool.add_tx({"fee_in_wei": fee})
+    assert [t["fee_in_wei"] for t in pool.get_next_batch()] == [9, 3]
+    assert pool.tx_pool_size() == 1 and pool.get_next_batch() == []
