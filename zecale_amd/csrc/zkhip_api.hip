@@ -592,11 +592,17 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   struct { const zkhip_bases* b; const uint64_t* sc; size_t len; int mode; uint64_t* out; } jobs[5] = {
       {crs->A, dz + a_lo * 6, a_len, 1, sums}, {crs->B2, dz + a_lo * 6, a_len, 1, sums + 36}, {crs->B1, dz + a_lo * 6, a_len, 1, sums + 72},
       {crs->H, (const uint64_t*)rd->bufA + h_lo * 6, h_len, 2, sums + 108}, {crs->L, dz + (l + 1 + l_lo) * 6, l_len, 1, sums + 144}};
-  if (tc > 0 && maxlen <= ((size_t)1 << 20) && g.batch_msms) {
+  bool batched = tc > 0 && g.batch_msms;
+  if (batched) {
     // table-backed key: the five MSMs share ONE launch sequence (one sort, one accumulation launch over all five entry
     // lists, one reduction chain with a bucket window per MSM) - a fifth of the launches, five times the lanes in each.
+    // (A plan that does not fit the engine's 32-bit entry positions is refused with ZKHIP_ERR_ARG: one sequence per MSM then.)
+    rc = ensure_ctx(&ps.ctx[4], &ps.ready[4], maxlen, tc, 5);
+    if (rc == ZKHIP_ERR_ARG) batched = false;
+    else if (rc != ZKHIP_OK) return rc;
+  }
+  if (batched) {
     MsmCtx* cx = &ps.ctx[4];
-    if ((rc = ensure_ctx(cx, &ps.ready[4], maxlen, tc, 5)) != ZKHIP_OK) return rc;
     MsmJob mj[5];
     for (int j = 0; j < 5; j++)
       mj[j] = MsmJob{jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].b->len,
