@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one MSM / one proof in flight (per-phase timings) instead of the streaming forms")
     ap.add_argument("--gpu-slots", type=int, default=6, help="aggregator pipeline: proofs in flight on the GPU")
     ap.add_argument("--witness-workers", type=int, default=8, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
+    ap.add_argument("--gpu-witness", action="store_true", help="aggregator pipeline: the witness workers generate the assignment on the GPU")
     ap.add_argument("--cpu-sample-log", type=int, default=20)
     ap.add_argument("--no-secondary", action="store_true", help="msm workload: skip the measurements that follow the timed region")
     args = ap.parse_args()
@@ -303,8 +304,9 @@ def main():
             # the streaming prover (zkhip_aggregator_pipeline_*): every step submits one batch (witness generation +
             # proof, nothing cached) and collects the oldest outstanding one; drain() inside the timed region collects
             # the rest, so exactly `steps` wrapping proofs are produced between the two barriers.
-            pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers)
-            tickets, depth = [], args.gpu_slots + args.witness_workers + 2
+            pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers, gpu_witness=args.gpu_witness)
+            # (GPU witness: launches of 16 witnesses take ~60 ms each, so the stream is kept several launches deep)
+            tickets, depth = [], (96 if args.gpu_witness else args.gpu_slots + args.witness_workers + 2)
             for t_ in [pipe.submit(nvk_l, npr, nin, rr, ss) for _ in range(2 * args.gpu_slots)]:   # set-up: every slot allocates its work space
                 pipe.wait(t_)
 
@@ -368,6 +370,16 @@ def main():
     dt = time.time() - t0
     cpu1 = os.times()
     extra["host_cores_busy"] = round(((cpu1.user + cpu1.system) - (cpu0.user + cpu0.system)) / dt, 2)   # this rank's process, timed region
+    if os.environ.get("ZKHIP_BENCH_THREADS"):        # where the host time goes: CPU seconds per thread name (whole process life)
+        acc = {}
+        for t in os.listdir("/proc/self/task"):
+            try:
+                name = open("/proc/self/task/%s/comm" % t).read().strip()
+                f = open("/proc/self/task/%s/stat" % t).read().rsplit(")", 1)[1].split()
+                acc[name] = acc.get(name, 0.0) + (int(f[11]) + int(f[12])) / os.sysconf("SC_CLK_TCK")
+            except Exception:
+                pass
+        extra["thread_cpu_s"] = {k: round(v, 2) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:8]}
     if world > 1 or force_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -392,7 +404,7 @@ def main():
                 extra["phase_ms"] = {k: round(float(np.mean([p[k] for p in phase])), 3) for k in phase[0]}
                 extra["phase_ms"]["witness_host"] = round(float(np.mean(wit_ms)), 3)
             else:
-                extra["pipeline"] = {"gpu_slots": args.gpu_slots, "witness_workers": args.witness_workers,
+                extra["pipeline"] = {"gpu_slots": args.gpu_slots, "witness_workers": args.witness_workers, "witness_on_gpu": bool(args.gpu_witness),
                                      "note": "proofs in flight overlap; --serial gives the per-phase timings of one proof"}
         else:
             value, unit = units_per_step * args.steps / dt, "proofs/s"

@@ -153,6 +153,7 @@ typedef struct zkhip_crs zkhip_crs;
 int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out);
 void zkhip_crs_free(zkhip_crs* c);
 int zkhip_crs_table_window(const zkhip_crs* c);          /* window of the key's tables, 0: none */
+int zkhip_crs_device(const zkhip_crs* c);                /* the GPU that holds the key */
 
 /* replaces: wsnarkT::generate_proof(pk, pb) = libsnark::r1cs_gg_ppzksnark_prover (called at
  * libzecale/circuits/aggregator_circuit.tcc:168), with the randomisers (r, s) injected so that
@@ -186,6 +187,8 @@ int zkhip_last_prove_timings(double out_ms[8]);
 typedef struct zkhip_prover zkhip_prover;
 int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prover** out);   /* crs must outlive the prover */
 int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r[6], const uint64_t s[6], uint64_t proof_affine[72]);
+/* the same with the assignment already in device memory (n_vars x 6 limbs, e.g. from zkhip_gpu_witness_run; must be complete) */
+int zkhip_prover_prove_dev(zkhip_prover* p, const void* d_z, const uint64_t r[6], const uint64_t s[6], uint64_t proof_affine[72]);
 int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]);   /* as zkhip_last_prove_timings, for p's last proof */
 float zkhip_prover_last_accumulate_ms(zkhip_prover* p);          /* as zkhip_last_accumulate_ms, for p's last proof */
 void zkhip_prover_free(zkhip_prover* p);
@@ -236,6 +239,32 @@ int zkhip_aggregator_check_inputs(const zkhip_aggregator* a, const uint64_t* nes
 /* replaces: verification_key_hash_gadget::compute_hash(vk, num_inputs) (verification_key_hash_gadget.tcc:42-59) */
 int zkhip_aggregator_vk_hash(const uint64_t* nested_vk, size_t inputs_per_proof, uint64_t out[6]);
 
+/* Witness generation ON THE GPU: the same assignment as zkhip_aggregator_witness, limb for limb, computed by a device kernel that
+ * interprets the straight-line program recorded from the circuit (witness_tape.cpp, witness.hip).  One batch occupies four waves for
+ * ~tens of milliseconds: the gain is not latency (the host generator takes 8 ms on three cores) but host cores - a server keeps
+ * many batches in flight and the GPU generates their witnesses under the provers' kernels.
+ *   zkhip_aggregator_witness_gpu   one batch, host in / host out (allocates its work space: a test / convenience entry point)
+ *   zkhip_gpu_witness_*            work space for one batch in flight on the calling thread's device; run() leaves the assignment
+ *                                  in DEVICE memory (d_z_out: n_vars x 6 limbs, ready for zkhip_prover_prove_dev) and returns the
+ *                                  primary inputs.  ZKHIP_ERR_ARG when an inversion met zero (degenerate nested points, where the
+ *                                  host generator branches): fall back to zkhip_aggregator_witness for that batch.
+ * replaces: the generate_r1cs_witness calls of aggregator_circuit::prove (aggregator_circuit.tcc:136-157, aggregator_gadget.tcc:87-112) */
+int zkhip_aggregator_witness_gpu(zkhip_aggregator* a, const uint64_t* nested_vk, const uint64_t* nested_proofs, const uint64_t* nested_inputs,
+                                 uint64_t* z_out);
+typedef struct zkhip_gpu_witness zkhip_gpu_witness;
+int zkhip_gpu_witness_new(zkhip_aggregator* a, zkhip_gpu_witness** out);
+int zkhip_gpu_witness_run(zkhip_gpu_witness* w, const uint64_t* nested_vk, const uint64_t* nested_proofs, const uint64_t* nested_inputs,
+                          void* d_z_out, uint64_t* primary_inputs);
+ /* several batches in ONE launch sequence (a workgroup each: n witnesses take as long as one).  d_z_out: n x n_vars x 6 limbs,
+ * contiguous; primary_inputs: n x n_primary x 6 limbs; degenerate[i] != 0: batch i met an inversion of zero, its assignment is void */
+int zkhip_gpu_witness_new_batched(zkhip_aggregator* a, size_t max_batches, zkhip_gpu_witness** out);
+int zkhip_gpu_witness_run_batched(zkhip_gpu_witness* w, size_t n, const uint64_t* const* nested_vk, const uint64_t* const* nested_proofs,
+                                  const uint64_t* const* nested_inputs, void* d_z_out, uint64_t* primary_inputs, int* degenerate);
+void zkhip_gpu_witness_free(zkhip_gpu_witness* w);
+/* the recorded program: [0] operations recorded, [1] positions after levelling (with padding), [2] dependent levels,
+ * [3] multiplications, [4] inversions, [5] distinct constants */
+int zkhip_gpu_witness_stats(zkhip_aggregator* a, size_t out[6]);
+
 /* Streaming form of aggregator_circuit::prove for a server that wraps batch after batch (the reference's
  * GenerateAggregatedTransaction loop, aggregator_server.cpp:300-420, handles one batch at a time on the CPU):
  * `witness_workers` host threads generate witnesses (zkhip_aggregator_witness) while `gpu_slots` prover instances
@@ -246,6 +275,11 @@ int zkhip_aggregator_vk_hash(const uint64_t* nested_vk, size_t inputs_per_proof,
  * Every result is bit-identical to zkhip_aggregator_witness + zkhip_groth16_prove on the same inputs, r and s. */
 typedef struct zkhip_pipeline zkhip_pipeline;
 int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, zkhip_pipeline** out);
+/* flags: ZKHIP_PIPELINE_GPU_WITNESS - the witness workers generate the assignment on the GPU (zkhip_gpu_witness_run: each worker is
+ * a host thread that waits on its batch's kernel; the assignment never leaves the device) and fall back to the host generator for a
+ * degenerate batch.  Results are the same proofs. */
+#define ZKHIP_PIPELINE_GPU_WITNESS 1u
+int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, unsigned flags, zkhip_pipeline** out);
 int zkhip_aggregator_pipeline_submit(zkhip_pipeline* p, const uint64_t* nested_vk, const uint64_t* nested_proofs,
                                      const uint64_t* nested_inputs, const uint64_t r[6], const uint64_t s[6], uint64_t* ticket);
 int zkhip_aggregator_pipeline_wait(zkhip_pipeline* p, uint64_t ticket, uint64_t* primary_inputs, uint64_t proof_affine[72]);

@@ -11,7 +11,7 @@
 #include "tower.hpp"
 
 namespace zkhip {
-namespace circuit {
+namespace ZK_CIRCUIT_NS {
 
 static const uint64_t BLS_U = 0x8508c00000000001ull;
 
@@ -217,5 +217,5 @@ template <class F> inline F groth16_verify_bit(const NestedVk<F>& vk, const Nest
   return fq12_is_one(final_exponentiation(f));
 }
 
-}  // namespace circuit
+}  // namespace ZK_CIRCUIT_NS
 }  // namespace zkhip

@@ -23,10 +23,31 @@
 
 #include "../host_field.hpp"
 
-namespace zkhip {
-namespace circuit {
+// The circuit headers compile a second time, in another namespace and over another scalar type, for the GPU witness
+// generator (witness_tape.cpp): there HFr is a RECORDING type whose operators append to a tape instead of (only) computing,
+// so the very same code that defines the constraints and the host witness also defines the straight-line program the
+// device interprets.  Everything value-dependent below is therefore written through four hooks the recording type overloads:
+//   inv()  a field inversion that must not see zero        fr_inv0()  an inversion that maps 0 to 0 by design
+//   fr_bit()  a bit of the canonical integer               batch_inv()  independent inversions
+#ifndef ZK_CIRCUIT_NS
+#define ZK_CIRCUIT_NS circuit
+#endif
 
+namespace zkhip {
+namespace ZK_CIRCUIT_NS {
+
+#ifdef ZK_CIRCUIT_FR
+using HFr = ZK_CIRCUIT_FR;
+#else
 using host::HFr;
+// bit t of the canonical integer, as a field element
+inline HFr fr_bit(const HFr& v, int t) {
+  uint64_t c[6];
+  v.to_canonical(c);
+  return ((c[t / 64] >> (t % 64)) & 1) ? HFr::one() : HFr::zero();
+}
+inline HFr fr_inv0(const HFr& v) { return v.is_zero() ? HFr::zero() : v.inv(); }
+#endif
 
 struct Term {
   uint32_t var;
@@ -74,6 +95,7 @@ struct NF {
   static NF constant(const HFr& c) { return NF(c); }
   static NF witness(const HFr& value) { return NF(value); }
   static NF witness_bit(bool b) { return NF(b ? HFr::one() : HFr::zero()); }
+  static NF witness_bitv(const HFr& bit) { return NF(bit); }
   const HFr& value() const { return v; }
   NF operator+(const NF& o) const { return NF(v + o.v); }
   NF operator-(const NF& o) const { return NF(v - o.v); }
@@ -111,6 +133,12 @@ struct CV {
   }
   static CV witness_bit(bool b) {
     CV r = witness(b ? HFr::one() : HFr::zero());
+    CV m = r - constant(HFr::one());
+    current_builder()->enforce(r.lc, m.lc, LC());      // b (b - 1) = 0
+    return r;
+  }
+  static CV witness_bitv(const HFr& bit) {               // the bit as a field element (fr_bit)
+    CV r = witness(bit);
     CV m = r - constant(HFr::one());
     current_builder()->enforce(r.lc, m.lc, LC());      // b (b - 1) = 0
     return r;
@@ -166,6 +194,7 @@ struct WV {
   static WV constant(const HFr& c) { WV r; r.val = c; return r; }
   static WV witness(const HFr& value) { WV r; r.val = value; r.cst = false; current_builder()->alloc(value); return r; }
   static WV witness_bit(bool b) { return witness(b ? HFr::one() : HFr::zero()); }
+  static WV witness_bitv(const HFr& bit) { return witness(bit); }
   const HFr& value() const { return val; }
   bool is_const() const { return cst; }
   WV operator+(const WV& o) const { WV r; r.val = val + o.val; r.cst = cst && o.cst; return r; }
@@ -191,6 +220,9 @@ inline bool f_is_const(const NF&) { return false; }
 inline bool f_is_const(const CV& x) { return x.is_const(); }
 // Witness generation is a chain of field inversions (the slopes of the in-circuit point additions); the ones that do not depend on
 // each other are inverted together: n inverses for one inversion and 3(n-1) multiplications (Montgomery's trick).  Zeros stay zero.
+#ifdef ZK_CIRCUIT_FR
+inline void batch_inv(HFr* v, int n) { for (int i = 0; i < n; i++) v[i] = v[i].inv(); }     // recorded as independent inversions
+#else
 inline void batch_inv(HFr* v, int n) {
   HFr pre[8];
   HFr acc = HFr::one();
@@ -203,9 +235,10 @@ inline void batch_inv(HFr* v, int n) {
     v[i] = vi;
   }
 }
+#endif
 // binv: the inverse of b's value if the caller already has it (batch_inv), else null
 template <class F> inline F f_div(const F& a, const F& b, const HFr* binv = nullptr) {
-  HFr bi = binv ? *binv : (b.value().is_zero() ? HFr::zero() : b.value().inv());
+  HFr bi = binv ? *binv : fr_inv0(b.value());
   if (f_is_const(a) && f_is_const(b)) return F::constant(a.value() * bi);
   F q = F::witness(a.value() * bi);
   F::assert_product(q, b, a);
@@ -213,7 +246,7 @@ template <class F> inline F f_div(const F& a, const F& b, const HFr* binv = null
 }
 // [x == 0] as a field element (1 or 0): m = 1/x (or 0), z = 1 - x m, enforce x z = 0      (2 constraints)
 template <class F> inline F f_is_zero(const F& x) {
-  HFr m = x.value().is_zero() ? HFr::zero() : x.value().inv();
+  HFr m = fr_inv0(x.value());
   F mw = F::witness(m);
   F z = f_one<F>() - x * mw;
   F::assert_product(x, z, f_zero<F>());
@@ -239,5 +272,5 @@ template <class F> inline F f_select(const F& sel, const F& a, const F& b) {
   return out;
 }
 
-}  // namespace circuit
+}  // namespace ZK_CIRCUIT_NS
 }  // namespace zkhip

@@ -12,7 +12,7 @@
 #include "dsl.hpp"
 
 namespace zkhip {
-namespace circuit {
+namespace ZK_CIRCUIT_NS {
 
 // ---- SHA-256 (constants only) ----------------------------------------------------------------------
 inline void sha256(const uint8_t* msg, size_t len, uint8_t out[32]) {
@@ -92,5 +92,5 @@ template <class F> inline F mimc_hash(const std::vector<F>& in) {
   return mimc_mp(F::constant(HFr::from_u64((uint64_t)in.size())), h);
 }
 
-}  // namespace circuit
+}  // namespace ZK_CIRCUIT_NS
 }  // namespace zkhip

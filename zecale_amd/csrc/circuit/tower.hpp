@@ -10,7 +10,7 @@
 #include "dsl.hpp"
 
 namespace zkhip {
-namespace circuit {
+namespace ZK_CIRCUIT_NS {
 
 template <class F>
 struct Fq2 {
@@ -52,9 +52,7 @@ inline V2 v2_inv(const V2& x, const HFr* ninv = nullptr) {
   HFr ni;
   if (ninv) ni = *ninv;
   else {
-    HFr n = v2_norm(x);
-    if (n.is_zero()) return V2{HFr::zero(), HFr::zero()};
-    ni = n.inv();
+    ni = fr_inv0(v2_norm(x));                 // (0 -> 0: the structure pass runs on zeros)
   }
   return V2{x.a * ni, (x.b * ni).neg()};
 }
@@ -364,5 +362,5 @@ template <class F> inline Fq12<F> fq12_inverse(const Fq12<F>& a) {
   return w;
 }
 
-}  // namespace circuit
+}  // namespace ZK_CIRCUIT_NS
 }  // namespace zkhip

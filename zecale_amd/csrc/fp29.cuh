@@ -204,6 +204,38 @@ ZK_HD ZK_INL Fp<PR> fp_cond_sub_p(const Fp<PR>& a) {
   return r;
 }
 
+// canonical limbs of K * p
+template <class PR, int K>
+struct KTimesP {
+  uint32_t l[PR::NL];
+  constexpr KTimesP() : l{} {
+    uint64_t c = 0;
+    for (int i = 0; i < PR::NL; i++) {
+      c += (uint64_t)PR::P[i] * K;
+      l[i] = (i + 1 < PR::NL) ? (uint32_t)(c & M29) : (uint32_t)c;
+      c >>= 29;
+    }
+  }
+};
+
+// a in [0, 2 K p) -> [0, K p)
+template <class PR, int K>
+ZK_HD ZK_INL Fp<PR> fp_cond_sub_kp(const Fp<PR>& a) {
+  constexpr int N = PR::NL;
+  constexpr KTimesP<PR, K> kp{};
+  Fp<PR> d;
+  int32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    int32_t t = (int32_t)a.l[i] - (int32_t)kp.l[i] + borrow;
+    d.l[i] = (i + 1 < N) ? ((uint32_t)t & M29) : (uint32_t)t;
+    borrow = (i + 1 < N) ? (t >> 29) : (t >> 31);
+  }
+  Fp<PR> r;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
+  return r;
+}
 // full reduction of a lazily bounded value (< 2^10 p) to the canonical representative
 template <class PR>
 ZK_HD ZK_INL Fp<PR> fp_canon(const Fp<PR>& a) {

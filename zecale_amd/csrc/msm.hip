@@ -25,6 +25,7 @@
 #include "ec_affine.cuh"
 #include "host_field.hpp"
 #include "msm.h"
+#include "wait.h"
 
 #ifndef ZK_ACC_REGY
 #define ZK_ACC_REGY 1
@@ -1257,7 +1258,7 @@ int msm_finish_multi(MsmCtx* ctx, int K, uint64_t* out_jac) {
   if (!ctx->pending || !ctx->merged || K < 1 || K > ctx->K) return ZKHIP_ERR_STATE;
   ctx->pending = false;
   if (ctx->pending_n) {
-    HIP_TRY(hipEventSynchronize(ctx->ev_done));
+    HIP_TRY(zk_event_wait(ctx->ev_done));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
     ctx->last_accumulate_ms = ms;
@@ -1281,7 +1282,7 @@ int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]) {
     inf.X.to_limbs(out_jac); inf.Y.to_limbs(out_jac + 12); inf.Z.to_limbs(out_jac + 24);
     return ZKHIP_OK;
   }
-  HIP_TRY(hipEventSynchronize(ctx->ev_done));
+  HIP_TRY(zk_event_wait(ctx->ev_done));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
   ctx->last_accumulate_ms = ms;

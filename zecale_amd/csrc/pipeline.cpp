@@ -17,6 +17,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <pthread.h>
 #include <string.h>
 
 #include "../../include/zkhip.h"
@@ -25,6 +26,8 @@ namespace {
 struct Job {
   uint64_t id = 0;
   std::vector<uint64_t> vk, proofs, inputs, z;
+  void* d_z = nullptr;            // GPU witness: the assignment in device memory (z then holds the primary inputs only)
+  int slab = -1;                  // ... inside this slab of the pipeline
   uint64_t r[6], s[6], proof[72];
   int rc = ZKHIP_OK;
   bool done = false;
@@ -43,11 +46,27 @@ struct zkhip_pipeline {
   size_t max_unfinished = 0, unfinished = 0;     // back-pressure counts batches not yet proved (finished ones wait for their collector)
   uint64_t next_id = 1;
   bool stop = false;
+  // witness generation on the GPU (ZKHIP_PIPELINE_GPU_WITNESS): device buffers for the assignments in flight
+  bool gpu_witness = false;
+  int device = 0;
+  size_t wit_batch = 16;                          // batches per witness launch (one workgroup each: 16 take as long as one)
+  struct Slab { void* base = nullptr; int outstanding = 0; };
+  std::vector<Slab> slabs;                        // wit_batch assignments each
+  std::vector<int> slab_free;
+  std::condition_variable cv_buf;
 };
 
 namespace {
 
+void finish_failed(zkhip_pipeline* p, const std::shared_ptr<Job>& j, int rc) {       // p->mu held
+  j->rc = rc; j->done = true;
+  p->unfinished--;
+  p->cv_done.notify_all();
+  p->cv_room.notify_one();
+}
+
 void witness_loop(zkhip_pipeline* p) {
+  pthread_setname_np(pthread_self(), "zk-witness");
   for (;;) {
     std::shared_ptr<Job> j;
     {
@@ -57,25 +76,83 @@ void witness_loop(zkhip_pipeline* p) {
       j = p->q_wit.front();
       p->q_wit.pop_front();
     }
-    j->z.resize(p->n_vars * 6);
     int wf = 0;
     int rc = zkhip_aggregator_check_inputs(p->agg, j->vk.data(), j->proofs.data(), &wf);      // off-curve points: no proof exists
     if (rc == ZKHIP_OK && !wf) rc = ZKHIP_ERR_ARG;
-    if (rc == ZKHIP_OK) rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
+    if (rc == ZKHIP_OK) {
+      j->z.resize(p->n_vars * 6);
+      rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
+    }
     std::lock_guard<std::mutex> lk(p->mu);
-    if (rc != ZKHIP_OK) {
-      j->rc = rc; j->done = true;
-      p->unfinished--;
-      p->cv_done.notify_all();
-      p->cv_room.notify_one();
-    } else {
+    if (rc != ZKHIP_OK) finish_failed(p, j, rc);
+    else {
       p->q_gpu.push_back(j);
       p->cv_gpu.notify_one();
     }
   }
 }
 
+// ZKHIP_PIPELINE_GPU_WITNESS: a batcher thread takes up to wit_batch queued batches, generates their assignments with ONE launch
+// sequence of the witness kernel (a workgroup per batch) into a slab of device buffers and hands them to the provers; the
+// assignments never leave the device.  A degenerate batch (the device met an inversion of zero) goes through the host generator.
+void gpu_witness_loop(zkhip_pipeline* p) {
+  pthread_setname_np(pthread_self(), "zk-gpu-witness");
+  zkhip_gpu_witness* gw = nullptr;
+  if (zkhip_set_device(p->device) != ZKHIP_OK || zkhip_gpu_witness_new_batched(p->agg, p->wit_batch, &gw) != ZKHIP_OK) { witness_loop(p); return; }
+  std::vector<std::shared_ptr<Job>> jobs, good;
+  std::vector<const uint64_t*> vks, prs, ins;
+  std::vector<uint64_t> prim(p->wit_batch * p->n_primary * 6);
+  std::vector<int> deg(p->wit_batch);
+  for (;;) {
+    jobs.clear(); good.clear();
+    int slab = -1;
+    {
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv_wit.wait(lk, [&] { return p->stop || !p->q_wit.empty(); });
+      if (p->stop) break;
+      p->cv_buf.wait(lk, [&] { return p->stop || !p->slab_free.empty(); });
+      if (p->stop) break;
+      while (!p->q_wit.empty() && jobs.size() < p->wit_batch) { jobs.push_back(p->q_wit.front()); p->q_wit.pop_front(); }
+      if (jobs.empty()) continue;                     // another batcher took them while this one waited for a slab
+      slab = p->slab_free.back(); p->slab_free.pop_back();
+    }
+    for (auto& j : jobs) {
+      int wf = 0;
+      int rc = zkhip_aggregator_check_inputs(p->agg, j->vk.data(), j->proofs.data(), &wf);
+      if (rc == ZKHIP_OK && !wf) rc = ZKHIP_ERR_ARG;
+      if (rc == ZKHIP_OK) good.push_back(j);
+      else { std::lock_guard<std::mutex> lk(p->mu); finish_failed(p, j, rc); }
+    }
+    int rc = ZKHIP_OK;
+    if (!good.empty()) {
+      vks.clear(); prs.clear(); ins.clear();
+      for (auto& j : good) { vks.push_back(j->vk.data()); prs.push_back(j->proofs.data()); ins.push_back(j->inputs.data()); }
+      rc = zkhip_gpu_witness_run_batched(gw, good.size(), vks.data(), prs.data(), ins.data(), p->slabs[slab].base, prim.data(), deg.data());
+    }
+    int on_device = 0;
+    for (size_t i = 0; i < good.size(); i++) {
+      auto& j = good[i];
+      if (rc == ZKHIP_OK && !deg[i]) {
+        j->z.assign(prim.begin() + i * p->n_primary * 6, prim.begin() + (i + 1) * p->n_primary * 6);
+        j->d_z = (char*)p->slabs[slab].base + i * p->n_vars * 48;
+        j->slab = slab;
+        on_device++;
+      } else {                                        // host generator for this one
+        j->z.resize(p->n_vars * 6);
+        int hrc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
+        if (hrc != ZKHIP_OK) { std::lock_guard<std::mutex> lk(p->mu); finish_failed(p, j, hrc); j.reset(); }
+      }
+    }
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->slabs[slab].outstanding = on_device;
+    if (on_device == 0) { p->slab_free.push_back(slab); p->cv_buf.notify_one(); }
+    for (auto& j : good) if (j) { p->q_gpu.push_back(j); p->cv_gpu.notify_one(); }
+  }
+  zkhip_gpu_witness_free(gw);
+}
+
 void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
+  pthread_setname_np(pthread_self(), "zk-prover");
   for (;;) {
     std::shared_ptr<Job> j;
     {
@@ -85,11 +162,16 @@ void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
       j = p->q_gpu.front();
       p->q_gpu.pop_front();
     }
-    int rc = zkhip_prover_prove(pr, j->z.data(), j->r, j->s, j->proof);
+    int rc = j->d_z ? zkhip_prover_prove_dev(pr, j->d_z, j->r, j->s, j->proof) : zkhip_prover_prove(pr, j->z.data(), j->r, j->s, j->proof);
     std::lock_guard<std::mutex> lk(p->mu);
     j->rc = rc; j->done = true;
-    std::vector<uint64_t> prim(j->z.begin() + 6, j->z.begin() + 6 + p->n_primary * 6);   // keep the primary inputs, drop the 2.4 MB witness
-    j->z.swap(prim);
+    if (j->d_z) {
+      j->d_z = nullptr;
+      if (--p->slabs[j->slab].outstanding == 0) { p->slab_free.push_back(j->slab); p->cv_buf.notify_all(); }
+    } else {
+      std::vector<uint64_t> prim(j->z.begin() + 6, j->z.begin() + 6 + p->n_primary * 6);   // keep the primary inputs, drop the 2.4 MB witness
+      j->z.swap(prim);
+    }
     p->unfinished--;
     p->cv_done.notify_all();
     p->cv_room.notify_one();
@@ -101,6 +183,10 @@ void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
 extern "C" {
 
 int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, zkhip_pipeline** out) {
+  return zkhip_aggregator_pipeline_new_ex(a, crs, gpu_slots, witness_workers, 0, out);
+}
+
+int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, unsigned flags, zkhip_pipeline** out) {
   if (!a || !crs || !out || gpu_slots < 1 || gpu_slots > 8 || witness_workers < 1 || witness_workers > 64) return ZKHIP_ERR_ARG;
   zkhip_r1cs_desc desc;
   int rc = zkhip_aggregator_get_r1cs(a, &desc);
@@ -111,17 +197,37 @@ int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int
   const size_t np = zkhip_aggregator_num_proofs(a), k = zkhip_aggregator_inputs_per_proof(a);
   p->vk_words = 60 + 12 * (k + 1); p->proofs_words = 48 * np; p->inputs_words = 6 * k * np;
   p->max_unfinished = (size_t)4 * (size_t)(gpu_slots + witness_workers);
+  p->gpu_witness = (flags & ZKHIP_PIPELINE_GPU_WITNESS) != 0;
+  p->device = zkhip_crs_device(crs);
+  if (p->gpu_witness) {
+    if (witness_workers > 4) witness_workers = 4;     // batcher threads: each keeps one launch of wit_batch witnesses in flight
+    if (zkhip_set_device(p->device) != ZKHIP_OK) { delete p; return ZKHIP_ERR_STATE; }
+    const size_t n_slabs = (size_t)witness_workers + (size_t)gpu_slots / 2 + 2;
+    for (size_t i = 0; i < n_slabs; i++) {
+      void* b = nullptr;
+      if (zkhip_device_alloc(p->wit_batch * p->n_vars * 48, &b) != ZKHIP_OK) {
+        for (auto& q : p->slabs) zkhip_device_free(q.base);
+        delete p;
+        return ZKHIP_ERR_HIP;
+      }
+      zkhip_pipeline::Slab sl; sl.base = b;
+      p->slabs.push_back(sl);
+      p->slab_free.push_back((int)i);
+    }
+    p->max_unfinished = p->wit_batch * n_slabs + (size_t)4 * gpu_slots;      // deep enough to fill the witness launches
+  }
   for (int i = 0; i < gpu_slots; i++) {
     zkhip_prover* pr = nullptr;
     rc = zkhip_prover_new(crs, &desc, &pr);
     if (rc != ZKHIP_OK) {
       for (zkhip_prover* q : p->provers) zkhip_prover_free(q);
+      for (auto& q : p->slabs) zkhip_device_free(q.base);
       delete p;
       return rc;
     }
     p->provers.push_back(pr);
   }
-  for (int i = 0; i < witness_workers; i++) p->threads.emplace_back(witness_loop, p);
+  for (int i = 0; i < witness_workers; i++) p->threads.emplace_back(p->gpu_witness ? gpu_witness_loop : witness_loop, p);
   for (zkhip_prover* pr : p->provers) p->threads.emplace_back(gpu_loop, p, pr);
   *out = p;
   return ZKHIP_OK;
@@ -133,9 +239,10 @@ void zkhip_aggregator_pipeline_free(zkhip_pipeline* p) {
     std::lock_guard<std::mutex> lk(p->mu);
     p->stop = true;
   }
-  p->cv_wit.notify_all(); p->cv_gpu.notify_all(); p->cv_done.notify_all(); p->cv_room.notify_all();
+  p->cv_wit.notify_all(); p->cv_gpu.notify_all(); p->cv_done.notify_all(); p->cv_room.notify_all(); p->cv_buf.notify_all();
   for (auto& t : p->threads) t.join();
   for (zkhip_prover* q : p->provers) zkhip_prover_free(q);
+  for (auto& q : p->slabs) zkhip_device_free(q.base);
   delete p;
 }
 

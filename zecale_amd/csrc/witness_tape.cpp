@@ -1,0 +1,219 @@
+// The wrapping circuit's witness generator as a straight-line program ("tape") for the GPU (witness.hip).
+//
+// The reference computes the assignment by walking its gadgets (aggregator_gadget::generate_r1cs_witness,
+// libzecale/circuits/aggregator_gadget.tcc:87-112, called from aggregator_circuit::prove, aggregator_circuit.tcc:144-157).  Here
+// the circuit is ONE body of template code (circuit/*.hpp) and this translation unit compiles it a second time over a
+// RECORDING scalar: every field operation on a value that depends on the inputs appends an instruction to a tape instead of
+// computing; operations on constants are folded.  The tape is then
+//   pruned      instructions no assignment entry depends on are dropped,
+//   levelled    an instruction's level is one more than its operands' - all instructions of a level are independent,
+//   laid out    level by level, inversions first, each level padded to whole 64-lane chunks; an instruction's position is also
+//               the slot its result is stored in, so a level's stores are contiguous.
+// The device interprets it with one workgroup per batch (witness.hip); the host generator (aggregator.cpp) stays the reference
+// for parity: tests compare the two assignments limb for limb.
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "host_field.hpp"
+#include "witness_tape.h"
+
+namespace zkhip {
+namespace rec {
+
+using HV = host::HFr;
+
+struct Recorder {
+  struct Op { uint8_t code; int32_t a, b; };
+  std::vector<Op> ops;                           // instruction i defines value i
+  std::vector<HV> consts;
+  std::map<std::string, int32_t> const_index;
+  const uint64_t *arena_lo = nullptr, *arena_hi = nullptr;
+  int32_t intern(const HV& c) {
+    std::string k((const char*)c.v, sizeof c.v);
+    auto it = const_index.find(k);
+    if (it != const_index.end()) return it->second;
+    int32_t idx = (int32_t)consts.size();
+    consts.push_back(c);
+    const_index[k] = idx;
+    return idx;
+  }
+};
+static thread_local Recorder* g_rec = nullptr;
+
+// The recording scalar.  id < 0: a constant (its value in `val`); id >= 0: the value defined by instruction id.
+struct RecFr {
+  HV val;
+  int32_t id = -1;
+  RecFr() : val(HV::zero()) {}
+  explicit RecFr(const HV& c) : val(c) {}
+  bool is_const() const { return id < 0; }
+  int32_t ref() const { return id >= 0 ? id : -1 - g_rec->intern(val); }
+  static RecFr emit(uint8_t code, int32_t a, int32_t b) {
+    if (g_rec->ops.size() >= (size_t)0x7fffff00) throw std::runtime_error("witness tape too long");
+    g_rec->ops.push_back({code, a, b});
+    RecFr r;
+    r.id = (int32_t)g_rec->ops.size() - 1;
+    return r;
+  }
+  static RecFr zero() { return RecFr(HV::zero()); }
+  static RecFr one() { return RecFr(HV::one()); }
+  static RecFr from_u64(uint64_t x) { return RecFr(HV::from_u64(x)); }
+  static RecFr from_limbs(const uint64_t* p) {
+    if (g_rec && p >= g_rec->arena_lo && p < g_rec->arena_hi) return emit(WT_INPUT, (int32_t)((p - g_rec->arena_lo) / 6), 0);
+    return RecFr(HV::from_limbs(p));
+  }
+  void to_limbs(uint64_t* p) const { need_const("to_limbs"); val.to_limbs(p); }
+  void to_canonical(uint64_t* p) const { need_const("to_canonical"); val.to_canonical(p); }
+  void need_const(const char* what) const { if (!is_const()) throw std::runtime_error(std::string("recording build: ") + what + " of a variable"); }
+  // value-dependent predicates: decided for constants, "generic" (non-zero, distinct) for variables - the recorded program must not
+  // depend on the data (the device flags an inversion of zero where the host generator would have branched)
+  bool is_zero() const { return is_const() && val.is_zero(); }
+  bool operator==(const RecFr& o) const { return (is_const() && o.is_const()) ? val == o.val : id == o.id; }
+  bool operator!=(const RecFr& o) const { return !(*this == o); }
+  RecFr operator+(const RecFr& o) const {
+    if (is_const() && o.is_const()) return RecFr(val + o.val);
+    if (is_const() && val.is_zero()) return o;
+    if (o.is_const() && o.val.is_zero()) return *this;
+    return emit(WT_ADD, ref(), o.ref());
+  }
+  RecFr operator-(const RecFr& o) const {
+    if (is_const() && o.is_const()) return RecFr(val - o.val);
+    if (o.is_const() && o.val.is_zero()) return *this;
+    return emit(WT_SUB, ref(), o.ref());
+  }
+  RecFr operator*(const RecFr& o) const {
+    if (is_const() && o.is_const()) return RecFr(val * o.val);
+    if ((is_const() && val.is_zero()) || (o.is_const() && o.val.is_zero())) return zero();
+    if (is_const() && val == HV::one()) return o;
+    if (o.is_const() && o.val == HV::one()) return *this;
+    return emit(WT_MUL, ref(), o.ref());
+  }
+  RecFr neg() const { return zero() - *this; }
+  RecFr dbl() const { return *this + *this; }
+  RecFr sqr() const { return *this * *this; }
+  RecFr inv() const { return is_const() ? RecFr(val.inv()) : emit(WT_INV, ref(), 0); }
+  RecFr pow_limbs(const uint64_t* e, int nlimbs) const {
+    RecFr acc = one();
+    for (int i = nlimbs * 64 - 1; i >= 0; i--) {
+      acc = acc.sqr();
+      if ((e[i / 64] >> (i % 64)) & 1) acc = acc * (*this);
+    }
+    return acc;
+  }
+};
+inline RecFr fr_bit(const RecFr& v, int t) {
+  if (v.is_const()) { uint64_t c[6]; v.val.to_canonical(c); return ((c[t / 64] >> (t % 64)) & 1) ? RecFr::one() : RecFr::zero(); }
+  return RecFr::emit(WT_BIT, v.ref(), t);
+}
+inline RecFr fr_inv0(const RecFr& v) { return v.is_const() ? RecFr(v.val.is_zero() ? HV::zero() : v.val.inv()) : RecFr::emit(WT_INV0, v.ref(), 0); }
+
+}  // namespace rec
+}  // namespace zkhip
+
+#define ZK_CIRCUIT_NS circuit_rec
+#define ZK_CIRCUIT_FR ::zkhip::rec::RecFr
+#include "circuit/sections.hpp"
+
+namespace zkhip {
+
+int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* out, std::string* err) {
+  using namespace circuit_rec;
+  using rec::Recorder;
+  using rec::RecFr;
+  try {
+    const size_t k = inputs_per_proof;
+    const size_t vk_w = 60 + 12 * (k + 1), pr_w = 48 * num_proofs, in_w = 6 * k * num_proofs;
+    std::vector<uint64_t> arena(vk_w + pr_w + in_w, 0);
+    Recorder R;
+    R.arena_lo = arena.data(); R.arena_hi = arena.data() + arena.size();
+    rec::g_rec = &R;
+    NestedData d{arena.data(), arena.data() + vk_w, arena.data() + vk_w + pr_w};
+    Builder b;
+    b.record = false;
+    synthesize<WV>(b, num_proofs, k, &d);
+    rec::g_rec = &R;                                  // (synthesize leaves the builder pointer cleared, not the recorder)
+    const size_t n_vars = b.z.size(), n_ops = R.ops.size();
+    // assignment entry -> reference
+    std::vector<int32_t> out_ref(n_vars);
+    for (size_t i = 0; i < n_vars; i++) out_ref[i] = b.z[i].ref();
+    rec::g_rec = nullptr;
+    // prune: keep what the assignment depends on
+    std::vector<uint8_t> live(n_ops, 0);
+    for (int32_t r : out_ref) if (r >= 0) live[r] = 1;
+    for (size_t i = n_ops; i-- > 0;) {
+      if (!live[i]) continue;
+      const auto& op = R.ops[i];
+      if (op.code == WT_INPUT) continue;
+      if (op.a >= 0) live[op.a] = 1;
+      if ((op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) && op.b >= 0) live[op.b] = 1;
+    }
+    // levels
+    std::vector<int32_t> level(n_ops, 0);
+    int32_t max_level = 0;
+    for (size_t i = 0; i < n_ops; i++) {
+      if (!live[i]) continue;
+      const auto& op = R.ops[i];
+      int32_t l = 0;
+      if (op.code != WT_INPUT) {
+        if (op.a >= 0) l = std::max(l, level[op.a] + 1);
+        if ((op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) && op.b >= 0) l = std::max(l, level[op.b] + 1);
+      }
+      level[i] = l;
+      max_level = std::max(max_level, l);
+    }
+    // layout: by level, inside a level by kind (inversions first, then multiplications, then the cheap ones)
+    auto kind_rank = [](uint8_t c) { return (c == WT_INV || c == WT_INV0) ? 0 : c == WT_MUL ? 1 : c == WT_INPUT ? 2 : c == WT_BIT ? 3 : 4; };
+    std::vector<uint32_t> order;
+    order.reserve(n_ops);
+    for (size_t i = 0; i < n_ops; i++) if (live[i]) order.push_back((uint32_t)i);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+      if (level[x] != level[y]) return level[x] < level[y];
+      return kind_rank(R.ops[x].code) < kind_rank(R.ops[y].code);
+    });
+    std::vector<int32_t> pos_of(n_ops, -1);
+    WitnessTape& T = *out;
+    T = WitnessTape();
+    T.level_start.push_back(0);
+    int32_t cur = 0;
+    for (uint32_t i : order) {
+      if (level[i] != cur) {
+        while (T.code.size() % 64) { T.code.push_back(WT_NOP); T.a.push_back(0); T.b.push_back(0); }
+        for (; cur < level[i]; cur++) T.level_start.push_back((uint32_t)T.code.size());
+      }
+      pos_of[i] = (int32_t)T.code.size();
+      T.code.push_back(R.ops[i].code); T.a.push_back(R.ops[i].a); T.b.push_back(R.ops[i].b);
+    }
+    while (T.code.size() % 64) { T.code.push_back(WT_NOP); T.a.push_back(0); T.b.push_back(0); }
+    T.level_start.push_back((uint32_t)T.code.size());
+    // operands: instruction ids -> positions
+    for (size_t p = 0; p < T.code.size(); p++) {
+      const uint8_t c = T.code[p];
+      if (c == WT_NOP || c == WT_INPUT) continue;
+      if (T.a[p] >= 0) T.a[p] = pos_of[T.a[p]];
+      if ((c == WT_ADD || c == WT_SUB || c == WT_MUL) && T.b[p] >= 0) T.b[p] = pos_of[T.b[p]];
+    }
+    T.out_ref.resize(n_vars);
+    for (size_t i = 0; i < n_vars; i++) T.out_ref[i] = out_ref[i] >= 0 ? pos_of[out_ref[i]] : out_ref[i];
+    T.consts.resize(R.consts.size() * 6);
+    for (size_t i = 0; i < R.consts.size(); i++) R.consts[i].to_limbs(&T.consts[i * 6]);
+    T.n_vars = n_vars; T.n_inputs = arena.size() / 6;
+    T.vk_words = vk_w; T.proofs_words = pr_w; T.inputs_words = in_w;
+    T.n_recorded = n_ops;
+    size_t n_mul = 0, n_inv = 0;
+    for (uint8_t c : T.code) { n_mul += c == WT_MUL; n_inv += (c == WT_INV || c == WT_INV0); }
+    T.n_mul = n_mul; T.n_inv = n_inv;
+    return 0;
+  } catch (const std::exception& e) {
+    rec::g_rec = nullptr;
+    if (err) *err = e.what();
+    return -1;
+  }
+}
+
+}  // namespace zkhip

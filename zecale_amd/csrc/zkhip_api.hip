@@ -7,9 +7,11 @@
 #include "ec.cuh"
 #include "host_field.hpp"
 #include "msm.h"
+#include "wait.h"
 #include "ntt.h"
 #include "qap.h"
 #include "pairing_host.hpp"
+#include "witness.h"
 #include <chrono>
 #include <future>
 #include <vector>
@@ -538,6 +540,7 @@ int zkhip_crs_upload_slice(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, s
 }
 
 int zkhip_crs_table_window(const zkhip_crs* c) { return (c && c->A) ? c->A->table_c : 0; }
+int zkhip_crs_device(const zkhip_crs* c) { return c ? c->device : -1; }
 
 void zkhip_crs_free(zkhip_crs* c) {
   if (!c) return;
@@ -556,8 +559,9 @@ int zkhip_last_prove_timings(double out_ms[8]) {
 // GPUs of a node; each rank computes partial sums, the ranks exchange 5 x 288 bytes).  Slice = [a_lo, a_lo + a_len) of
 // the A / B queries (indices into z), [h_lo, h_lo + h_len) of the H query (indices into h), [l_lo, l_lo + l_len) of the
 // L query (indices into z[n_primary+1 ..]).  The whole key is the slice (0, n_vars), (0, d - 1), (0, n_vars - l - 1).
+// z: host assignment (uploaded here) - or d_z_ready: the assignment already in device memory, ABI form, complete (GPU witness)
 static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
-                         uint64_t sums[5 * 36]) {
+                         uint64_t sums[5 * 36], const uint64_t* d_z_ready = nullptr) {
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
   const size_t m = rd->n_vars, l = rd->n_primary, d = (size_t)1 << rd->log_d;
@@ -576,16 +580,18 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     API_HIP(hipMalloc(&ps.dz, m * 48));
     ps.dz_cap = m;
   }
-  uint64_t* dz = ps.dz;
-  API_HIP(hipMemcpyAsync(dz, z, m * 48, hipMemcpyHostToDevice, ps.st));
-  API_HIP(hipEventRecord(ps.ev_st, ps.st));
-  API_HIP(hipEventSynchronize(ps.ev_st));
+  const uint64_t* dz = d_z_ready ? d_z_ready : ps.dz;
+  if (!d_z_ready) {
+    API_HIP(hipMemcpyAsync(ps.dz, z, m * 48, hipMemcpyHostToDevice, ps.st));
+    API_HIP(hipEventRecord(ps.ev_st, ps.st));
+    API_HIP(zk_event_wait(ps.ev_st));
+  }
   ps.ms[0] = ms_since(t0);
   t0 = clk::now();
   int rc = qap_h_dev(rd, dz, ps.st, t_err, sizeof t_err);
   if (rc != ZKHIP_OK) return rc;
   API_HIP(hipEventRecord(ps.ev_st, ps.st));
-  API_HIP(hipEventSynchronize(ps.ev_st));   // the MSM contexts run on their own streams
+  API_HIP(zk_event_wait(ps.ev_st));   // the MSM contexts run on their own streams
   ps.ms[1] = ms_since(t0);
   size_t maxlen = a_len > h_len ? a_len : h_len;
   if (maxlen < 1) maxlen = 1;
@@ -746,12 +752,21 @@ void zkhip_prover_free(zkhip_prover* p) {
   delete p;
 }
 
+static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t* d_z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]);
 int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]) {
-  if (!p || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (!z) return fail(ZKHIP_ERR_ARG, "null pointer");
+  return prover_prove_impl(p, z, nullptr, r_m, s_m, proof_affine);
+}
+int zkhip_prover_prove_dev(zkhip_prover* p, const void* d_z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]) {
+  if (!d_z) return fail(ZKHIP_ERR_ARG, "null pointer");
+  return prover_prove_impl(p, nullptr, (const uint64_t*)d_z, r_m, s_m, proof_affine);
+}
+static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t* d_z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]) {
+  if (!p || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
   BIND(p);                                    // called from pipeline / application threads that never ran zkhip_init
   std::lock_guard<std::mutex> lk(p->mu);
   uint64_t sums[180];
-  int rc = prove_partial(p->ps, p->crs, p->rd, z, 0, 0, 0, sums);
+  int rc = prove_partial(p->ps, p->crs, p->rd, z, 0, 0, 0, sums, d_z);
   if (rc != ZKHIP_OK) return rc;
   const zkhip_crs* c = p->crs;
   return finish_impl(c->alpha_g1, c->beta_g1, c->beta_g2, c->delta_g1, c->delta_g2, sums, r_m, s_m, proof_affine, &p->ps.ms[7]);
@@ -985,6 +1000,126 @@ int zkhip_keypair_read(const char* path, zkhip_keypair** out) {
 void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 
 float zkhip_last_accumulate_ms(void) { return cur_dev() >= 0 ? g.dev[cur_dev()].ps.last_accumulate_ms : 0.f; }
+
+// ---- witness generation on the GPU (witness.hip) ---------------------------------------------------------------------------
+struct zkhip_gpu_witness {
+  int device;
+  zkhip_aggregator* agg;
+  WitnessProg prog;
+  size_t in_words;
+  size_t max_batches = 1;
+  uint64_t* d_in = nullptr;
+  uint32_t* d_vals = nullptr;
+  uint32_t* d_flag = nullptr;
+  uint64_t* h_in = nullptr;       // pinned staging: inputs, then the flag and the primary inputs on the way back
+  hipStream_t st = nullptr;
+  hipEvent_t ev = nullptr;
+};
+
+int zkhip_gpu_witness_new(zkhip_aggregator* a, zkhip_gpu_witness** out) { return zkhip_gpu_witness_new_batched(a, 1, out); }
+
+int zkhip_gpu_witness_new_batched(zkhip_aggregator* a, size_t max_batches, zkhip_gpu_witness** out) {
+  BIND_CUR();
+  if (!a || !out || max_batches < 1 || max_batches > 256) return fail(ZKHIP_ERR_ARG, "bad argument");
+  zkhip_gpu_witness* w = new zkhip_gpu_witness();
+  w->device = cur_dev(); w->agg = a; w->max_batches = max_batches;
+  const WitnessTape* tape = nullptr;
+  int rc = witness_prog(a, &w->prog, &tape, t_err, sizeof t_err);
+  if (rc != ZKHIP_OK) { delete w; return rc; }
+  w->in_words = (size_t)w->prog.n_inputs * 6;
+  hipError_t e = hipMalloc(&w->d_in, max_batches * w->in_words * 8);
+  if (e == hipSuccess) e = hipMalloc(&w->d_vals, max_batches * (size_t)w->prog.n_pos * 48);
+  if (e == hipSuccess) e = hipMalloc(&w->d_flag, max_batches * 4 + 64);
+  if (e == hipSuccess) e = hipHostMalloc(&w->h_in, max_batches * (w->in_words + 1 + a->n_primary * 6) * 8);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev, hipEventBlockingSync | hipEventDisableTiming);
+  if (e != hipSuccess) {
+    snprintf(t_err, sizeof t_err, "zkhip_gpu_witness_new: %s", hipGetErrorString(e));
+    zkhip_gpu_witness_free(w);
+    return ZKHIP_ERR_HIP;
+  }
+  *out = w;
+  return ZKHIP_OK;
+}
+
+void zkhip_gpu_witness_free(zkhip_gpu_witness* w) {
+  if (!w) return;
+  (void)bind_dev(w->device);
+  if (w->d_in) (void)hipFree(w->d_in);
+  if (w->d_vals) (void)hipFree(w->d_vals);
+  if (w->d_flag) (void)hipFree(w->d_flag);
+  if (w->h_in) (void)hipHostFree(w->h_in);
+  if (w->st) (void)hipStreamDestroy(w->st);
+  if (w->ev) (void)hipEventDestroy(w->ev);
+  delete w;
+}
+
+// n batches in ONE launch sequence (one workgroup each).  vk / proofs / inputs: n pointers; d_z_out: n x n_vars x 6 limbs in device
+// memory, contiguous; primary_inputs: n x n_primary x 6 limbs (host, may be null); degenerate[i] = 1 where an inversion met zero
+// (that batch's assignment is unusable: use the host generator).
+int zkhip_gpu_witness_run_batched(zkhip_gpu_witness* w, size_t n, const uint64_t* const* nested_vk, const uint64_t* const* nested_proofs,
+                                  const uint64_t* const* nested_inputs, void* d_z_out, uint64_t* primary_inputs, int* degenerate) {
+  if (!w || !nested_vk || !nested_proofs || !nested_inputs || !d_z_out || !degenerate) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (n < 1 || n > w->max_batches) return fail(ZKHIP_ERR_ARG, "more batches than the work space holds");
+  BIND(w);
+  const zkhip_aggregator* a = w->agg;
+  const size_t vk_w = 60 + 12 * (a->inputs_per_proof + 1), pr_w = 48 * a->num_proofs, in_w = 6 * a->inputs_per_proof * a->num_proofs;
+  if (vk_w + pr_w + in_w != w->in_words) return fail(ZKHIP_ERR_STATE, "witness program does not match the circuit");
+  for (size_t i = 0; i < n; i++) {
+    uint64_t* h = w->h_in + i * w->in_words;
+    memcpy(h, nested_vk[i], vk_w * 8); memcpy(h + vk_w, nested_proofs[i], pr_w * 8); memcpy(h + vk_w + pr_w, nested_inputs[i], in_w * 8);
+  }
+  uint64_t* h_flags = w->h_in + w->max_batches * w->in_words;            // [n flags as u32 | primary inputs]
+  uint64_t* h_prim = h_flags + w->max_batches;
+  API_HIP(hipMemcpyAsync(w->d_in, w->h_in, n * w->in_words * 8, hipMemcpyHostToDevice, w->st));
+  API_HIP(hipMemsetAsync(w->d_flag, 0, n * 4, w->st));
+  witness_launch(w->prog, w->d_in, w->d_vals, (uint64_t*)d_z_out, w->d_flag, (uint32_t)n, w->st);
+  API_HIP(hipGetLastError());
+  API_HIP(hipMemcpyAsync(h_flags, w->d_flag, n * 4, hipMemcpyDeviceToHost, w->st));
+  for (size_t i = 0; i < n; i++)
+    API_HIP(hipMemcpyAsync(h_prim + i * a->n_primary * 6, (const uint64_t*)d_z_out + (i * a->n_vars + 1) * 6, a->n_primary * 48, hipMemcpyDeviceToHost, w->st));
+  API_HIP(hipEventRecord(w->ev, w->st));
+  API_HIP(zk_event_wait(w->ev));
+  for (size_t i = 0; i < n; i++) degenerate[i] = ((const uint32_t*)h_flags)[i] != 0;
+  if (primary_inputs) memcpy(primary_inputs, h_prim, n * a->n_primary * 48);
+  return ZKHIP_OK;
+}
+
+int zkhip_gpu_witness_run(zkhip_gpu_witness* w, const uint64_t* nested_vk, const uint64_t* nested_proofs, const uint64_t* nested_inputs,
+                          void* d_z_out, uint64_t* primary_inputs) {
+  int deg = 0;
+  int rc = zkhip_gpu_witness_run_batched(w, 1, &nested_vk, &nested_proofs, &nested_inputs, d_z_out, primary_inputs, &deg);
+  if (rc == ZKHIP_OK && deg)
+    return fail(ZKHIP_ERR_ARG, "GPU witness: an inversion met zero (degenerate input); use the host generator for this batch");
+  return rc;
+}
+
+int zkhip_aggregator_witness_gpu(zkhip_aggregator* a, const uint64_t* nested_vk, const uint64_t* nested_proofs, const uint64_t* nested_inputs,
+                                 uint64_t* z_out) {
+  if (!a || !z_out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  zkhip_gpu_witness* w = nullptr;
+  int rc = zkhip_gpu_witness_new(a, &w);
+  if (rc != ZKHIP_OK) return rc;
+  void* dz = nullptr;
+  hipError_t e = hipMalloc(&dz, a->n_vars * 48);
+  if (e != hipSuccess) { zkhip_gpu_witness_free(w); snprintf(t_err, sizeof t_err, "hipMalloc: %s", hipGetErrorString(e)); return ZKHIP_ERR_HIP; }
+  rc = zkhip_gpu_witness_run(w, nested_vk, nested_proofs, nested_inputs, dz, nullptr);
+  if (rc == ZKHIP_OK && hipMemcpy(z_out, dz, a->n_vars * 48, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ZKHIP_ERR_HIP, "copy of the assignment failed");
+  (void)hipFree(dz);
+  zkhip_gpu_witness_free(w);
+  return rc;
+}
+
+int zkhip_gpu_witness_stats(zkhip_aggregator* a, size_t out[6]) {
+  BIND_CUR();
+  if (!a || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  WitnessProg P;
+  const WitnessTape* T = nullptr;
+  int rc = witness_prog(a, &P, &T, t_err, sizeof t_err);
+  if (rc != ZKHIP_OK) return rc;
+  out[0] = T->n_recorded; out[1] = T->code.size(); out[2] = T->level_start.size() - 1; out[3] = T->n_mul; out[4] = T->n_inv; out[5] = T->consts.size() / 6;
+  return ZKHIP_OK;
+}
 
 int zkhip_device_count(void) {
   int count = 0;

@@ -22,9 +22,10 @@ EXPORTS = [
     "zkhip_crs_upload_slice", "zkhip_groth16_prove_partial", "zkhip_groth16_finish",
     "zkhip_bls12_377_groth16_verify", "zkhip_aggregator_new", "zkhip_aggregator_free", "zkhip_aggregator_num_constraints",
     "zkhip_aggregator_num_variables", "zkhip_aggregator_num_primary_inputs", "zkhip_aggregator_get_r1cs",
-    "zkhip_aggregator_witness", "zkhip_aggregator_check_inputs", "zkhip_aggregator_vk_hash", "zkhip_aggregator_num_proofs", "zkhip_aggregator_inputs_per_proof",
+    "zkhip_aggregator_witness", "zkhip_aggregator_witness_gpu", "zkhip_gpu_witness_new", "zkhip_gpu_witness_new_batched", "zkhip_gpu_witness_run", "zkhip_gpu_witness_run_batched", "zkhip_gpu_witness_free",
+    "zkhip_gpu_witness_stats", "zkhip_prover_prove_dev", "zkhip_aggregator_check_inputs", "zkhip_aggregator_vk_hash", "zkhip_aggregator_num_proofs", "zkhip_aggregator_inputs_per_proof",
     "zkhip_prover_new", "zkhip_prover_prove", "zkhip_prover_timings", "zkhip_prover_free", "zkhip_prover_last_accumulate_ms",
-    "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
+    "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_new_ex", "zkhip_crs_device", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
 ]
@@ -514,6 +515,21 @@ class AggregatorCircuit:
         _check(load().zkhip_aggregator_witness(self.handle, _p(vk), _p(pr), _p(inp), _p(z)))
         return z
 
+    def witness_gpu(self, nested_vk, nested_proofs, nested_inputs):
+        """The same assignment computed on the GPU (zkhip_aggregator_witness_gpu): needs zkhip.init()."""
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+        vk, pr, inp = c(nested_vk), c(nested_proofs), c(nested_inputs)
+        k = self.inputs_per_nested_proof
+        assert vk.size == 60 + 12 * (k + 1) and pr.size == 48 * self.num_proofs and inp.size == 6 * k * self.num_proofs
+        z = np.zeros((self.num_variables, 6), dtype=np.uint64)
+        _check(load().zkhip_aggregator_witness_gpu(self.handle, _p(vk), _p(pr), _p(inp), _p(z)))
+        return z
+
+    def gpu_witness_stats(self):
+        out = (ctypes.c_size_t * 6)()
+        _check(load().zkhip_gpu_witness_stats(self.handle, out))
+        return dict(zip(["recorded", "positions", "levels", "multiplications", "inversions", "constants"], [int(x) for x in out]))
+
     def check_inputs(self, nested_vk, nested_proofs):
         """True iff every point of the nested key and proofs is on its curve (proof.is_well_formed() in the reference's stack)."""
         c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
@@ -561,9 +577,11 @@ class AggregatorPipeline:
     """Streaming aggregator_circuit::prove (zkhip_aggregator_pipeline_*): submit() returns a ticket at once, wait(ticket)
     returns (primary_inputs, proof).  Witness generation, the GPU prover and the host tail of successive batches overlap."""
 
-    def __init__(self, agg, crs, gpu_slots=2, witness_workers=2):
+    def __init__(self, agg, crs, gpu_slots=2, witness_workers=2, gpu_witness=False):
         h = ctypes.c_void_p()
-        _check(load().zkhip_aggregator_pipeline_new(agg.handle, crs.handle, gpu_slots, witness_workers, ctypes.byref(h)))
+        lib = load()
+        lib.zkhip_aggregator_pipeline_new_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]
+        _check(lib.zkhip_aggregator_pipeline_new_ex(agg.handle, crs.handle, gpu_slots, witness_workers, 1 if gpu_witness else 0, ctypes.byref(h)))
         self.handle, self._agg, self._crs = h, agg, crs
         self.n_primary = agg.num_primary_inputs()
 
