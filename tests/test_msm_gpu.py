@@ -15,9 +15,12 @@ pytestmark = pytest.mark.gpu
 def affine_levels(request, zk):
     """Every case runs with the default accumulation (XYZZ mixed additions only) and with one and three batched-affine levels
     forced in front of it (pairwise affine sums inside the buckets, one shared inversion per lane: the same group element)."""
-    big = any(t in request.node.name for t in ("2_22", "full_size", "closed_form"))
-    if big and request.param == 1:
-        pytest.skip("full-size cases: default and three levels")
+    name = request.node.name
+    if request.param != -1:
+        wanted = ("golden", "random_vs_oracle", "witness_like", "heavy_buckets", "order_two", "table_random", "submit_collect")
+        big3 = request.param == 3 and ("full_size_2_20_closed_form" in name or "table_full_size" in name)
+        if not (any(w in name for w in wanted) or big3):
+            pytest.skip("affine-level variants run on the cases that reach the level kernel's branches")
     zk.set_affine_levels(request.param)
     yield request.param
     zk.set_affine_levels(-1)

@@ -6,10 +6,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <sched.h>
+#include <sys/prctl.h>
 #include <time.h>
 
 namespace zkhip {
 inline hipError_t zk_event_wait(hipEvent_t ev) {
+  static thread_local bool slack_set = false;
+  if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 2000UL); slack_set = true; }     // the default slack of 50 us would triple a 20 us sleep
   for (int i = 0;; i++) {
     hipError_t e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
