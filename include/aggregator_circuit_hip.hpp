@@ -143,8 +143,9 @@ class aggregator_circuit {
   // tail of successive batches overlap.  The stream must not outlive the circuit or the keypair.
   class stream {
    public:
-    stream(aggregator_circuit& c, const keypair& kp, int gpu_slots, int witness_workers) : c_(c) {
-      zk_check(zkhip_aggregator_pipeline_new(c.agg_, kp.pk(), gpu_slots, witness_workers, &p_), "zkhip_aggregator_pipeline_new");
+    stream(aggregator_circuit& c, const keypair& kp, int gpu_slots, int witness_workers, bool witness_on_gpu = false) : c_(c) {
+      zk_check(zkhip_aggregator_pipeline_new_ex(c.agg_, kp.pk(), gpu_slots, witness_workers, witness_on_gpu ? ZKHIP_PIPELINE_GPU_WITNESS : 0u, &p_),
+               "zkhip_aggregator_pipeline_new_ex");
     }
     stream(const stream&) = delete;
     stream& operator=(const stream&) = delete;
@@ -175,8 +176,9 @@ class aggregator_circuit {
     aggregator_circuit& c_;
     zkhip_pipeline* p_ = nullptr;
   };
-  std::unique_ptr<stream> open_stream(const keypair& kp, int gpu_slots = 4, int witness_workers = 6) {
-    return std::unique_ptr<stream>(new stream(*this, kp, gpu_slots, witness_workers));
+  // witness_on_gpu: the assignments are generated by a device kernel (zkhip_gpu_witness_*): fewer host cores, a deeper stream
+  std::unique_ptr<stream> open_stream(const keypair& kp, int gpu_slots = 4, int witness_workers = 6, bool witness_on_gpu = false) {
+    return std::unique_ptr<stream>(new stream(*this, kp, gpu_slots, witness_workers, witness_on_gpu));
   }
 
   // Non-const like the reference (it fills its protoboard); not re-entrant.

@@ -60,6 +60,12 @@ int main(int argc, char** argv) {
       extended_proof e = st->wait(t[i]);
       std::printf("STREAM %d VERIFY %d %s\n", i, kp->verify(e) ? 1 : 0, e.to_json().c_str());
     }
+    // the same stream with the witness generated on the GPU
+    auto st2 = agg.open_stream(*kp, 2, 2, true);
+    uint64_t tg = st2->submit(nvk, swapped);
+    extended_proof eg = st2->wait(tg);
+    std::printf("GPUWITNESS VERIFY %d INPUTS_EQUAL %d\n", kp->verify(eg) ? 1 : 0,
+                (int)(eg.primary_inputs[2] == np[1].primary_inputs[0] && eg.primary_inputs[3] == np[0].primary_inputs[0]));
     std::printf("DONE\n");
   } catch (const std::exception& e) {
     std::printf("EXCEPTION %s\n", e.what());

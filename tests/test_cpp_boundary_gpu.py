@@ -45,6 +45,7 @@ def test_cpp_mirror_setup_prove_verify_and_stream(zk, tmp_path):
     assert lines["VERIFY"] == "1" and lines["REPROVE_DIFFERS"] == "1 VERIFY 1" and lines["TAMPERED_VERIFY"] == "0"
     assert lines["THROW"] == "attempt to aggregate proof with invalid number of inputs"     # aggregator_circuit.tcc:138-141
     assert lines["OFFCURVE"].startswith("nested proof or verification key has a point that is not on its curve")
+    assert lines["GPUWITNESS"] == "VERIFY 1 INPUTS_EQUAL 1"
     assert "DONE" in out.stdout
     # the printed JSON is the reference's encoding: decode it here and verify with the host pairing check
     vk = E.verification_key_from_json(json.loads(lines["VK"]))

@@ -105,7 +105,9 @@ void synthesize(Builder& b, size_t num_proofs, size_t k, const NestedData* data)
   current_builder() = &b;
   Inputs<V> in;
   alloc_inputs(in, num_proofs, k, data);
+  if (b.on_section) b.on_section(0);
   V h = section_hash(in);
+  if (b.on_section) b.on_section(1);
   b.z[1] = h.value();
   vk_precompute(in.vk);
   V packed_lc;

@@ -54,77 +54,154 @@ __global__ void __launch_bounds__(256) k_witness_consts(const uint64_t* __restri
   w_store12(out + (size_t)i * 12, fp_cond_sub_p(fp_from_abi<FrParams>(x)));
 }
 
-// levels [l0, l1) of the program; the launch that reaches the last level also writes the assignment.  (A witness is cut into
-// several launches of a few milliseconds so that the kernels of the provers that share a hardware queue with it are not held up
-// for the whole 60 ms.)
-// WIT_TPW lanes per batch, WIT_WPB batches per workgroup.  (Measured: eight batches of 128 lanes in one 1,024-lane workgroup - fewer
-// CUs shared with the provers' 256-VGPR accumulation waves - lose more to the slower level loop than they win: 114-170 proofs/s
-// against 170-185 with one 256-lane workgroup per batch.)
-constexpr uint32_t WIT_TPW = 256, WIT_WPB = 1;
-__global__ void __launch_bounds__(WIT_TPW * WIT_WPB) k_witness(WitnessProg P, uint32_t l0, uint32_t l1, uint32_t n_batches,
-                                                  const uint64_t* __restrict__ inputs /* batches x n_inputs x 6, ABI */,
-                                                  uint32_t* __restrict__ values /* batches x n_pos x 12 */,
-                                                  uint64_t* __restrict__ z_out /* batches x n_vars x 6, ABI */, uint32_t* __restrict__ flags) {
-  const uint32_t tid = threadIdx.x % WIT_TPW;
-  uint32_t batch = blockIdx.x * WIT_WPB + threadIdx.x / WIT_TPW;
-  const bool active = batch < n_batches;
-  if (!active) batch = 0;               // (idle lane groups keep walking the levels for the barrier; they touch nothing)
+// one instruction: operands x (and y), result r.  Returns true when an inversion that must not meet zero did.
+__device__ __forceinline__ bool w_exec(uint32_t c, int32_t rb, const FrD& x, const FrD& y, const uint64_t* __restrict__ in, int32_t ra, FrD& r) {
+  bool bad = false;
+  switch (c) {
+    case WT_INPUT: {
+      uint64_t w[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) w[k] = in[(size_t)ra * 6 + k];
+      r = fp_cond_sub_p(fp_from_abi<FrParams>(w));
+      break;
+    }
+    case WT_ADD: r = fp_cond_sub_kp<FrParams, 2>(fp_add(x, y)); break;                  // stored values stay below 2p
+    case WT_SUB: r = fp_cond_sub_kp<FrParams, 2>(fp_sub<FrParams, 2>(x, y)); break;
+    case WT_MUL: r = fp_mul(x, y); break;
+    case WT_INV:
+    case WT_INV0:
+      r = fp_inv<FrParams>(x);
+      bad = (c == WT_INV) && fp_is_zero_2p(r);                                        // the host generator would have taken another path
+      break;
+    default: {                                                                         // WT_BIT
+      FrD one_raw = fp_zero<FrParams>();
+      one_raw.l[0] = 1;
+      uint32_t w[12];
+      fp_pack32<FrParams>(fp_cond_sub_p(fp_mul(x, one_raw)), w);                        // the canonical integer
+      r = ((w[rb >> 5] >> (rb & 31)) & 1u) ? fp_one<FrParams>() : fp_zero<FrParams>();
+      break;
+    }
+  }
+  return bad;
+}
+
+// levels [l0, l1) of the levelled program.  (A witness is cut into several launches of a few milliseconds so that the kernels of
+// the provers that share a hardware queue with it are not held up for its whole duration.)
+// Most levels hold a handful of instructions that read what the previous few levels wrote: a round trip through global memory per
+// level would be most of the level.  Every result therefore also goes into an LDS ring (slot = position mod WIT_RING; positions
+// are level-major, so the ring holds the last ~30 narrow levels) and an operand younger than the ring is read from there.
+constexpr uint32_t WIT_RING = 2048;      // 96 KiB of the CU's 160
+__global__ void __launch_bounds__(256) k_witness(WitnessProg P, uint32_t l0, uint32_t l1, const uint64_t* __restrict__ inputs /* batches x n_inputs x 6, ABI */,
+                                                  uint32_t* __restrict__ values /* batches x n_pos x 12 */, uint32_t* __restrict__ flags) {
+  __shared__ uint4 ring[WIT_RING * 3];
+  const uint32_t batch = blockIdx.x, tid = threadIdx.x;
   const uint64_t* in = inputs + (size_t)batch * P.n_inputs * 6;
   uint32_t* vals = values + (size_t)batch * P.n_pos * 12;
   uint32_t bad = 0;
+  auto load = [&](int32_t ref, uint32_t ring_lo) -> FrD {
+    if (ref < 0) return w_load12(P.consts + (size_t)(-1 - ref) * 12);
+    if ((uint32_t)ref >= ring_lo) {                      // young enough to be in the ring (and not yet overwritten by this level)
+      const uint4* q = &ring[((uint32_t)ref % WIT_RING) * 3];
+      uint4 x = q[0], y = q[1], z = q[2];
+      uint32_t w[12] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w, z.x, z.y, z.z, z.w};
+      return fp_unpack32<FrParams>(w);
+    }
+    return w_load12(vals + (size_t)ref * 12);
+  };
+  uint32_t first_written = P.level_start[l0];             // this launch has written positions [first_written, ...) into its ring
 #pragma unroll 1
   for (uint32_t l = l0; l < l1; l++) {
-    const uint32_t p1 = P.level_start[l + 1];
+    const uint32_t p0 = P.level_start[l], p1 = P.level_start[l + 1];
+    // readable from the ring: written by this launch, and not overwritten by anything this level writes (positions < p1)
+    const uint32_t ring_lo = max(first_written, p1 > WIT_RING ? p1 - WIT_RING : 0u);
 #pragma unroll 1
-    for (uint32_t p = P.level_start[l] + (active ? tid : 0x7fffffffu); p < p1; p += WIT_TPW) {
+    for (uint32_t p = p0 + tid; p < p1; p += 256) {
       const uint32_t c = P.code[p];
       if (c == WT_NOP) continue;
       const int32_t ra = P.a[p], rb = P.b[p];
       FrD x = fp_zero<FrParams>(), y = x, r = x;
-      if (c != WT_INPUT) x = w_load12(ra >= 0 ? vals + (size_t)ra * 12 : P.consts + (size_t)(-1 - ra) * 12);
-      if (c == WT_ADD || c == WT_SUB || c == WT_MUL) y = w_load12(rb >= 0 ? vals + (size_t)rb * 12 : P.consts + (size_t)(-1 - rb) * 12);
-      switch (c) {
-        case WT_INPUT: {
-          uint64_t w[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) w[k] = in[(size_t)ra * 6 + k];
-          r = fp_cond_sub_p(fp_from_abi<FrParams>(w));
-          break;
-        }
-        case WT_ADD: r = fp_cond_sub_kp<FrParams, 2>(fp_add(x, y)); break;                  // stored values stay below 2p
-        case WT_SUB: r = fp_cond_sub_kp<FrParams, 2>(fp_sub<FrParams, 2>(x, y)); break;
-        case WT_MUL: r = fp_mul(x, y); break;
-        case WT_INV:
-        case WT_INV0: {
-          r = fp_inv<FrParams>(x);
-          if (c == WT_INV && fp_is_zero_2p(r)) bad = 1;                            // the host generator would have taken another path
-          break;
-        }
-        default: {                                                                 // WT_BIT
-          FrD one_raw = fp_zero<FrParams>();
-          one_raw.l[0] = 1;
-          uint32_t w[12];
-          fp_pack32<FrParams>(fp_cond_sub_p(fp_mul(x, one_raw)), w);                // the canonical integer
-          r = ((w[rb >> 5] >> (rb & 31)) & 1u) ? fp_one<FrParams>() : fp_zero<FrParams>();
-          break;
-        }
-      }
-      w_store12(vals + (size_t)p * 12, r);
+      if (c != WT_INPUT) x = load(ra, ring_lo);
+      if (c == WT_ADD || c == WT_SUB || c == WT_MUL) y = load(rb, ring_lo);
+      if (w_exec(c, rb, x, y, in, ra, r)) bad = 1;
+      uint32_t w[12];
+      fp_pack32<FrParams>(r, w);
+      uint4* g = reinterpret_cast<uint4*>(vals + (size_t)p * 12);
+      uint4* q = &ring[(p % WIT_RING) * 3];
+      const uint4 v0 = make_uint4(w[0], w[1], w[2], w[3]), v1 = make_uint4(w[4], w[5], w[6], w[7]), v2 = make_uint4(w[8], w[9], w[10], w[11]);
+      g[0] = v0; g[1] = v1; g[2] = v2;
+      q[0] = v0; q[1] = v1; q[2] = v2;
     }
     __syncthreads();
   }
   if (bad) atomicOr(&flags[batch], 1u);
-  if (l1 < P.n_levels || !active) return;
-  // the assignment, in ABI form
-  uint64_t* z = z_out + (size_t)batch * P.n_vars * 6;
-  for (uint32_t i = tid; i < P.n_vars; i += WIT_TPW) {
-    const int32_t ref = P.out_ref[i];
-    FrD v = w_load12(ref >= 0 ? vals + (size_t)ref * 12 : P.consts + (size_t)(-1 - ref) * 12);
-    uint64_t w[6];
-    fp_to_abi<FrParams>(v, w);
-#pragma unroll
-    for (int k = 0; k < 6; k++) z[(size_t)i * 6 + k] = w[k];
+}
+
+// The key-hash chain ([chain_start, n_pos) of the program, in execution order) by ONE wave per batch: every lane computes the
+// same instruction (a chain has nothing to spread), lane 0 stores.  The last 64 results wait in an LDS ring; the instruction
+// words are fetched 64 at a time, a lane each, and broadcast.
+__global__ void __launch_bounds__(64) k_witness_chain(WitnessProg P, uint32_t chain_start, const uint64_t* __restrict__ inputs,
+                                                       uint32_t* __restrict__ values, uint32_t* __restrict__ flags) {
+  __shared__ uint4 ring[64 * 3];
+  const uint32_t batch = blockIdx.x, lane = threadIdx.x;
+  const uint64_t* in = inputs + (size_t)batch * P.n_inputs * 6;
+  uint32_t* vals = values + (size_t)batch * P.n_pos * 12;
+  uint32_t bad = 0;
+#pragma unroll 1
+  for (uint32_t base = chain_start; base < P.n_pos; base += 64) {
+    const uint32_t mine = base + lane;
+    const uint32_t my_c = mine < P.n_pos ? P.code[mine] : (uint32_t)WT_NOP;
+    const int32_t my_a = mine < P.n_pos ? P.a[mine] : 0, my_b = mine < P.n_pos ? P.b[mine] : 0;
+    const uint32_t n = min(64u, P.n_pos - base);
+#pragma unroll 1
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t p = base + i;
+      const uint32_t c = (uint32_t)__shfl((int)my_c, (int)i);
+      const int32_t ra = __shfl(my_a, (int)i), rb = __shfl(my_b, (int)i);
+      if (c == WT_NOP) continue;
+      auto load = [&](int32_t ref) -> FrD {
+        if (ref < 0) return w_load12(P.consts + (size_t)(-1 - ref) * 12);
+        if ((uint32_t)ref + 64 > p) {                     // one of the last 64 results
+          const uint4* q = &ring[((uint32_t)ref % 64) * 3];
+          uint4 x = q[0], y = q[1], z = q[2];
+          uint32_t w[12] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w, z.x, z.y, z.z, z.w};
+          return fp_unpack32<FrParams>(w);
+        }
+        return w_load12(vals + (size_t)ref * 12);            // older: its store is long complete (fenced below every 64 instructions)
+      };
+      FrD x = fp_zero<FrParams>(), y = x, r = x;
+      if (c != WT_INPUT) x = load(ra);
+      if (c == WT_ADD || c == WT_SUB || c == WT_MUL) y = load(rb);
+      if (w_exec(c, rb, x, y, in, ra, r)) bad = 1;
+      uint32_t w[12];
+      fp_pack32<FrParams>(r, w);
+      const uint4 v0 = make_uint4(w[0], w[1], w[2], w[3]), v1 = make_uint4(w[4], w[5], w[6], w[7]), v2 = make_uint4(w[8], w[9], w[10], w[11]);
+      if (lane == 0) {
+        uint4* g = reinterpret_cast<uint4*>(vals + (size_t)p * 12);
+        g[0] = v0; g[1] = v1; g[2] = v2;
+        uint4* q = &ring[(p % 64) * 3];
+        q[0] = v0; q[1] = v1; q[2] = v2;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // LDS write visible to the wave's next read
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          // global stores of this chunk complete before older values are re-read
   }
+  if (bad && lane == 0) atomicOr(&flags[batch], 1u);
+}
+
+// the assignment, in ABI form (after both programs)
+__global__ void __launch_bounds__(256) k_witness_out(WitnessProg P, const uint32_t* __restrict__ values, uint64_t* __restrict__ z_out) {
+  const uint32_t batch = blockIdx.y;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_vars) return;
+  const uint32_t* vals = values + (size_t)batch * P.n_pos * 12;
+  const int32_t ref = P.out_ref[i];
+  FrD v = w_load12(ref >= 0 ? vals + (size_t)ref * 12 : P.consts + (size_t)(-1 - ref) * 12);
+  uint64_t w[6];
+  fp_to_abi<FrParams>(v, w);
+  uint64_t* z = z_out + ((size_t)batch * P.n_vars + i) * 6;
+#pragma unroll
+  for (int k = 0; k < 6; k++) z[k] = w[k];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -191,7 +268,7 @@ int witness_prog(zkhip_aggregator* a, WitnessProg* out, const WitnessTape** tape
     }
     pd.prog = WitnessProg{(const uint8_t*)pd.bufs[0], (const int32_t*)pd.bufs[1], (const int32_t*)pd.bufs[2], (const uint32_t*)pd.bufs[3],
                           (const int32_t*)pd.bufs[4], (const uint32_t*)pd.bufs[5], (uint32_t)(T.level_start.size() - 1), (uint32_t)n,
-                          (uint32_t)T.n_vars, (uint32_t)T.n_inputs};
+                          (uint32_t)T.n_vars, (uint32_t)T.n_inputs, T.chain_start};
     it = st->dev.emplace(device, pd).first;
   }
   *out = it->second.prog;
@@ -199,11 +276,18 @@ int witness_prog(zkhip_aggregator* a, WitnessProg* out, const WitnessTape** tape
   return ZKHIP_OK;
 }
 
-void witness_launch(const WitnessProg& P, const uint64_t* d_inputs, uint32_t* d_values, uint64_t* d_z, uint32_t* d_flags, uint32_t batches, hipStream_t st) {
-  const uint32_t seg = 1024;       // levels per launch: ~6 ms
+void witness_launch(const WitnessProg& P, const uint64_t* d_inputs, uint32_t* d_values, uint64_t* d_z, uint32_t* d_flags, uint32_t batches,
+                    hipStream_t st, hipStream_t st_chain, hipEvent_t ev_fork, hipEvent_t ev_join) {
+  // the key-hash chain on a second stream, next to the levelled program; the assignment is gathered when both are done
+  (void)hipEventRecord(ev_fork, st);
+  (void)hipStreamWaitEvent(st_chain, ev_fork, 0);
+  if (P.chain_start < P.n_pos) hipLaunchKernelGGL(k_witness_chain, dim3(batches), dim3(64), 0, st_chain, P, P.chain_start, d_inputs, d_values, d_flags);
+  (void)hipEventRecord(ev_join, st_chain);
+  const uint32_t seg = 1536;       // levels per launch: a few milliseconds
   for (uint32_t l0 = 0; l0 < P.n_levels; l0 += seg)
-    hipLaunchKernelGGL(k_witness, dim3((batches + WIT_WPB - 1) / WIT_WPB), dim3(WIT_TPW * WIT_WPB), 0, st, P, l0,
-                       (l0 + seg < P.n_levels ? l0 + seg : P.n_levels), batches, d_inputs, d_values, d_z, d_flags);
+    hipLaunchKernelGGL(k_witness, dim3(batches), dim3(256), 0, st, P, l0, (l0 + seg < P.n_levels ? l0 + seg : P.n_levels), d_inputs, d_values, d_flags);
+  (void)hipStreamWaitEvent(st, ev_join, 0);
+  hipLaunchKernelGGL(k_witness_out, dim3((P.n_vars + 255) / 256, batches), dim3(256), 0, st, P, d_values, d_z);
 }
 
 }  // namespace zkhip

@@ -45,6 +45,8 @@ struct Recorder {
   }
 };
 static thread_local Recorder* g_rec = nullptr;
+static thread_local size_t g_mark[2] = {0, 0};       // the key-hash section: instructions [g_mark[0], g_mark[1])
+static void on_section(int which) { g_mark[which] = g_rec->ops.size(); }
 
 // The recording scalar.  id < 0: a constant (its value in `val`); id >= 0: the value defined by instruction id.
 struct RecFr {
@@ -136,13 +138,101 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
     NestedData d{arena.data(), arena.data() + vk_w, arena.data() + vk_w + pr_w};
     Builder b;
     b.record = false;
+    b.on_section = rec::on_section;
     synthesize<WV>(b, num_proofs, k, &d);
+    size_t h0 = rec::g_mark[0], h1 = rec::g_mark[1];
     rec::g_rec = &R;                                  // (synthesize leaves the builder pointer cleared, not the recorder)
-    const size_t n_vars = b.z.size(), n_ops = R.ops.size();
+    const size_t n_vars = b.z.size();
     // assignment entry -> reference
     std::vector<int32_t> out_ref(n_vars);
     for (size_t i = 0; i < n_vars; i++) out_ref[i] = b.z[i].ref();
     rec::g_rec = nullptr;
+    // Re-association of sums.  The host code accumulates left to right (a coefficient of an Fq12 product is a chain of twelve
+    // additions), which is what it should do on a CPU and twelve dependent levels here.  Field addition is exact, so a chain of
+    // additions / subtractions whose intermediate results nobody else reads is rewritten as a balanced tree (positive terms, negative
+    // terms, one subtraction): the same value, log2 of the depth.
+    {
+      const size_t n0 = R.ops.size();
+      auto is_lin = [&](size_t i) { return R.ops[i].code == WT_ADD || R.ops[i].code == WT_SUB; };
+      std::vector<uint32_t> uses(n0, 0);
+      std::vector<int32_t> user(n0, -1);
+      for (size_t i = 0; i < n0; i++) {
+        const auto& op = R.ops[i];
+        if (op.code == WT_INPUT) continue;
+        if (op.a >= 0) { uses[op.a]++; user[op.a] = (int32_t)i; }
+        if ((op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) && op.b >= 0) { uses[op.b]++; user[op.b] = (int32_t)i; }
+      }
+      for (int32_t r : out_ref) if (r >= 0) uses[r] += 2;                       // an assignment entry is a reader
+      std::vector<uint8_t> absorbed(n0, 0);
+      for (size_t i = 0; i < n0; i++)
+        absorbed[i] = is_lin(i) && uses[i] == 1 && user[i] >= 0 && is_lin((size_t)user[i]) && ((i >= h0 && i < h1) == ((size_t)user[i] >= h0 && (size_t)user[i] < h1));
+      std::vector<Recorder::Op> ops2;
+      std::vector<int32_t> remap(n0, -1);
+      size_t nh0 = 0, nh1 = 0;
+      bool seen_h0 = false;
+      std::vector<std::pair<int32_t, int>> terms, stack;
+      for (size_t i = 0; i < n0; i++) {
+        if (i == h0) { nh0 = ops2.size(); seen_h0 = true; }
+        if (i == h1) nh1 = ops2.size();
+        if (absorbed[i]) continue;
+        const auto& op = R.ops[i];
+        auto rm = [&](int32_t ref) { return ref >= 0 ? remap[ref] : ref; };
+        if (!is_lin(i)) {
+          Recorder::Op o = op;
+          if (op.code != WT_INPUT) {
+            o.a = rm(op.a);
+            if (op.code == WT_MUL) o.b = rm(op.b);
+          }
+          ops2.push_back(o);
+          remap[i] = (int32_t)ops2.size() - 1;
+          continue;
+        }
+        // gather the terms of this sum through the absorbed operands
+        terms.clear(); stack.clear();
+        stack.push_back({(int32_t)i, +1});
+        while (!stack.empty()) {
+          auto [ref, sign] = stack.back();
+          stack.pop_back();
+          if (ref >= 0 && (absorbed[ref] || ref == (int32_t)i)) {
+            const auto& o = R.ops[ref];
+            stack.push_back({o.a, sign});
+            stack.push_back({o.b, o.code == WT_SUB ? -sign : sign});
+          } else {
+            terms.push_back({ref, sign});
+          }
+        }
+        std::vector<int32_t> pos, neg;
+        for (auto& t : terms) (t.second > 0 ? pos : neg).push_back(rm(t.first));
+        auto tree = [&](std::vector<int32_t>& v) -> int32_t {
+          while (v.size() > 1) {
+            std::vector<int32_t> nx;
+            for (size_t k = 0; k + 1 < v.size(); k += 2) { ops2.push_back({WT_ADD, v[k], v[k + 1]}); nx.push_back((int32_t)ops2.size() - 1); }
+            if (v.size() & 1) nx.push_back(v.back());
+            v.swap(nx);
+          }
+          return v[0];
+        };
+        int32_t res;
+        if (neg.empty()) res = tree(pos);
+        else {
+          int32_t n_ = tree(neg);
+          int32_t p_ = pos.empty() ? (-1 - R.intern(rec::HV::zero())) : tree(pos);
+          ops2.push_back({WT_SUB, p_, n_});
+          res = (int32_t)ops2.size() - 1;
+        }
+        if (res < 0 || (size_t)res + 1 != ops2.size()) {          // a single (remapped) term: keep a defining instruction for this value
+          ops2.push_back({WT_ADD, res, -1 - R.intern(rec::HV::zero())});
+          res = (int32_t)ops2.size() - 1;
+        }
+        remap[i] = res;
+      }
+      if (!seen_h0) nh0 = ops2.size();
+      if (h1 >= n0) nh1 = ops2.size();
+      for (auto& r : out_ref) if (r >= 0) r = remap[r];
+      R.ops.swap(ops2);
+      h0 = nh0; h1 = nh1;
+    }
+    const size_t n_ops = R.ops.size();
     // prune: keep what the assignment depends on
     std::vector<uint8_t> live(n_ops, 0);
     for (int32_t r : out_ref) if (r >= 0) live[r] = 1;
@@ -153,11 +243,16 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
       if (op.a >= 0) live[op.a] = 1;
       if ((op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) && op.b >= 0) live[op.b] = 1;
     }
+    // The key hash (MiMC, Miyaguchi-Preneel chaining: 13 absorptions x 93 rounds x 7 dependent operations) is one long chain with
+    // nothing to run beside it: as levels of the common program it would be 8,500 of its 9,800 levels, each paying a barrier and a
+    // round trip through memory for ONE instruction.  It depends on the inputs only and nothing but the assignment reads it, so it
+    // becomes a program of its own, run in recorded order by a single wave next to the levelled rest (k_witness_chain).
+    auto in_chain = [&](size_t i) { return i >= h0 && i < h1; };
     // levels
     std::vector<int32_t> level(n_ops, 0);
     int32_t max_level = 0;
     for (size_t i = 0; i < n_ops; i++) {
-      if (!live[i]) continue;
+      if (!live[i] || in_chain(i)) continue;
       const auto& op = R.ops[i];
       int32_t l = 0;
       if (op.code != WT_INPUT) {
@@ -171,7 +266,7 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
     auto kind_rank = [](uint8_t c) { return (c == WT_INV || c == WT_INV0) ? 0 : c == WT_MUL ? 1 : c == WT_INPUT ? 2 : c == WT_BIT ? 3 : 4; };
     std::vector<uint32_t> order;
     order.reserve(n_ops);
-    for (size_t i = 0; i < n_ops; i++) if (live[i]) order.push_back((uint32_t)i);
+    for (size_t i = 0; i < n_ops; i++) if (live[i] && !in_chain(i)) order.push_back((uint32_t)i);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
       if (level[x] != level[y]) return level[x] < level[y];
       return kind_rank(R.ops[x].code) < kind_rank(R.ops[y].code);
@@ -191,8 +286,46 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
     }
     while (T.code.size() % 64) { T.code.push_back(WT_NOP); T.a.push_back(0); T.b.push_back(0); }
     T.level_start.push_back((uint32_t)T.code.size());
+    // the chain program, appended: its own copies of the inputs it reads, then its instructions in recorded order
+    T.chain_start = (uint32_t)T.code.size();
+    {
+      std::map<uint32_t, int32_t> input_copy;
+      auto need_input = [&](int32_t ref) {
+        if (ref < 0 || in_chain((size_t)ref)) return;
+        if (R.ops[ref].code != WT_INPUT) throw std::runtime_error("the key-hash section reads a value of another section");
+        if (!input_copy.count((uint32_t)ref)) input_copy[(uint32_t)ref] = 0;
+      };
+      for (size_t i = h0; i < h1; i++) {
+        if (!live[i]) continue;
+        const auto& op = R.ops[i];
+        if (op.code == WT_INPUT) continue;
+        need_input(op.a);
+        if (op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) need_input(op.b);
+      }
+      for (auto& kv : input_copy) {
+        kv.second = (int32_t)T.code.size();
+        T.code.push_back(WT_INPUT); T.a.push_back(R.ops[kv.first].a); T.b.push_back(0);
+      }
+      // (inside the chain, references to an input outside it go to the chain's copy: remembered through chain_alias)
+      for (size_t i = h0; i < h1; i++) {
+        if (!live[i]) continue;
+        pos_of[i] = (int32_t)T.code.size();
+        T.code.push_back(R.ops[i].code); T.a.push_back(R.ops[i].a); T.b.push_back(R.ops[i].b);
+      }
+      for (size_t p = T.chain_start; p < T.code.size(); p++) {
+        const uint8_t c = T.code[p];
+        if (c == WT_INPUT) continue;
+        auto fix = [&](int32_t ref) -> int32_t {
+          if (ref < 0) return ref;
+          if (in_chain((size_t)ref)) return pos_of[ref];
+          return input_copy.at((uint32_t)ref);
+        };
+        T.a[p] = fix(T.a[p]);
+        if (c == WT_ADD || c == WT_SUB || c == WT_MUL) T.b[p] = fix(T.b[p]);
+      }
+    }
     // operands: instruction ids -> positions
-    for (size_t p = 0; p < T.code.size(); p++) {
+    for (size_t p = 0; p < T.chain_start; p++) {
       const uint8_t c = T.code[p];
       if (c == WT_NOP || c == WT_INPUT) continue;
       if (T.a[p] >= 0) T.a[p] = pos_of[T.a[p]];

@@ -22,6 +22,7 @@ struct WitnessTape {
   std::vector<uint8_t> code;
   std::vector<int32_t> a, b;
   std::vector<uint32_t> level_start;     // positions; level l = [level_start[l], level_start[l + 1]), multiples of 64
+  uint32_t chain_start = 0;              // positions [chain_start, code.size()): the key-hash chain, in execution order
   std::vector<int32_t> out_ref;          // assignment entry i = value at this reference
   std::vector<uint64_t> consts;          // 6 limbs each, ABI form (Montgomery 2^384)
   size_t n_vars = 0, n_inputs = 0, vk_words = 0, proofs_words = 0, inputs_words = 0;

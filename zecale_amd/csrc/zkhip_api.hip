@@ -1012,8 +1012,8 @@ struct zkhip_gpu_witness {
   uint32_t* d_vals = nullptr;
   uint32_t* d_flag = nullptr;
   uint64_t* h_in = nullptr;       // pinned staging: inputs, then the flag and the primary inputs on the way back
-  hipStream_t st = nullptr;
-  hipEvent_t ev = nullptr;
+  hipStream_t st = nullptr, st2 = nullptr;
+  hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
 };
 
 int zkhip_gpu_witness_new(zkhip_aggregator* a, zkhip_gpu_witness** out) { return zkhip_gpu_witness_new_batched(a, 1, out); }
@@ -1032,7 +1032,10 @@ int zkhip_gpu_witness_new_batched(zkhip_aggregator* a, size_t max_batches, zkhip
   if (e == hipSuccess) e = hipMalloc(&w->d_flag, max_batches * 4 + 64);
   if (e == hipSuccess) e = hipHostMalloc(&w->h_in, max_batches * (w->in_words + 1 + a->n_primary * 6) * 8);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->st2, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev, hipEventBlockingSync | hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming);
   if (e != hipSuccess) {
     snprintf(t_err, sizeof t_err, "zkhip_gpu_witness_new: %s", hipGetErrorString(e));
     zkhip_gpu_witness_free(w);
@@ -1050,7 +1053,10 @@ void zkhip_gpu_witness_free(zkhip_gpu_witness* w) {
   if (w->d_flag) (void)hipFree(w->d_flag);
   if (w->h_in) (void)hipHostFree(w->h_in);
   if (w->st) (void)hipStreamDestroy(w->st);
+  if (w->st2) (void)hipStreamDestroy(w->st2);
   if (w->ev) (void)hipEventDestroy(w->ev);
+  if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
+  if (w->ev_join) (void)hipEventDestroy(w->ev_join);
   delete w;
 }
 
@@ -1073,7 +1079,7 @@ int zkhip_gpu_witness_run_batched(zkhip_gpu_witness* w, size_t n, const uint64_t
   uint64_t* h_prim = h_flags + w->max_batches;
   API_HIP(hipMemcpyAsync(w->d_in, w->h_in, n * w->in_words * 8, hipMemcpyHostToDevice, w->st));
   API_HIP(hipMemsetAsync(w->d_flag, 0, n * 4, w->st));
-  witness_launch(w->prog, w->d_in, w->d_vals, (uint64_t*)d_z_out, w->d_flag, (uint32_t)n, w->st);
+  witness_launch(w->prog, w->d_in, w->d_vals, (uint64_t*)d_z_out, w->d_flag, (uint32_t)n, w->st, w->st2, w->ev_fork, w->ev_join);
   API_HIP(hipGetLastError());
   API_HIP(hipMemcpyAsync(h_flags, w->d_flag, n * 4, hipMemcpyDeviceToHost, w->st));
   for (size_t i = 0; i < n; i++)

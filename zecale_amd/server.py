@@ -215,7 +215,7 @@ class GpuProver:
     """The wrapping prover behind the service: circuit, keypair (file or fresh setup), HBM-resident key, streaming pipeline."""
     snark_name = "GROTH16"
 
-    def __init__(self, keypair_file=None, device=0, gpu_slots=4, witness_workers=6):
+    def __init__(self, keypair_file=None, device=0, gpu_slots=4, witness_workers=6, gpu_witness=False):
         from . import zkhip
         self.zk = zkhip
         zkhip.init(device)
@@ -233,7 +233,7 @@ class GpuProver:
         if self.vk["ABC"].shape[0] != self.agg.num_primary_inputs() + 1:      # the server's "invalid VK" check (:490, :504)
             raise ValueError("invalid VK")
         self.crs = self.kp.upload_crs()
-        self.pipe = zkhip.AggregatorPipeline(self.agg, self.crs, gpu_slots=gpu_slots, witness_workers=witness_workers)
+        self.pipe = zkhip.AggregatorPipeline(self.agg, self.crs, gpu_slots=gpu_slots, witness_workers=witness_workers, gpu_witness=gpu_witness)
 
     def verification_key_json(self):
         return E.verification_key_to_json(self.vk)
@@ -421,9 +421,10 @@ def main(argv=None):
                     help="file to load the keypair from (generated and written there when missing)")
     ap.add_argument("--endpoint", default=DEFAULT_ENDPOINT)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--gpu-witness", action="store_true", help="generate the assignments on the GPU (fewer host cores per GPU)")
     args = ap.parse_args(argv)
     print("[INFO] Init params of both curves")
-    prover = GpuProver(args.keypair, device=args.device)
+    prover = GpuProver(args.keypair, device=args.device, gpu_witness=args.gpu_witness)
     print("[INFO] Circuit has %d constraints" % prover.agg.num_constraints)
     print("[INFO] Setup successful, starting the server...")
     server, port, _ = serve(prover, args.endpoint)
