@@ -3,16 +3,26 @@
 // r1cs_to_qap_witness_map that the reference reaches through wsnarkT::generate_proof
 // (libzecale/circuits/aggregator_circuit.tcc:168; libfqfft basic_radix2_domain).
 //
-// Structure: "four-step" decomposition d = K * N2 with both factors <= 2^11 so that every
-// sub-transform runs entirely in LDS (limb-major [14][K] image, conflict-free: 2^11 x 56 B =
-// 112 KiB of the CU's 160 KiB):
-//   pass A   N2 column transforms of size K (stride N2), root omega^N2, then the inter-step
-//            twiddle omega^(c*k1); the forward coset shift g^i is folded into the load
-//   pass B   K row transforms of size N2 (contiguous), root omega^K; the result X[k1 + K*k2] is
-//            written in natural order; 1/d and the inverse coset shift are folded into the store
-// Two HBM round trips per transform (algorithmic bytes 2 * d * 48 B; here 4 * d * 48 B).
-// Elements travel between passes as 12 packed words (48 B, device Montgomery form, value < 2^384:
-// lazily reduced, no canonicalisation between passes).
+// Structure: "four-step" decomposition d = K * N2 with both factors <= 2^11, every sub-transform entirely in LDS
+// (limb-major image, 14 x 2048 words = 112 KiB of the CU's 160 KiB), BOTH passes in place - no second buffer:
+//   a vector v of length d is kept either in natural order or in TRANSPOSED order, v[k1 + K*k2] at k1*N2 + k2.
+//   natural -> transposed   pass 1: the N2 column transforms of size K (stride N2), then the inter-step twiddle
+//                           omega^(c*k1); pass 2: the K row transforms of size N2 (contiguous), result left in the row
+//   transposed -> natural   pass 1: the K row transforms of size N2 (contiguous: element i1*K + i2 lives at i2*N2 + i1),
+//                           twiddle omega^(i2*k1'); pass 2: the N2 column transforms of size K; X[k1' + N2*k2'] lands
+//                           at k2'*N2 + k1' - natural order
+//   r1cs_to_qap_witness_map chains them so that nothing is ever reordered: SpMV writes transposed, iFFT (t->n),
+//   cosetFFT (n->t), the pointwise H (order-blind), icosetFFT (t->n).
+//   Two HBM round trips per transform (2 * 2 * d * 48 B), the algorithmic minimum of a two-pass transform.
+// A workgroup takes C adjacent sub-transforms (C * K = 2048 elements when there are that many): the strided pass then
+// moves C * 48 contiguous bytes per row instead of 48, and a thread carries FOUR elements through two butterfly stages
+// per LDS round trip (radix 4): half the barriers and half the LDS traffic of one butterfly per thread per stage.
+// Multiplications per element of a 2^20 transform: 10 in the butterflies, ONE for everything else.  The inter-step
+// twiddle comes from a full table laid out like the data (one 48-byte load, no two-level product), and the scalings ride
+// along: 1/d and the column part of a coset shift are folded into that table; the row part of the forward shift g^i is
+// folded into the first pass's stage twiddles (a DIT transform of x_j*c^j is the plain one with stage-s twiddles times
+// c^(K/2^s)); only the inverse coset shift needs a second table multiplication (K entries, by output index).
+// Elements travel as 12 packed words (48 B, device Montgomery form, value < 2^384: lazily reduced).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -62,11 +72,13 @@ __global__ void __launch_bounds__(256) k_fr_abi_to_dev(const uint64_t* __restric
   for (int k = 0; k < 6; k++) x[k] = in[i * 6 + k];
   fr_store12(out + i * 12, fp_from_abi<FrParams>(x));
 }
-__global__ void __launch_bounds__(256) k_fr_dev_to_abi(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, size_t n) {
+// (log_k != 0: `in` is in transposed order, element i at (i mod 2^log_k) * 2^log_n2 + (i >> log_k))
+__global__ void __launch_bounds__(256) k_fr_dev_to_abi(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, size_t n, int log_k, int log_n2) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t x[6];
-  fp_to_abi<FrParams>(fr_load12(in + i * 12), x);
+  const size_t loc = log_k ? ((i & (((size_t)1 << log_k) - 1)) << log_n2) + (i >> log_k) : i;
+  fp_to_abi<FrParams>(fr_load12(in + loc * 12), x);
 #pragma unroll
   for (int k = 0; k < 6; k++) out[i * 6 + k] = x[k];
 }
@@ -76,78 +88,134 @@ __device__ __forceinline__ FrD pow_tab(const uint32_t* __restrict__ lo, const ui
   return fp_mul(fr_load14(lo + (size_t)(e & 1023u) * 14), fr_load14(hi + (size_t)(e >> 10) * 14));
 }
 
-struct TileArgs {
-  const uint32_t* src;      // packed elements
-  uint32_t* dst;
-  uint32_t in_b, in_j;      // element j of tile b is src[b*in_b + j*in_j]
-  uint32_t out_b, out_j;    // ... and goes to dst[b*out_b + j*out_j]
-  const uint32_t* tw;       // K/2 twiddles of the size-K transform (14 limbs each)
-  const uint32_t* pre_lo;   // optional: multiply input element with global index i by pre^i
-  const uint32_t* pre_hi;
-  const uint32_t* mid_lo;   // optional: multiply output j of tile b by mid^(b*j)
-  const uint32_t* mid_hi;
-  const uint32_t* post_lo;  // optional: multiply output with global index o by post^o (constant folded into lo)
-  const uint32_t* post_hi;
-  const uint32_t* post_const;   // optional: multiply every output by a constant (14 limbs)
+struct PassArgs {
+  uint32_t* data;           // packed elements, transformed in place
+  uint32_t strided;         // 1: sub-transform q is column q (element j at q + j*S); 0: row q (element j at q*K + j)
+  uint32_t S;               // row length of the strided pass
+  const uint32_t* tw;       // stage twiddles, heap order: stage s (butterflies of span 2^s) entry jj at 2^(s-1) + jj (14 limbs each)
+  uint32_t tw_scaled;       // the stage twiddles carry a coset shift: the first stage multiplies too
+  const uint32_t* mid;      // optional: the output at data location loc is multiplied by mid[loc] (12 packed words each)
+  const uint32_t* post_k;   // optional: output k of every sub-transform is multiplied by post_k[k] (14 limbs each)
+  const uint32_t* post_const;   // optional: every output multiplied by a constant (14 limbs)
 };
 
-constexpr int tile_threads(int logk) { return logk <= 6 ? 64 : (1 << (logk - 1)); }
+constexpr int pass_threads(int logk, int logc) { return (logk + logc) <= 8 ? 64 : (1 << (logk + logc - 2)); }
 
-template <int LOGK>
-__global__ void __launch_bounds__(tile_threads(LOGK)) k_ntt_tile(TileArgs a) {
-  constexpr int K = 1 << LOGK;
-  constexpr int NT = (K / 2) < 1 ? 1 : (K / 2);
-  __shared__ uint32_t lds[14 * K];
+// Inputs < 8r (every producer here stores < 2r); values grow by at most 2r per stage (< 2^7 r = 2^384 at the end).
+template <int LOGK, int LOGC>
+__global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs a) {
+  constexpr uint32_t K = 1u << LOGK, C = 1u << LOGC, E = K * C, T = pass_threads(LOGK, LOGC);
+  __shared__ uint32_t lds[14 * E];
   const uint32_t tid = threadIdx.x;
-  const uint32_t b = blockIdx.x;
-  if (tid < (uint32_t)NT) {
-    // load two elements, (optionally) pre-multiply, store bit-reversed into LDS
+  const uint32_t q0 = blockIdx.x * C;
+  constexpr uint32_t EPT = (E + T - 1) / T;
+  // ---- load: C*48 contiguous bytes per row in the strided pass, the whole tile contiguous in the other
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      uint32_t j = tid + h * NT;
-      if (j >= (uint32_t)K) break;
-      uint32_t gi = b * a.in_b + j * a.in_j;
-      FrD v = fr_load12(a.src + (size_t)gi * 12);
-      if (a.pre_lo) v = fp_mul(v, pow_tab(a.pre_lo, a.pre_hi, gi));
-      uint32_t rj = LOGK ? (__brev(j) >> ((32 - LOGK) & 31)) : 0u;     // (LOGK = 0: a transform of size 1)
+  for (uint32_t h = 0; h < EPT; h++) {
+    const uint32_t e = tid + h * T;
+    if (E < T && e >= E) break;
+    uint32_t cc, j;
+    if (a.strided) { cc = e & (C - 1); j = e >> LOGC; } else { j = e & (K - 1); cc = e >> LOGK; }
+    const uint32_t q = q0 + cc;
+    const size_t loc = a.strided ? (size_t)q + (size_t)j * a.S : ((size_t)q << LOGK) + j;
+    const FrD v = fr_load12(a.data + loc * 12);
+    const uint32_t rj = LOGK ? (__brev(j) >> ((32 - LOGK) & 31)) : 0u;     // (LOGK = 0: a transform of size 1)
 #pragma unroll
-      for (int i = 0; i < 14; i++) lds[i * K + rj] = v.l[i];
-    }
+    for (int i = 0; i < 14; i++) lds[i * E + cc * K + rj] = v.l[i];
   }
   __syncthreads();
+  // ---- two stages per round trip through LDS
+  int s = 1;
 #pragma unroll 1
-  for (int s = 1; s <= LOGK; s++) {
-    if (tid < (uint32_t)NT) {
-      const uint32_t half = 1u << (s - 1);
-      const uint32_t jj = tid & (half - 1);
-      const uint32_t p0 = ((tid >> (s - 1)) << s) + jj, p1 = p0 + half;
-      FrD u, v;
+  for (; s + 1 <= LOGK; s += 2) {
+    for (uint32_t g = tid; g < E / 4; g += T) {
+      const uint32_t cc = LOGK >= 2 ? (g >> ((LOGK - 2) & 31)) : 0u, gi = g & (K / 4 - 1);
+      const uint32_t qq = 1u << (s - 1);
+      const uint32_t jj = gi & (qq - 1), blk = gi >> (s - 1);
+      const uint32_t p0 = cc * K + (blk << (s + 1)) + jj;
+      FrD x0, x1, x2, x3;
 #pragma unroll
-      for (int i = 0; i < 14; i++) { u.l[i] = lds[i * K + p0]; v.l[i] = lds[i * K + p1]; }
-      FrD t = (s == 1) ? v : fp_mul(v, fr_load14(a.tw + (size_t)(jj << (LOGK - s)) * 14));   // first stage: w = 1
-      FrD x = fp_add(u, t);
-      FrD y = fp_sub<FrParams, 2>(u, t);
-      if (s == 1) y = fp_sub<FrParams, 16>(u, t);   // t = v may be lazily bounded (< 16 r) here
+      for (int i = 0; i < 14; i++) {
+        x0.l[i] = lds[i * E + p0]; x1.l[i] = lds[i * E + p0 + qq];
+        x2.l[i] = lds[i * E + p0 + 2 * qq]; x3.l[i] = lds[i * E + p0 + 3 * qq];
+      }
+      FrD y0, y1, y2, y3, z0, z1, z2, z3;
+      if (s == 1 && !a.tw_scaled) {                     // twiddles 1, 1 | 1, omega^(K/4): one multiplication
+        y0 = fp_add(x0, x1); y1 = fp_sub<FrParams, 16>(x0, x1);
+        y2 = fp_add(x2, x3); y3 = fp_sub<FrParams, 16>(x2, x3);
+        FrD u3 = fp_mul(y3, fr_load14(a.tw + (size_t)3 * 14));
+        z0 = fp_add(y0, y2); z2 = fp_sub<FrParams, 16>(y0, y2);
+        z1 = fp_add(y1, u3); z3 = fp_sub<FrParams, 2>(y1, u3);
+      } else {
+        const FrD w = fr_load14(a.tw + (size_t)(qq + jj) * 14);
+        const FrD wa = fr_load14(a.tw + (size_t)(2 * qq + jj) * 14);
+        const FrD wb = fr_load14(a.tw + (size_t)(3 * qq + jj) * 14);
+        FrD t1 = fp_mul(x1, w), t3 = fp_mul(x3, w);
+        y0 = fp_add(x0, t1); y1 = fp_sub<FrParams, 2>(x0, t1);
+        y2 = fp_add(x2, t3); y3 = fp_sub<FrParams, 2>(x2, t3);
+        FrD u2 = fp_mul(y2, wa), u3 = fp_mul(y3, wb);
+        z0 = fp_add(y0, u2); z2 = fp_sub<FrParams, 2>(y0, u2);
+        z1 = fp_add(y1, u3); z3 = fp_sub<FrParams, 2>(y1, u3);
+      }
 #pragma unroll
-      for (int i = 0; i < 14; i++) { lds[i * K + p0] = x.l[i]; lds[i * K + p1] = y.l[i]; }
+      for (int i = 0; i < 14; i++) {
+        lds[i * E + p0] = z0.l[i]; lds[i * E + p0 + qq] = z1.l[i];
+        lds[i * E + p0 + 2 * qq] = z2.l[i]; lds[i * E + p0 + 3 * qq] = z3.l[i];
+      }
     }
     __syncthreads();
   }
-  if (tid < (uint32_t)NT) {
+  if (s == LOGK) {                                      // an odd number of stages: the last one alone
+    for (uint32_t g = tid; g < E / 2; g += T) {
+      const uint32_t cc = LOGK >= 1 ? (g >> ((LOGK - 1) & 31)) : 0u, gi = g & (K / 2 - 1);
+      const uint32_t half = 1u << (s - 1);
+      const uint32_t jj = gi & (half - 1);
+      const uint32_t p0 = cc * K + ((gi >> (s - 1)) << s) + jj, p1 = p0 + half;
+      FrD u, v;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      uint32_t j = tid + h * NT;
-      if (j >= (uint32_t)K) break;
-      FrD v;
+      for (int i = 0; i < 14; i++) { u.l[i] = lds[i * E + p0]; v.l[i] = lds[i * E + p1]; }
+      FrD x, y;
+      if (s == 1 && !a.tw_scaled) { x = fp_add(u, v); y = fp_sub<FrParams, 16>(u, v); }
+      else {
+        FrD t = fp_mul(v, fr_load14(a.tw + (size_t)(half + jj) * 14));
+        x = fp_add(u, t); y = fp_sub<FrParams, 2>(u, t);
+      }
 #pragma unroll
-      for (int i = 0; i < 14; i++) v.l[i] = lds[i * K + j];
-      uint32_t go = b * a.out_b + j * a.out_j;
-      if (a.mid_lo) v = fp_mul(v, pow_tab(a.mid_lo, a.mid_hi, b * j));
-      if (a.post_lo) v = fp_mul(v, pow_tab(a.post_lo, a.post_hi, go));
-      if (a.post_const) v = fp_mul(v, fr_load14(a.post_const));
-      fr_store12(a.dst + (size_t)go * 12, v);
+      for (int i = 0; i < 14; i++) { lds[i * E + p0] = x.l[i]; lds[i * E + p1] = y.l[i]; }
     }
+    __syncthreads();
   }
+  // ---- store (same places)
+#pragma unroll
+  for (uint32_t h = 0; h < EPT; h++) {
+    const uint32_t e = tid + h * T;
+    if (E < T && e >= E) break;
+    uint32_t cc, k;
+    if (a.strided) { cc = e & (C - 1); k = e >> LOGC; } else { k = e & (K - 1); cc = e >> LOGK; }
+    const uint32_t q = q0 + cc;
+    const size_t loc = a.strided ? (size_t)q + (size_t)k * a.S : ((size_t)q << LOGK) + k;
+    FrD v;
+#pragma unroll
+    for (int i = 0; i < 14; i++) v.l[i] = lds[i * E + cc * K + k];
+    if (a.mid) v = fp_mul(v, fr_load12(a.mid + loc * 12));
+    if (a.post_k) v = fp_mul(v, fr_load14(a.post_k + (size_t)k * 14));
+    if (a.post_const) v = fp_mul(v, fr_load14(a.post_const));
+    fr_store12(a.data + loc * 12, v);
+  }
+}
+
+// out[loc] = mid^(q*k) * ext^(q*ext_q + k*ext_k)   for the element (sub-transform q, output k) that lives at loc:
+// loc = q + k*S (strided first pass) or q*K1 + k (contiguous first pass).  ext_lo == nullptr: no second factor.
+__global__ void __launch_bounds__(256) k_mid_table(uint32_t* __restrict__ out, uint32_t d, uint32_t strided, uint32_t log_s /* log2 of S or K1 */,
+                                                    const uint32_t* __restrict__ mid_lo, const uint32_t* __restrict__ mid_hi,
+                                                    const uint32_t* __restrict__ ext_lo, const uint32_t* __restrict__ ext_hi, uint32_t ext_q, uint32_t ext_k) {
+  const uint32_t loc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (loc >= d) return;
+  const uint32_t lo_part = loc & ((1u << log_s) - 1), hi_part = loc >> log_s;
+  const uint32_t q = strided ? lo_part : hi_part, k = strided ? hi_part : lo_part;
+  FrD v = pow_tab(mid_lo, mid_hi, q * k);
+  if (ext_lo) v = fp_mul(v, pow_tab(ext_lo, ext_hi, q * ext_q + k * ext_k));
+  fr_store12(out + (size_t)loc * 12, v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -171,10 +239,13 @@ struct PowTable { uint32_t *lo = nullptr, *hi = nullptr; };
 
 struct NttTables {
   int log_d = 0, log_k = 0, log_n2 = 0;
-  uint32_t *twA = nullptr, *twB = nullptr;   // size-K and size-N2 twiddles for this direction
-  PowTable mid;                              // omega^(+-1) powers (inter-step twiddle)
+  uint32_t *twA = nullptr, *twB = nullptr;   // stage twiddles (heap order) of the size-K and size-N2 transforms of this direction
+  uint32_t* twA_coset = nullptr;             // forward: those of size K times (g^N2)^(K/2^s) - the row part of the shift g^i
+  PowTable mid;                              // omega^(+-1) powers (the tables below are made from these two)
   PowTable coset;                            // forward: g^i ; inverse: g^-i * d^-1
   uint32_t* inv_d = nullptr;                 // inverse only: d^-1
+  uint32_t* mid_full[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [coset][input transposed]: inter-step twiddle with the scalings folded in
+  uint32_t* post_k[2] = {nullptr, nullptr};  // inverse coset, [input transposed]: the part of g^-o the table above cannot hold
 };
 
 static hipError_t upload(const std::vector<uint32_t>& v, uint32_t** d) {
@@ -194,12 +265,24 @@ static hipError_t make_pow_table(const HFr& base, const HFr& constant, uint32_t 
   return upload(hi, &t->hi);
 }
 
-static hipError_t make_twiddles(const HFr& root /* primitive 2^log_k-th root */, int log_k, uint32_t** d) {
+// stage twiddles of a size-2^log_k DIT transform with root `root`, in heap order: entry 2^(s-1) + jj = root^(jj * 2^(log_k-s))
+// times shift^(2^(log_k-s))  (shift = 1: the plain transform; entry 0 unused)
+static hipError_t make_twiddles(const HFr& root, const HFr& shift, int log_k, uint32_t** d) {
   std::vector<uint32_t> tw;
-  HFr acc = HFr::one();
-  size_t half = log_k == 0 ? 1 : ((size_t)1 << (log_k - 1));
-  for (size_t j = 0; j < half; j++) { push_dev_limbs(tw, acc); acc = acc * root; }
+  push_dev_limbs(tw, HFr::one());
+  for (int s = 1; s <= log_k; s++) {
+    const HFr step = hfr_pow_u64(root, (uint64_t)1 << (log_k - s)), scale = hfr_pow_u64(shift, (uint64_t)1 << (log_k - s));
+    HFr acc = scale;
+    for (size_t jj = 0; jj < ((size_t)1 << (s - 1)); jj++) { push_dev_limbs(tw, acc); acc = acc * step; }
+  }
   return upload(tw, d);
+}
+
+static hipError_t make_powers(const HFr& base, const HFr& constant, size_t n, uint32_t** d) {
+  std::vector<uint32_t> v;
+  HFr acc = constant;
+  for (size_t j = 0; j < n; j++) { push_dev_limbs(v, acc); acc = acc * base; }
+  return upload(v, d);
 }
 
 static std::map<int, NttTables>& table_cache() {
@@ -230,19 +313,29 @@ static int get_tables(int log_d, int inverse, NttTables** out, char* err, size_t
   hipError_t e = hipSuccess;
   do {
     // root of the size-K column transforms: omega^N2 ; of the size-N2 row transforms: omega^K
-    if ((e = make_twiddles(hfr_pow_u64(omega, (uint64_t)1 << t.log_n2), t.log_k, &t.twA)) != hipSuccess) break;
+    const HFr rootA = hfr_pow_u64(omega, (uint64_t)1 << t.log_n2);
+    if ((e = make_twiddles(rootA, HFr::one(), t.log_k, &t.twA)) != hipSuccess) break;
     if (t.log_n2 > 0) {
-      if ((e = make_twiddles(hfr_pow_u64(omega, (uint64_t)1 << t.log_k), t.log_n2, &t.twB)) != hipSuccess) break;
+      if ((e = make_twiddles(hfr_pow_u64(omega, (uint64_t)1 << t.log_k), HFr::one(), t.log_n2, &t.twB)) != hipSuccess) break;
       if ((e = make_pow_table(omega, HFr::one(), d, &t.mid)) != hipSuccess) break;
     }
+    const uint64_t K = (uint64_t)1 << t.log_k, N2 = (uint64_t)1 << t.log_n2;
     if (!inverse) {
       if ((e = make_pow_table(g, HFr::one(), d, &t.coset)) != hipSuccess) break;
+      if ((e = make_twiddles(rootA, hfr_pow_u64(g, N2), t.log_k, &t.twA_coset)) != hipSuccess) break;
     } else {
-      HFr dinv = HFr::from_u64(d).inv();
-      if ((e = make_pow_table(g.inv(), dinv, d, &t.coset)) != hipSuccess) break;
+      const HFr dinv = HFr::from_u64(d).inv(), h = g.inv();
+      if ((e = make_pow_table(h, dinv, d, &t.coset)) != hipSuccess) break;
       std::vector<uint32_t> v;
       push_dev_limbs(v, dinv);
       if ((e = upload(v, &t.inv_d)) != hipSuccess) break;
+      if (t.log_n2 == 0) {
+        if ((e = make_powers(h, dinv, K, &t.post_k[0])) != hipSuccess) break;                  // one tile: g^-k / d
+      } else {
+        // output o = k1 + K*k2 (natural input) or k1' + N2*k2' (transposed input): the first part is in the full table
+        if ((e = make_powers(hfr_pow_u64(h, K), HFr::one(), N2, &t.post_k[0])) != hipSuccess) break;
+        if ((e = make_powers(hfr_pow_u64(h, N2), HFr::one(), K, &t.post_k[1])) != hipSuccess) break;
+      }
     }
   } while (0);
   if (e != hipSuccess) { snprintf(err, errlen, "ntt tables: %s", hipGetErrorString(e)); return ZKHIP_ERR_HIP; }
@@ -251,57 +344,107 @@ static int get_tables(int log_d, int inverse, NttTables** out, char* err, size_t
   return ZKHIP_OK;
 }
 
-template <int LOGK>
-static void launch_tile(const TileArgs& a, uint32_t tiles, hipStream_t st) {
-  hipLaunchKernelGGL(k_ntt_tile<LOGK>, dim3(tiles), dim3(tile_threads(LOGK)), 0, st, a);
+template <int LOGK, int LOGC>
+static void launch_pass(const PassArgs& a, uint32_t groups, hipStream_t st) {
+  hipLaunchKernelGGL((k_ntt_pass<LOGK, LOGC>), dim3(groups), dim3(pass_threads(LOGK, LOGC)), 0, st, a);
 }
-static void launch_tile_dyn(int log_k, const TileArgs& a, uint32_t tiles, hipStream_t st) {
+// One workgroup per sub-transform up to 2^18 elements (the passes are latency-bound there: as many workgroups as possible);
+// beyond, 2048 elements per workgroup (adjacent sub-transforms: C * 48 contiguous bytes per row of the strided pass).
+static void launch_pass_dyn(int log_k, bool one_each, const PassArgs& a, uint32_t n_sub, hipStream_t st) {
+  if (one_each) {
+    switch (log_k) {
+      case 0: launch_pass<0, 0>(a, n_sub, st); break;
+      case 1: launch_pass<1, 0>(a, n_sub, st); break;
+      case 2: launch_pass<2, 0>(a, n_sub, st); break;
+      case 3: launch_pass<3, 0>(a, n_sub, st); break;
+      case 4: launch_pass<4, 0>(a, n_sub, st); break;
+      case 5: launch_pass<5, 0>(a, n_sub, st); break;
+      case 6: launch_pass<6, 0>(a, n_sub, st); break;
+      case 7: launch_pass<7, 0>(a, n_sub, st); break;
+      case 8: launch_pass<8, 0>(a, n_sub, st); break;
+      case 9: launch_pass<9, 0>(a, n_sub, st); break;
+      case 10: launch_pass<10, 0>(a, n_sub, st); break;
+      default: launch_pass<11, 0>(a, n_sub, st); break;
+    }
+    return;
+  }
   switch (log_k) {
-    case 0: launch_tile<0>(a, tiles, st); break;
-    case 1: launch_tile<1>(a, tiles, st); break;
-    case 2: launch_tile<2>(a, tiles, st); break;
-    case 3: launch_tile<3>(a, tiles, st); break;
-    case 4: launch_tile<4>(a, tiles, st); break;
-    case 5: launch_tile<5>(a, tiles, st); break;
-    case 6: launch_tile<6>(a, tiles, st); break;
-    case 7: launch_tile<7>(a, tiles, st); break;
-    case 8: launch_tile<8>(a, tiles, st); break;
-    case 9: launch_tile<9>(a, tiles, st); break;
-    case 10: launch_tile<10>(a, tiles, st); break;
-    default: launch_tile<11>(a, tiles, st); break;
+    case 9: launch_pass<9, 2>(a, n_sub >> 2, st); break;
+    case 10: launch_pass<10, 1>(a, n_sub >> 1, st); break;
+    default: launch_pass<11, 0>(a, n_sub, st); break;
   }
 }
 
-// Transform `d_data` (packed device form, 2^log_d elements) in place, using `d_tmp` (same size).
-int ntt_dev_packed(uint32_t* d_data, uint32_t* d_tmp, int log_d, int inverse, int coset, hipStream_t st, char* err, size_t errlen) {
+int ntt_layout_logk(int log_d) { return log_d <= 11 ? 0 : (log_d + 1) / 2; }
+
+// the inter-step twiddle table of one kind of transform, made on first use (on the caller's stream)
+static int get_mid_full(NttTables* t, int inverse, int coset, int in_transposed, hipStream_t st, uint32_t** out, char* err, size_t errlen) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  uint32_t*& m = t->mid_full[coset ? 1 : 0][in_transposed ? 1 : 0];
+  if (!m) {
+    const uint32_t d = 1u << t->log_d;
+    uint32_t* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)d * 48);
+    if (e != hipSuccess) { snprintf(err, errlen, "ntt tables: %s", hipGetErrorString(e)); return ZKHIP_ERR_HIP; }
+    // first pass: strided columns q (loc = q + k*N2) for natural input, contiguous rows q (loc = q*N2 + k) for transposed input
+    const uint32_t *ext_lo = nullptr, *ext_hi = nullptr;
+    uint32_t ext_q = 0, ext_k = 0;
+    if (!inverse && coset) { ext_lo = t->coset.lo; ext_hi = t->coset.hi; ext_q = 1; }             // g^q (the rest of g^i is in the stage twiddles)
+    if (inverse) { ext_lo = t->coset.lo; ext_hi = t->coset.hi; ext_k = coset ? 1 : 0; }           // g^-k / d, or 1/d alone
+    hipLaunchKernelGGL(k_mid_table, dim3((d + 255) / 256), dim3(256), 0, st, p, d, in_transposed ? 0u : 1u, (uint32_t)t->log_n2,
+                       t->mid.lo, t->mid.hi, ext_lo, ext_hi, ext_q, ext_k);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(p); snprintf(err, errlen, "ntt tables: %s", hipGetErrorString(e)); return ZKHIP_ERR_HIP; }
+    m = p;
+  }
+  *out = m;
+  return ZKHIP_OK;
+}
+
+// Transform `d_data` (packed device form, 2^log_d elements) in place.  Vectors of 2^12 elements and more are in natural order on
+// one side and in transposed order on the other (ntt_layout_logk): in_transposed says which side the input is.
+int ntt_dev_packed(uint32_t* d_data, int log_d, int inverse, int coset, int in_transposed, hipStream_t st, char* err, size_t errlen) {
   if (log_d < 0 || log_d > 22) { snprintf(err, errlen, "ntt: log_d must be in [0, 22]"); return ZKHIP_ERR_ARG; }
   NttTables* t;
   int rc = get_tables(log_d, inverse, &t, err, errlen);
   if (rc != ZKHIP_OK) return rc;
   const uint32_t K = 1u << t->log_k, N2 = 1u << t->log_n2;
-  TileArgs a;
+  PassArgs a;
   memset(&a, 0, sizeof a);
+  a.data = d_data;
   if (t->log_n2 == 0) {
-    // single tile: whole transform in LDS
-    a.src = d_data; a.dst = d_data; a.in_b = 0; a.in_j = 1; a.out_b = 0; a.out_j = 1; a.tw = t->twA;
-    if (!inverse && coset) { a.pre_lo = t->coset.lo; a.pre_hi = t->coset.hi; }
-    if (inverse && coset) { a.post_lo = t->coset.lo; a.post_hi = t->coset.hi; }
+    // one workgroup: the whole transform in LDS
+    a.strided = 0; a.tw = t->twA;
+    if (!inverse && coset) { a.tw = t->twA_coset; a.tw_scaled = 1; }
+    if (inverse && coset) a.post_k = t->post_k[0];
     if (inverse && !coset) a.post_const = t->inv_d;
-    launch_tile_dyn(t->log_k, a, 1, st);
+    launch_pass_dyn(t->log_k, true, a, 1, st);
   } else {
-    // pass A: columns c = tile index, elements c + N2*j; in place; inter-step twiddle omega^(c*k1)
-    a.src = d_data; a.dst = d_data; a.in_b = 1; a.in_j = N2; a.out_b = 1; a.out_j = N2; a.tw = t->twA;
-    a.mid_lo = t->mid.lo; a.mid_hi = t->mid.hi;
-    if (!inverse && coset) { a.pre_lo = t->coset.lo; a.pre_hi = t->coset.hi; }
-    launch_tile_dyn(t->log_k, a, N2, st);
-    // pass B: rows k1 = tile index, elements N2*k1 + c (contiguous); X[k1 + K*k2] -> tmp
-    memset(&a, 0, sizeof a);
-    a.src = d_data; a.dst = d_tmp; a.in_b = N2; a.in_j = 1; a.out_b = 1; a.out_j = K; a.tw = t->twB;
-    if (inverse && coset) { a.post_lo = t->coset.lo; a.post_hi = t->coset.hi; }
-    if (inverse && !coset) a.post_const = t->inv_d;
-    launch_tile_dyn(t->log_n2, a, K, st);
-    hipError_t e = hipMemcpyAsync(d_data, d_tmp, ((size_t)12 * 4) << log_d, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) { snprintf(err, errlen, "ntt: %s", hipGetErrorString(e)); return ZKHIP_ERR_HIP; }
+    if (!inverse && coset && in_transposed) { snprintf(err, errlen, "ntt: a forward coset transform takes its input in natural order"); return ZKHIP_ERR_ARG; }
+    uint32_t* mid = nullptr;
+    if ((rc = get_mid_full(t, inverse, coset, in_transposed, st, &mid, err, errlen)) != ZKHIP_OK) return rc;
+    a.mid = mid;
+    if (!in_transposed) {
+      // pass 1: columns c (elements c + N2*j), twiddle omega^(c*k1)
+      a.strided = 1; a.S = N2; a.tw = t->twA;
+      if (!inverse && coset) { a.tw = t->twA_coset; a.tw_scaled = 1; }
+      launch_pass_dyn(t->log_k, log_d <= 18, a, N2, st);
+      // pass 2: rows k1 (contiguous); output k2 is X[k1 + K*k2], left in the row
+      memset(&a, 0, sizeof a);
+      a.data = d_data; a.strided = 0; a.tw = t->twB;
+      if (inverse && coset) a.post_k = t->post_k[0];
+      launch_pass_dyn(t->log_n2, log_d <= 18, a, K, st);
+    } else {
+      // pass 1: rows i2 (element i1*K + i2 of the input lives at i2*N2 + i1), twiddle omega^(i2*k1')
+      a.strided = 0; a.tw = t->twB;
+      launch_pass_dyn(t->log_n2, log_d <= 18, a, K, st);
+      // pass 2: columns k1' (stride N2); output k2' is X[k1' + N2*k2'] at k2'*N2 + k1'
+      memset(&a, 0, sizeof a);
+      a.data = d_data; a.strided = 1; a.S = N2; a.tw = t->twA;
+      if (inverse && coset) a.post_k = t->post_k[1];
+      launch_pass_dyn(t->log_k, log_d <= 18, a, N2, st);
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(err, errlen, "ntt launch: %s", hipGetErrorString(e)); return ZKHIP_ERR_HIP; }
@@ -312,29 +455,25 @@ void fr_abi_to_dev(const uint64_t* d_in, uint32_t* d_out, size_t n, hipStream_t 
   if (n) hipLaunchKernelGGL(k_fr_abi_to_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, d_out, n);
 }
 void fr_dev_to_abi(const uint32_t* d_in, uint64_t* d_out, size_t n, hipStream_t st) {
-  if (n) hipLaunchKernelGGL(k_fr_dev_to_abi, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, d_out, n);
+  if (n) hipLaunchKernelGGL(k_fr_dev_to_abi, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, d_out, n, 0, 0);
 }
 
-// ABI-form device buffer (6 u64 per element), in place
+// ABI-form device buffer (6 u64 per element), in place, natural order on both sides
 int ntt_dev_abi(uint64_t* d_data, int log_d, int inverse, int coset, char* err, size_t errlen) {
   size_t d = (size_t)1 << log_d;
-  uint32_t *p = nullptr, *tmp = nullptr;
+  uint32_t* p = nullptr;
   int rc = ZKHIP_OK;
   hipError_t e;
-  if ((e = hipMalloc(&p, d * 48)) != hipSuccess || (e = hipMalloc(&tmp, d * 48)) != hipSuccess) {
-    snprintf(err, errlen, "ntt: %s", hipGetErrorString(e));
-    if (p) (void)hipFree(p);
-    return ZKHIP_ERR_HIP;
-  }
+  if ((e = hipMalloc(&p, d * 48)) != hipSuccess) { snprintf(err, errlen, "ntt: %s", hipGetErrorString(e)); return ZKHIP_ERR_HIP; }
   fr_abi_to_dev(d_data, p, d, 0);
-  rc = ntt_dev_packed(p, tmp, log_d, inverse, coset, 0, err, errlen);
+  rc = ntt_dev_packed(p, log_d, inverse, coset, 0, 0, err, errlen);
   if (rc == ZKHIP_OK) {
-    fr_dev_to_abi(p, d_data, d, 0);
+    const int lk = ntt_layout_logk(log_d);                 // the result is transposed: put back in order on the way out
+    hipLaunchKernelGGL(k_fr_dev_to_abi, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, 0, p, d_data, d, lk, lk ? log_d - lk : 0);
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { snprintf(err, errlen, "ntt: %s", hipGetErrorString(e)); rc = ZKHIP_ERR_HIP; }
   }
   (void)hipFree(p);
-  (void)hipFree(tmp);
   return rc;
 }
 

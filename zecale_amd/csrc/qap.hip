@@ -49,6 +49,7 @@ __device__ __forceinline__ FrD fr_shfl_down16(const FrD& v, int delta) {
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                const uint32_t* __restrict__ val, const uint32_t* __restrict__ z,
                                                uint32_t n, uint32_t extra /* n_primary + 1 for A, else 0 */, uint32_t d,
+                                               int log_k, int log_n2 /* log_k != 0: out in the NTT's transposed order */,
                                                uint32_t* __restrict__ out) {
   uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t i = gt >> 4, sub = gt & 15u;
@@ -69,7 +70,8 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_p
   } else if (i < n + extra) {
     acc = q_load12(z + (size_t)(i - n) * 12);
   }
-  if (sub == 0) q_store12(out + (size_t)i * 12, acc);
+  const size_t loc = log_k ? ((size_t)(i & ((1u << log_k) - 1)) << log_n2) + (i >> log_k) : i;
+  if (sub == 0) q_store12(out + loc * 12, acc);
 }
 
 // H[i] = (A[i] B[i] - C[i]) * zinv   (in place into A)
@@ -156,7 +158,7 @@ static int r1cs_upload_impl(const zkhip_r1cs_desc* d, R1csDev* r, char* err, siz
   if ((rc = csr_upload(d->b_row_ptr, d->b_col, d->b_val, d->n_constraints, &r->B, err, errlen)) != ZKHIP_OK) return rc;
   if ((rc = csr_upload(d->c_row_ptr, d->c_col, d->c_val, d->n_constraints, &r->C, err, errlen)) != ZKHIP_OK) return rc;
   Q_HIP(hipMalloc(&r->bufA, dd * 48)); Q_HIP(hipMalloc(&r->bufB, dd * 48)); Q_HIP(hipMalloc(&r->bufC, dd * 48));
-  Q_HIP(hipMalloc(&r->tmp, dd * 48)); Q_HIP(hipMalloc(&r->z, d->n_vars * 48));
+  Q_HIP(hipMalloc(&r->tmp, 256)); Q_HIP(hipMalloc(&r->z, d->n_vars * 48));     // tmp: the satisfiability flag
   // 1 / (g^d - 1): Z is constant on the coset g<omega>
   HFr g = HFr::from_limbs(FrParams::GEN64);
   uint64_t e[1] = {(uint64_t)dd};
@@ -177,12 +179,14 @@ void r1cs_free(R1csDev* r) {
   delete r;
 }
 
+// the three products, in the order the first transform wants (transposed for 2^12 rows and more, see ntt.h)
 static void spmv3(R1csDev* r, hipStream_t st) {
   uint32_t n = (uint32_t)r->n_constraints, d = 1u << r->log_d;
   unsigned nb = (unsigned)(((size_t)d * 16 + 255) / 256);
-  hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->A.row_ptr, r->A.col, r->A.val, r->z, n, (uint32_t)r->n_primary + 1, d, r->bufA);
-  hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->B.row_ptr, r->B.col, r->B.val, r->z, n, 0u, d, r->bufB);
-  hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->C.row_ptr, r->C.col, r->C.val, r->z, n, 0u, d, r->bufC);
+  const int lk = ntt_layout_logk(r->log_d), ln = lk ? r->log_d - lk : 0;
+  hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->A.row_ptr, r->A.col, r->A.val, r->z, n, (uint32_t)r->n_primary + 1, d, lk, ln, r->bufA);
+  hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->B.row_ptr, r->B.col, r->B.val, r->z, n, 0u, d, lk, ln, r->bufB);
+  hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->C.row_ptr, r->C.col, r->C.val, r->z, n, 0u, d, lk, ln, r->bufC);
 }
 
 int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, size_t errlen) {
@@ -193,11 +197,11 @@ int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, si
   int rc;
   uint32_t* bufs[3] = {r->bufA, r->bufB, r->bufC};
   for (int k = 0; k < 3; k++) {
-    if ((rc = ntt_dev_packed(bufs[k], r->tmp, lg, 1, 0, st, err, errlen)) != ZKHIP_OK) return rc;   // iFFT
-    if ((rc = ntt_dev_packed(bufs[k], r->tmp, lg, 0, 1, st, err, errlen)) != ZKHIP_OK) return rc;   // cosetFFT
+    if ((rc = ntt_dev_packed(bufs[k], lg, 1, 0, 1, st, err, errlen)) != ZKHIP_OK) return rc;   // iFFT: transposed -> natural
+    if ((rc = ntt_dev_packed(bufs[k], lg, 0, 1, 0, st, err, errlen)) != ZKHIP_OK) return rc;   // cosetFFT: natural -> transposed
   }
-  hipLaunchKernelGGL(k_h_pointwise, dim3((d + 255) / 256), dim3(256), 0, st, r->bufA, r->bufB, r->bufC, r->zinv, d);
-  if ((rc = ntt_dev_packed(r->bufA, r->tmp, lg, 1, 1, st, err, errlen)) != ZKHIP_OK) return rc;       // icosetFFT
+  hipLaunchKernelGGL(k_h_pointwise, dim3((d + 255) / 256), dim3(256), 0, st, r->bufA, r->bufB, r->bufC, r->zinv, d);   // (any order)
+  if ((rc = ntt_dev_packed(r->bufA, lg, 1, 1, 1, st, err, errlen)) != ZKHIP_OK) return rc;       // icosetFFT: transposed -> natural
   Q_HIP(hipGetLastError());
   return ZKHIP_OK;
 }
@@ -207,8 +211,9 @@ int r1cs_is_satisfied_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, i
   spmv3(r, st);
   uint32_t* flag = r->tmp;   // first word of the scratch buffer
   Q_HIP(hipMemsetAsync(flag, 0, 4, st));
-  uint32_t n = (uint32_t)r->n_constraints;
-  if (n) hipLaunchKernelGGL(k_check_sat, dim3((n + 255) / 256), dim3(256), 0, st, r->bufA, r->bufB, r->bufC, n, flag);
+  // every place of the three vectors (whatever their order): the rows past the constraints have B = C = 0
+  uint32_t n = 1u << r->log_d;
+  hipLaunchKernelGGL(k_check_sat, dim3((n + 255) / 256), dim3(256), 0, st, r->bufA, r->bufB, r->bufC, n, flag);
   uint32_t h = 0;
   Q_HIP(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, st));
   Q_HIP(hipStreamSynchronize(st));
