@@ -8,6 +8,7 @@
 // E : y^2 = x^3 + 1 over Fq;  E' : y^2 = x^3 + 1/u over Fq2 (D-twist);  psi(x', y') = (x' w^2, y' w^3).
 // Loop parameter u = 0x8508c00000000001 (r = u^4 - u^2 + 1).
 #pragma once
+#include <array>
 #include "tower.hpp"
 
 namespace zkhip {
@@ -174,15 +175,112 @@ template <class F> struct NestedProof { G1<F> a; G2<F> b; G1<F> c; };
 
 template <class F> inline G2<F> g2_neg(const G2<F>& p) { return G2<F>{p.x, p.y.neg()}; }
 
+#ifdef ZK_CIRCUIT_FR
+// The recorded witness program (witness_tape.cpp) must not contain the accumulator's chain of 2 x 253 dependent inversions - an
+// inversion costs a GPU lane what thirty multiplications do and a level of the program waits for it.  The denominators of the
+// slopes are therefore derived from a Jacobian run of the same two chains (the doublings pw_j = 2^j ABC_k, the conditional
+// additions acc_j), where nothing is inverted:
+//   x(pw_j) - x(acc_j) = H_j / (Za Zp)^2      so  1 / (...) = (Za Zp)^3 / Zs_j       (Zs_j = Za Zp H_j, the Z of the Jacobian sum)
+//   2 y(pw_j)          = 2 Yp / Zp^3          so  1 / (...) = Zp^4 / Zp_{j+1}        (Zp_{j+1} = 2 Yp Zp, the Z of the double)
+// and every Zs_j, Zp_{j+1} of the accumulator is inverted in ONE inversion (a product tree).  The same field elements as the
+// affine chain of the host generator computes, by another route.
+struct JacH { HFr X, Y, Z; };
+inline JacH jac_dbl(const JacH& p) {                       // y^2 = x^3 + b
+  HFr A = p.X * p.X, B = p.Y * p.Y, C = B * B;
+  HFr t = p.X + B;
+  HFr D = t * t - A - C; D = D + D;
+  HFr E = A + A + A, F = E * E;
+  JacH r;
+  r.X = F - (D + D);
+  HFr C8 = C + C; C8 = C8 + C8; C8 = C8 + C8;
+  r.Y = E * (D - r.X) - C8;
+  HFr yz = p.Y * p.Z;
+  r.Z = yz + yz;
+  return r;
+}
+inline JacH jac_add(const JacH& p, const JacH& q) {        // p != +-q (else Z = 0: the inversion below meets zero and says so)
+  HFr z1z1 = p.Z * p.Z, z2z2 = q.Z * q.Z;
+  HFr U1 = p.X * z2z2, U2 = q.X * z1z1;
+  HFr S1 = p.Y * (q.Z * z2z2), S2 = q.Y * (p.Z * z1z1);
+  HFr H = U2 - U1, R = S2 - S1;
+  HFr HH = H * H, HHH = H * HH, V = U1 * HH;
+  JacH r;
+  r.X = R * R - HHH - (V + V);
+  r.Y = R * (V - r.X) - S1 * HHH;
+  r.Z = (p.Z * q.Z) * H;
+  return r;
+}
+inline void batch_inv_tree(std::vector<HFr>& v) {          // none of them zero
+  std::vector<std::vector<HFr>> lv;
+  lv.push_back(v);
+  while (lv.back().size() > 1) {
+    const std::vector<HFr>& c = lv.back();
+    std::vector<HFr> n;
+    for (size_t i = 0; i + 1 < c.size(); i += 2) n.push_back(c[i] * c[i + 1]);
+    if (c.size() & 1) n.push_back(c.back());
+    lv.push_back(std::move(n));
+  }
+  std::vector<HFr> inv = {lv.back()[0].inv()};
+  for (size_t L = lv.size() - 1; L-- > 0;) {
+    const std::vector<HFr>& c = lv[L];
+    std::vector<HFr> ni(c.size());
+    for (size_t i = 0; i + 1 < c.size(); i += 2) { ni[i] = inv[i / 2] * c[i + 1]; ni[i + 1] = inv[i / 2] * c[i]; }
+    if (c.size() & 1) ni[c.size() - 1] = inv[c.size() / 2];
+    inv.swap(ni);
+  }
+  v.swap(inv);
+}
+// dinv[k][j] = {1 / (x(pw) - x(acc)), 1 / (2 y(pw))} at step j of input k
+template <class F> inline std::vector<std::vector<std::array<HFr, 2>>> accumulator_denominators(const NestedVk<F>& vk, const std::vector<std::vector<F>>& input_bits) {
+  std::vector<std::vector<std::array<HFr, 2>>> out(input_bits.size());
+  std::vector<HFr> zs, num;                                 // the Z to invert and what its inverse is multiplied by, in step order
+  JacH acc{vk.abc[0].x.value(), vk.abc[0].y.value(), HFr::one()};
+  for (size_t k = 0; k < input_bits.size(); k++) {
+    JacH pw{vk.abc[k + 1].x.value(), vk.abc[k + 1].y.value(), HFr::one()};
+    for (size_t j = 0; j < input_bits[k].size(); j++) {
+      const bool more = j + 1 < input_bits[k].size();
+      JacH s = jac_add(acc, pw);
+      HFr zz = acc.Z * pw.Z;
+      zs.push_back(s.Z); num.push_back(zz * zz * zz);
+      const HFr b = input_bits[k][j].value();
+      acc = JacH{acc.X + b * (s.X - acc.X), acc.Y + b * (s.Y - acc.Y), acc.Z + b * (s.Z - acc.Z)};
+      if (more) {
+        JacH d = jac_dbl(pw);
+        HFr z2 = pw.Z * pw.Z;
+        zs.push_back(d.Z); num.push_back(z2 * z2);
+        pw = d;
+      }
+    }
+  }
+  batch_inv_tree(zs);
+  size_t at = 0;
+  for (size_t k = 0; k < input_bits.size(); k++) {
+    out[k].resize(input_bits[k].size());
+    for (size_t j = 0; j < input_bits[k].size(); j++) {
+      out[k][j][0] = num[at] * zs[at]; at++;
+      if (j + 1 < input_bits[k].size()) { out[k][j][1] = num[at] * zs[at]; at++; }
+    }
+  }
+  return out;
+}
+#endif
+
 // acc = ABC_0 + sum_j bits_j (2^j ABC_1) ...: one input, bits little-endian
 template <class F> inline G1<F> input_accumulator(const NestedVk<F>& vk, const std::vector<std::vector<F>>& input_bits) {
+#ifdef ZK_CIRCUIT_FR
+  const auto den = accumulator_denominators(vk, input_bits);
+#endif
   G1<F> acc = vk.abc[0];
   for (size_t k = 0; k < input_bits.size(); k++) {
     G1<F> pw = vk.abc[k + 1];
     for (size_t j = 0; j < input_bits[k].size(); j++) {
       const bool more = j + 1 < input_bits[k].size();
+#ifdef ZK_CIRCUIT_FR
+      HFr dinv[2] = {den[k][j][0], den[k][j][1]};
+#else
       HFr dinv[2] = {(pw.x - acc.x).value(), (pw.y + pw.y).value()};      // denominators of the addition and of the doubling
       batch_inv(dinv, more ? 2 : 1);
+#endif
       G1<F> s = g1_add(acc, pw, &dinv[0]);
       acc = g1_select(input_bits[k][j], s, acc);
       if (more) pw = g1_dbl(pw, &dinv[1]);

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "bw6_params.h"
+#include "fp_inv.cuh"
 
 namespace zkhip {
 namespace host {
@@ -106,34 +107,15 @@ struct HF {
     e[0] -= 2;  // p odd and p0 >= 2
     return pow_limbs(e, N);
   }
-  // Inverse by the binary extended Euclidean algorithm on the limbs (about 8x faster than Fermat; the wrapping
-  // circuit's witness needs ~1500 inversions per proof).  Input aR -> output a^-1 R.  0 -> 0.
+  // Inverse by Bernstein-Yang division steps (fp_inv.cuh, the routine the device uses, compiled for the host): 4.7 us for Fr
+  // against 18 us for a binary extended Euclid on the limbs and 60 us for Fermat - the wrapping circuit's witness needs
+  // hundreds of inversions per proof.  Input aR -> output a^-1 R.  0 -> 0.
   HF inv() const {
     if (is_zero()) return zero();
-    // invariants: x1 * a_int = u (mod p), x2 * a_int = w (mod p), where a_int = aR is the stored integer
-    uint64_t u[N], w[N], x1[N], x2[N];
-    memcpy(u, v, sizeof u);
-    memcpy(w, PR::P64, sizeof w);
-    memset(x1, 0, sizeof x1); x1[0] = 1;
-    memset(x2, 0, sizeof x2);
-    auto is_one = [](const uint64_t* a) { if (a[0] != 1) return false; for (int i = 1; i < N; i++) if (a[i]) return false; return true; };
-    auto shr1 = [](uint64_t* a, uint64_t top) { for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 63); a[N - 1] = (a[N - 1] >> 1) | (top << 63); };
-    auto add_p = [](uint64_t* a) { uint64_t c = 0; for (int i = 0; i < N; i++) { u128 t = (u128)a[i] + PR::P64[i] + c; a[i] = (uint64_t)t; c = (uint64_t)(t >> 64); } return c; };
-    auto sub = [](uint64_t* a, const uint64_t* b) { uint64_t br = 0; for (int i = 0; i < N; i++) { u128 t = (u128)a[i] - b[i] - br; a[i] = (uint64_t)t; br = (uint64_t)(t >> 64) & 1; } return br; };
-    auto geq = [](const uint64_t* a, const uint64_t* b) { for (int i = N - 1; i >= 0; i--) { if (a[i] > b[i]) return true; if (a[i] < b[i]) return false; } return true; };
-    auto halve_mod = [&](uint64_t* x) { uint64_t top = 0; if (x[0] & 1) top = add_p(x); shr1(x, top); };
-    while (!is_one(u) && !is_one(w)) {
-      while (!(u[0] & 1)) { shr1(u, 0); halve_mod(x1); }
-      while (!(w[0] & 1)) { shr1(w, 0); halve_mod(x2); }
-      if (geq(u, w)) { sub(u, w); if (sub(x1, x2)) add_p(x1); }
-      else { sub(w, u); if (sub(x2, x1)) add_p(x2); }
-    }
-    HF r = from_limbs(is_one(u) ? x1 : x2);        // = (aR)^-1 as an integer mod p
-    // (aR)^-1 = a^-1 R^-1  ->  a^-1 R : multiply by R^2 (one Montgomery product with R^3)
-    HF r2, r3;
-    for (int i = 0; i < N; i++) r2.v[i] = PR::R2_64[i];
-    r3 = r2 * r2;                                   // R^2 * R^2 / R = R^3
-    return r * r3;                                  // a^-1 R^-1 * R^3 / R = a^-1 R
+    uint64_t l[N], o[N];
+    to_limbs(l);
+    fp_to_abi<PR>(fp_inv<PR>(fp_from_abi<PR>(l)), o);
+    return from_limbs(o);
   }
 };
 

@@ -85,53 +85,92 @@ __device__ __forceinline__ bool w_exec(uint32_t c, int32_t rb, const FrD& x, con
   return bad;
 }
 
-// levels [l0, l1) of the levelled program.  (A witness is cut into several launches of a few milliseconds so that the kernels of
-// the provers that share a hardware queue with it are not held up for its whole duration.)
-// Most levels hold a handful of instructions that read what the previous few levels wrote: a round trip through global memory per
-// level would be most of the level.  Every result therefore also goes into an LDS ring (slot = position mod WIT_RING; positions
-// are level-major, so the ring holds the last ~30 narrow levels) and an operand younger than the ring is read from there.
+// Chunks [c0, c1) of the levelled program, a chunk being 64 consecutive positions (a level is padded to whole chunks, so a chunk
+// never straddles two levels and running the chunks in order respects every dependency).  ONE WAVE PER BATCH: a level of this
+// program holds fifteen multiplications on average - there is nothing for a second wave to do, and with one wave there is no
+// barrier and no waiting for stores between levels.  What a level costs is then the latency of its operands, and the
+// program being static, almost all of it is taken off the critical path:
+//   * the instruction words are fetched three chunks ahead;
+//   * the last 2,048 results wait in an LDS ring (slot = position mod 2,048: the last 32 chunks) - nine operands in ten;
+//   * an older operand is loaded from the value array one chunk ahead (its store is tens of chunks old).
+// (A witness is cut into several launches of a few milliseconds so that the kernels of the provers that share a hardware queue
+// with it are not held up for its whole duration.)
+struct WIns { uint32_t code; int32_t a, b; };
+__device__ __forceinline__ WIns w_fetch(const WitnessProg& P, uint32_t chunk, uint32_t n_chunks, uint32_t lane) {
+  WIns r{(uint32_t)WT_NOP, 0, 0};
+  if (chunk < n_chunks) {
+    const uint32_t p = chunk * 64 + lane;
+    r.code = P.code[p]; r.a = P.a[p]; r.b = P.b[p];
+  }
+  return r;
+}
+__device__ __forceinline__ bool w_binary(uint32_t c) { return c == WT_ADD || c == WT_SUB || c == WT_MUL; }
+// issue the loads of the operands of `in` that are complete in memory (constants; positions below lim)
+__device__ __forceinline__ void w_prefetch(const WitnessProg& P, const uint32_t* __restrict__ vals, const WIns& in, uint32_t lim, uint4 (&px)[3], uint4 (&py)[3]) {
+  if (in.code == WT_NOP || in.code == WT_INPUT) return;
+  if (in.a < 0 || (uint32_t)in.a < lim) {
+    const uint4* q = reinterpret_cast<const uint4*>(in.a < 0 ? P.consts + (size_t)(-1 - in.a) * 12 : vals + (size_t)in.a * 12);
+    px[0] = q[0]; px[1] = q[1]; px[2] = q[2];
+  }
+  if (w_binary(in.code) && (in.b < 0 || (uint32_t)in.b < lim)) {
+    const uint4* q = reinterpret_cast<const uint4*>(in.b < 0 ? P.consts + (size_t)(-1 - in.b) * 12 : vals + (size_t)in.b * 12);
+    py[0] = q[0]; py[1] = q[1]; py[2] = q[2];
+  }
+}
+__device__ __forceinline__ FrD w_from3(const uint4 (&v)[3]) {
+  uint32_t w[12] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w};
+  return fp_unpack32<FrParams>(w);
+}
+
 constexpr uint32_t WIT_RING = 2048;      // 96 KiB of the CU's 160
-__global__ void __launch_bounds__(256) k_witness(WitnessProg P, uint32_t l0, uint32_t l1, const uint64_t* __restrict__ inputs /* batches x n_inputs x 6, ABI */,
-                                                  uint32_t* __restrict__ values /* batches x n_pos x 12 */, uint32_t* __restrict__ flags) {
+__global__ void __launch_bounds__(64) k_witness(WitnessProg P, uint32_t c0, uint32_t c1, const uint64_t* __restrict__ inputs /* batches x n_inputs x 6, ABI */,
+                                                 uint32_t* __restrict__ values /* batches x n_pos x 12 */, uint32_t* __restrict__ flags) {
   __shared__ uint4 ring[WIT_RING * 3];
-  const uint32_t batch = blockIdx.x, tid = threadIdx.x;
+  const uint32_t batch = blockIdx.x, lane = threadIdx.x;
   const uint64_t* in = inputs + (size_t)batch * P.n_inputs * 6;
   uint32_t* vals = values + (size_t)batch * P.n_pos * 12;
   uint32_t bad = 0;
-  auto load = [&](int32_t ref, uint32_t ring_lo) -> FrD {
-    if (ref < 0) return w_load12(P.consts + (size_t)(-1 - ref) * 12);
-    if ((uint32_t)ref >= ring_lo) {                      // young enough to be in the ring (and not yet overwritten by this level)
-      const uint4* q = &ring[((uint32_t)ref % WIT_RING) * 3];
-      uint4 x = q[0], y = q[1], z = q[2];
-      uint32_t w[12] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w, z.x, z.y, z.z, z.w};
-      return fp_unpack32<FrParams>(w);
-    }
-    return w_load12(vals + (size_t)ref * 12);
-  };
-  uint32_t first_written = P.level_start[l0];             // this launch has written positions [first_written, ...) into its ring
-#pragma unroll 1
-  for (uint32_t l = l0; l < l1; l++) {
-    const uint32_t p0 = P.level_start[l], p1 = P.level_start[l + 1];
-    // readable from the ring: written by this launch, and not overwritten by anything this level writes (positions < p1)
-    const uint32_t ring_lo = max(first_written, p1 > WIT_RING ? p1 - WIT_RING : 0u);
-#pragma unroll 1
-    for (uint32_t p = p0 + tid; p < p1; p += 256) {
-      const uint32_t c = P.code[p];
-      if (c == WT_NOP) continue;
-      const int32_t ra = P.a[p], rb = P.b[p];
+  // one chunk: `cur` with its prefetched operands (cx, cy); `nxt` is the chunk after it, whose operands are requested here
+  auto step = [&](uint32_t j, const WIns& cur, uint4 (&cx)[3], uint4 (&cy)[3], const WIns& nxt, uint4 (&nx)[3], uint4 (&ny)[3]) {
+    // chunk i finds in the ring what this launch wrote and chunk i itself does not overwrite: positions from ring_lo(i) on
+    auto ring_lo = [&](uint32_t i) { const uint32_t w = (i + 1) * 64; return max(c0 * 64, w > WIT_RING ? w - WIT_RING : 0u); };
+    w_prefetch(P, vals, nxt, ring_lo(j + 1), nx, ny);
+    const uint32_t lim = ring_lo(j);
+    const uint32_t c = cur.code;
+    if (c != WT_NOP) {
       FrD x = fp_zero<FrParams>(), y = x, r = x;
-      if (c != WT_INPUT) x = load(ra, ring_lo);
-      if (c == WT_ADD || c == WT_SUB || c == WT_MUL) y = load(rb, ring_lo);
-      if (w_exec(c, rb, x, y, in, ra, r)) bad = 1;
+      if (c != WT_INPUT) {
+        if (cur.a < 0 || (uint32_t)cur.a < lim) x = w_from3(cx);
+        else { const uint4* q = &ring[((uint32_t)cur.a % WIT_RING) * 3]; uint4 t[3] = {q[0], q[1], q[2]}; x = w_from3(t); }
+        if (w_binary(c)) {
+          if (cur.b < 0 || (uint32_t)cur.b < lim) y = w_from3(cy);
+          else { const uint4* q = &ring[((uint32_t)cur.b % WIT_RING) * 3]; uint4 t[3] = {q[0], q[1], q[2]}; y = w_from3(t); }
+        }
+      }
+      if (w_exec(c, cur.b, x, y, in, cur.a, r)) bad = 1;
       uint32_t w[12];
       fp_pack32<FrParams>(r, w);
-      uint4* g = reinterpret_cast<uint4*>(vals + (size_t)p * 12);
-      uint4* q = &ring[(p % WIT_RING) * 3];
       const uint4 v0 = make_uint4(w[0], w[1], w[2], w[3]), v1 = make_uint4(w[4], w[5], w[6], w[7]), v2 = make_uint4(w[8], w[9], w[10], w[11]);
+      uint4* g = reinterpret_cast<uint4*>(vals + ((size_t)j * 64 + lane) * 12);
       g[0] = v0; g[1] = v1; g[2] = v2;
+      uint4* q = &ring[((j * 64 + lane) % WIT_RING) * 3];
       q[0] = v0; q[1] = v1; q[2] = v2;
     }
-    __syncthreads();
+    // the ring: this chunk's reads above come before its writes in program order, the next chunk's reads after them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const uint32_t n_chunks = c1;
+  WIns i0 = w_fetch(P, c0, n_chunks, lane), i1 = w_fetch(P, c0 + 1, n_chunks, lane), i2 = w_fetch(P, c0 + 2, n_chunks, lane), i3 = w_fetch(P, c0 + 3, n_chunks, lane);
+  uint4 ax[3], ay[3], bx[3], by[3];
+  for (int k = 0; k < 3; k++) ax[k] = ay[k] = bx[k] = by[k] = make_uint4(0, 0, 0, 0);
+  w_prefetch(P, vals, i0, c0 * 64, ax, ay);                            // everything before this launch is in memory (ring_lo(c0))
+#pragma unroll 1
+  for (uint32_t j = c0; j < c1; j += 2) {
+    const WIns n4 = w_fetch(P, j + 4, n_chunks, lane), n5 = w_fetch(P, j + 5, n_chunks, lane);
+    step(j, i0, ax, ay, i1, bx, by);
+    if (j + 1 < c1) step(j + 1, i1, bx, by, i2, ax, ay);
+    i0 = i2; i1 = i3; i2 = n4; i3 = n5;
   }
   if (bad) atomicOr(&flags[batch], 1u);
 }
@@ -283,9 +322,9 @@ void witness_launch(const WitnessProg& P, const uint64_t* d_inputs, uint32_t* d_
   (void)hipStreamWaitEvent(st_chain, ev_fork, 0);
   if (P.chain_start < P.n_pos) hipLaunchKernelGGL(k_witness_chain, dim3(batches), dim3(64), 0, st_chain, P, P.chain_start, d_inputs, d_values, d_flags);
   (void)hipEventRecord(ev_join, st_chain);
-  const uint32_t seg = 1536;       // levels per launch: a few milliseconds
-  for (uint32_t l0 = 0; l0 < P.n_levels; l0 += seg)
-    hipLaunchKernelGGL(k_witness, dim3(batches), dim3(256), 0, st, P, l0, (l0 + seg < P.n_levels ? l0 + seg : P.n_levels), d_inputs, d_values, d_flags);
+  const uint32_t n_chunks = P.chain_start / 64, seg = 2048;       // chunks per launch: a few milliseconds
+  for (uint32_t c0 = 0; c0 < n_chunks; c0 += seg)
+    hipLaunchKernelGGL(k_witness, dim3(batches), dim3(64), 0, st, P, c0, (c0 + seg < n_chunks ? c0 + seg : n_chunks), d_inputs, d_values, d_flags);
   (void)hipStreamWaitEvent(st, ev_join, 0);
   hipLaunchKernelGGL(k_witness_out, dim3((P.n_vars + 255) / 256, batches), dim3(256), 0, st, P, d_values, d_z);
 }

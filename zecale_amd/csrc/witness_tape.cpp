@@ -248,19 +248,57 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
     // round trip through memory for ONE instruction.  It depends on the inputs only and nothing but the assignment reads it, so it
     // becomes a program of its own, run in recorded order by a single wave next to the levelled rest (k_witness_chain).
     auto in_chain = [&](size_t i) { return i >= h0 && i < h1; };
-    // levels
+    // Levels.  ONE wave runs the levelled program, a chunk of 64 instructions at a time (witness.hip), so a level costs what its
+    // dearest instruction costs: ~0.2 us if it only adds, ~2 us if it multiplies, ~45 us if it inverts - and as-soon-as-possible
+    // levels mix the three in almost every level (8,100 of 9,700 levels held a multiplication, the longest path has 3,200).  The
+    // levels are therefore built by KIND: as long as an addition / subtraction / input is ready, a level of those; else all the
+    // multiplications that are ready; else all the inversions.  Every multiplication then sits in the level of its multiplication
+    // depth and every inversion in that of its inversion depth - the fewest dear levels any order of execution can have.
+    auto klass = [](uint8_t c) { return (c == WT_INV || c == WT_INV0) ? 2 : (c == WT_MUL || c == WT_BIT) ? 1 : 0; };
     std::vector<int32_t> level(n_ops, 0);
     int32_t max_level = 0;
-    for (size_t i = 0; i < n_ops; i++) {
-      if (!live[i] || in_chain(i)) continue;
-      const auto& op = R.ops[i];
-      int32_t l = 0;
-      if (op.code != WT_INPUT) {
-        if (op.a >= 0) l = std::max(l, level[op.a] + 1);
-        if ((op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) && op.b >= 0) l = std::max(l, level[op.b] + 1);
+    {
+      std::vector<uint32_t> pending(n_ops, 0), succ_off(n_ops + 1, 0), succ;
+      auto deps = [&](size_t i, int32_t (&d)[2]) {
+        const auto& op = R.ops[i];
+        d[0] = d[1] = -1;
+        if (op.code == WT_INPUT) return;
+        if (op.a >= 0) d[0] = op.a;
+        if ((op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) && op.b >= 0 && op.b != op.a) d[1] = op.b;
+      };
+      for (size_t i = 0; i < n_ops; i++) {
+        if (!live[i] || in_chain(i)) continue;
+        int32_t d[2];
+        deps(i, d);
+        for (int32_t x : d) if (x >= 0) { pending[i]++; succ_off[(size_t)x + 1]++; }
       }
-      level[i] = l;
-      max_level = std::max(max_level, l);
+      for (size_t i = 0; i < n_ops; i++) succ_off[i + 1] += succ_off[i];
+      succ.resize(succ_off[n_ops]);
+      {
+        std::vector<uint32_t> fill(succ_off.begin(), succ_off.end() - 1);
+        for (size_t i = 0; i < n_ops; i++) {
+          if (!live[i] || in_chain(i)) continue;
+          int32_t d[2];
+          deps(i, d);
+          for (int32_t x : d) if (x >= 0) succ[fill[x]++] = (uint32_t)i;
+        }
+      }
+      std::vector<uint32_t> ready[3], firing;
+      for (size_t i = 0; i < n_ops; i++) if (live[i] && !in_chain(i) && pending[i] == 0) ready[klass(R.ops[i].code)].push_back((uint32_t)i);
+      int32_t l = 0;
+      for (;;) {
+        const int k = !ready[0].empty() ? 0 : !ready[1].empty() ? 1 : !ready[2].empty() ? 2 : -1;
+        if (k < 0) break;
+        firing.swap(ready[k]);
+        ready[k].clear();
+        for (uint32_t i : firing) level[i] = l;
+        for (uint32_t i : firing)
+          for (uint32_t e = succ_off[i]; e < succ_off[i + 1]; e++) {
+            const uint32_t j = succ[e];
+            if (--pending[j] == 0) ready[klass(R.ops[j].code)].push_back(j);
+          }
+        max_level = l++;
+      }
     }
     // layout: by level, inside a level by kind (inversions first, then multiplications, then the cheap ones)
     auto kind_rank = [](uint8_t c) { return (c == WT_INV || c == WT_INV0) ? 0 : c == WT_MUL ? 1 : c == WT_INPUT ? 2 : c == WT_BIT ? 3 : 4; };
