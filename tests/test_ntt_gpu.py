@@ -16,7 +16,7 @@ def test_golden_vectors(zk):
             assert fr_ints(zk.ntt(a, v["log_d"], inverse=inv, coset=coset)) == [h2i(x) for x in v[key]], (v["log_d"], key)
 
 
-@pytest.mark.parametrize("log_d", [0, 2, 6, 10, 11, 12, 13, 15])
+@pytest.mark.parametrize("log_d", [0, 1, 2, 3, 6, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19])
 def test_vs_oracle(zk, oracle_lib, log_d):
     O = oracle_lib
     a = random_fr_canonical(300 + log_d, 1 << log_d)    # canonical words < 2^376 < r: valid Montgomery residues
@@ -33,11 +33,15 @@ def test_full_size_round_trip_and_oracle(zk, oracle_lib):
     c = zk.ntt(a, log_d, coset=True)
     assert (zk.ntt(c, log_d, inverse=True, coset=True) == a).all()
     assert (f == oracle_lib.ntt(a, log_d)).all()
-    # linearity: FFT(a + b) = FFT(a) + FFT(b) on a few entries
-    b = random_fr_canonical(78, 1 << log_d)
-    O = oracle_lib
-    s = np.array([O.f_op("add", 1, a[i], b[i]) for i in range(1 << 8)])
-    assert True  # (sum checked implicitly by the oracle comparison above)
+
+
+def test_log_d_21(zk, oracle_lib):
+    """an odd size above 2^18 (2^11 x 2^10: unequal factors, two row transforms per workgroup): round trip and the oracle"""
+    log_d = 21
+    a = random_fr_canonical(80, 1 << log_d)
+    f = zk.ntt(a, log_d, inverse=True, coset=True)
+    assert (f == oracle_lib.ntt(a, log_d, inverse=True, coset=True)).all()
+    assert (zk.ntt(f, log_d, coset=True) == a).all()
 
 
 def test_log_d_22(zk):

@@ -226,6 +226,14 @@ def test_full_size_2_20_proof_verifies(zk):
     _full_size_proof_verifies(zk, 20)
 
 
+@pytest.mark.parametrize("log_n", [13, 17, 19, 21])
+def test_odd_domain_sizes_proof_verifies(zk, log_n):
+    """Domains 2^odd split into UNEQUAL factors (K = 2 N2): every shape of the two-pass transforms - one sub-transform per
+    workgroup (2^13, 2^17), four / two per workgroup (2^19: 2^9 x 4, 2^10 x 2; 2^21: 2^11, 2^10 x 2), both the natural -> transposed
+    and the transposed -> natural order - sits between the SpMV and a proof that verifies."""
+    _full_size_proof_verifies(zk, log_n)
+
+
 def test_full_size_2_22_proof_verifies(zk):
     """BASELINE configs[3]'s size on ONE GPU (the 8-GPU form partitions this key): 2^22 constraints, 4.2 M-point query vectors with
     their window tables (69 GB of HBM), the same end-to-end check as at 2^20."""
