@@ -1,6 +1,6 @@
 """Soak run of the streaming prover on the GPU box: N batches with varying nested proofs, inputs (some bumped -> invalid nested
 proof -> result bit 0) and (r, s); every wrapping proof is verified with the host pairing verifier and its public inputs checked.
-Usage: python tools/soak_pipeline.py [N]"""
+Usage: python tools/soak_pipeline.py [N] [gpu]      ("gpu": the assignments are generated on the GPU)"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +18,8 @@ _, _, _, trapdoor = bench.aggregator_inputs()
 agg = zkhip.AggregatorCircuit(2, 1)
 kp = zkhip.Keypair(zkhip.r1cs_desc_from_aggregator(agg), *trapdoor)
 vk, crs = kp.vk(), kp.upload_crs()
-pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=6, witness_workers=8)
+GPU_WITNESS = "gpu" in sys.argv[2:]
+pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=6, witness_workers=2 if GPU_WITNESS else 8, gpu_witness=GPU_WITNESS)
 rng = np.random.default_rng(1)
 rs = bench.random_fr_canonical(77, 2 * N)
 jobs, bad, t0 = [], 0, time.time()
@@ -35,7 +36,7 @@ for i in range(N):
         else:
             expect |= 1 << p
     jobs.append((pipe.submit(nvk, np.concatenate([txs[a][1], txs[b][1]]), nin, rs[2 * i], rs[2 * i + 1]), expect, nin))
-    if len(jobs) > 32:
+    if len(jobs) > (96 if GPU_WITNESS else 32):
         t, exp, nin_ = jobs.pop(0)
         prim, proof = pipe.wait(t)
         ok = zkhip.groth16_verify(vk, prim, proof) and int(E.fr_to_json(prim[1]), 16) == exp and (prim[2:] == nin_.reshape(-1, 6)).all()
@@ -46,6 +47,6 @@ while jobs:
     ok = zkhip.groth16_verify(vk, prim, proof) and int(E.fr_to_json(prim[1]), 16) == exp and (prim[2:] == nin_.reshape(-1, 6)).all()
     bad += 0 if ok else 1
 dt = time.time() - t0
-print(f"soak: {N} wrapping proofs in {dt:.1f} s ({N/dt:.1f} proofs/s including host verification of each), failures: {bad}")
+print(f"soak ({'GPU' if GPU_WITNESS else 'host'} witness): {N} wrapping proofs in {dt:.1f} s ({N/dt:.1f} proofs/s including host verification of each), failures: {bad}")
 pipe.free(); crs.free(); kp.free(); agg.free()
 sys.exit(1 if bad else 0)
