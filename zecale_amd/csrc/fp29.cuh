@@ -161,6 +161,32 @@ ZK_HD ZK_INL Fp<PR> fp_sub(const Fp<PR>& a, const Fp<PR>& b) {
   return r;
 }
 
+// K * p with every limb but the top raised by 2^29 at its upper neighbour's expense (same number): a_i + d_i - b_i never goes
+// below zero for normalised a_i, b_i.  Any K with K p < 2^(29 NL) (the generated SUBK2..16 of the parameter file are this for K <= 16).
+template <class PR, int K>
+struct SubSafeKP {
+  uint32_t l[PR::NL];
+  constexpr SubSafeKP() : l{} {
+    uint64_t c = 0;
+    for (int i = 0; i < PR::NL; i++) {
+      c += (uint64_t)PR::P[i] * K;
+      l[i] = (i + 1 < PR::NL) ? (uint32_t)(c & M29) : (uint32_t)c;
+      c >>= 29;
+    }
+    for (int i = 0; i + 1 < PR::NL; i++) { l[i] += 1u << 29; l[i + 1] -= 1u; }
+  }
+};
+// r = a - b + K*p, requires b <= K*p; bound(r) = bound(a) + K
+template <class PR, int K>
+ZK_HD ZK_INL Fp<PR> fp_sub_k(const Fp<PR>& a, const Fp<PR>& b) {
+  constexpr SubSafeKP<PR, K> kp{};
+  Fp<PR> r;
+#pragma unroll
+  for (int i = 0; i < PR::NL; i++) r.l[i] = a.l[i] + kp.l[i] - b.l[i];
+  fp_normalise(r);
+  return r;
+}
+
 template <class PR>
 ZK_HD ZK_INL Fp<PR> fp_const(const uint32_t (&c)[PR::NL]) {
   Fp<PR> r;

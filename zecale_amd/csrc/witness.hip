@@ -27,36 +27,67 @@ namespace zkhip {
 
 typedef Fp<FrParams> FrD;
 
-__device__ __forceinline__ FrD w_load12(const uint32_t* p) {
-  uint32_t w[12];
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 x = q[0], y = q[1], z = q[2];
-  w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; w[4] = y.x; w[5] = y.y; w[6] = y.z; w[7] = y.w;
-  w[8] = z.x; w[9] = z.y; w[10] = z.z; w[11] = z.w;
-  return fp_unpack32<FrParams>(w);
+// A value slot: the 14 limbs of the device form as they are (no packing: an addition is then 14 adds and a carry pass), padded
+// to 16 words = 64 bytes.  Values are LAZILY reduced: the tape builder tracks an upper bound (a multiple of r) for every value,
+// picks the subtraction's K r accordingly and inserts a reduction where a bound would pass 256 r (witness_tape.cpp).
+constexpr int WSLOT = 16;
+struct WVal { uint4 q[4]; };
+__device__ __forceinline__ FrD w_from(const WVal& v) {
+  FrD r;
+  r.l[0] = v.q[0].x; r.l[1] = v.q[0].y; r.l[2] = v.q[0].z; r.l[3] = v.q[0].w; r.l[4] = v.q[1].x; r.l[5] = v.q[1].y; r.l[6] = v.q[1].z;
+  r.l[7] = v.q[1].w; r.l[8] = v.q[2].x; r.l[9] = v.q[2].y; r.l[10] = v.q[2].z; r.l[11] = v.q[2].w; r.l[12] = v.q[3].x; r.l[13] = v.q[3].y;
+  return r;
 }
-__device__ __forceinline__ void w_store12(uint32_t* p, const FrD& v) {     // v < 2^384, limbs normalised
-  uint32_t w[12];
-  fp_pack32<FrParams>(v, w);
-  uint4* q = reinterpret_cast<uint4*>(p);
-  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
-  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
-  q[2] = make_uint4(w[8], w[9], w[10], w[11]);
+__device__ __forceinline__ WVal w_to(const FrD& r) {
+  WVal v;
+  v.q[0] = make_uint4(r.l[0], r.l[1], r.l[2], r.l[3]); v.q[1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
+  v.q[2] = make_uint4(r.l[8], r.l[9], r.l[10], r.l[11]); v.q[3] = make_uint4(r.l[12], r.l[13], 0u, 0u);
+  return v;
 }
+__device__ __forceinline__ WVal w_ld(const uint4* q) { WVal v; v.q[0] = q[0]; v.q[1] = q[1]; v.q[2] = q[2]; v.q[3] = q[3]; return v; }
+__device__ __forceinline__ void w_st(uint4* q, const WVal& v) { q[0] = v.q[0]; q[1] = v.q[1]; q[2] = v.q[2]; q[3] = v.q[3]; }
 
-// constants: ABI form -> packed device form (once per upload)
+// constants: ABI form -> a value slot (once per upload)
 __global__ void __launch_bounds__(256) k_witness_consts(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t x[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) x[k] = in[(size_t)i * 6 + k];
-  w_store12(out + (size_t)i * 12, fp_cond_sub_p(fp_from_abi<FrParams>(x)));
+  w_st(reinterpret_cast<uint4*>(out + (size_t)i * WSLOT), w_to(fp_cond_sub_p(fp_from_abi<FrParams>(x))));
+}
+
+__device__ __forceinline__ bool w_binary(uint32_t c) { return c == WT_ADD || c == WT_MUL || c >= WT_SUBK; }
+
+// x (below 2^12 r) minus an estimated multiple of r: below 3r.  With t = floor(x / 2^358) (31 bits) and mu <= floor(2^390 / r)
+// (off by one at most), q = floor(t mu / 2^32) is never above floor(x / r) and at most 2 below it.  Fourteen small products and a
+// borrow chain - the price of an addition, where a multiplication by one would cost a level of the dear kind.
+__device__ __forceinline__ FrD w_reduce(const FrD& x, uint32_t mu) {
+  const uint32_t t = (x.l[13] << 19) | (x.l[12] >> 10);
+  const uint32_t q = (uint32_t)(((uint64_t)t * mu) >> 32);
+  FrD r;
+  int64_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 14; i++) {
+    const int64_t v = (int64_t)x.l[i] - (int64_t)((uint64_t)q * FrParams::P[i]) + carry;
+    r.l[i] = (i < 13) ? ((uint32_t)v & M29) : (uint32_t)v;
+    carry = v >> 29;
+  }
+  return r;
 }
 
 // one instruction: operands x (and y), result r.  Returns true when an inversion that must not meet zero did.
-__device__ __forceinline__ bool w_exec(uint32_t c, int32_t rb, const FrD& x, const FrD& y, const uint64_t* __restrict__ in, int32_t ra, FrD& r) {
+// subk: the table of K r in subtraction-safe limbs (LDS), a value slot per log2 K.
+__device__ __forceinline__ bool w_exec(uint32_t c, int32_t rb, const FrD& x, const FrD& y, const uint64_t* __restrict__ in, int32_t ra, FrD& r,
+                                       const uint4* subk, uint32_t mu) {
   bool bad = false;
+  if (c >= WT_SUBK) {                                                                  // a - b + 2^k r
+    const FrD kp = w_from(w_ld(&subk[(c - WT_SUBK) * 4]));
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = x.l[i] + kp.l[i] - y.l[i];
+    fp_normalise(r);
+    return false;
+  }
   switch (c) {
     case WT_INPUT: {
       uint64_t w[6];
@@ -65,12 +96,12 @@ __device__ __forceinline__ bool w_exec(uint32_t c, int32_t rb, const FrD& x, con
       r = fp_cond_sub_p(fp_from_abi<FrParams>(w));
       break;
     }
-    case WT_ADD: r = fp_cond_sub_kp<FrParams, 2>(fp_add(x, y)); break;                  // stored values stay below 2p
-    case WT_SUB: r = fp_cond_sub_kp<FrParams, 2>(fp_sub<FrParams, 2>(x, y)); break;
+    case WT_ADD: r = fp_add(x, y); break;
+    case WT_RED: r = w_reduce(x, mu); break;
     case WT_MUL: r = fp_mul(x, y); break;
     case WT_INV:
     case WT_INV0:
-      r = fp_inv<FrParams>(x);
+      r = fp_inv<FrParams>(fp_cond_sub_kp<FrParams, 2>(x));                           // (its operand is below 4r: the builder sees to it)
       bad = (c == WT_INV) && fp_is_zero_2p(r);                                        // the host generator would have taken another path
       break;
     default: {                                                                         // WT_BIT
@@ -87,51 +118,52 @@ __device__ __forceinline__ bool w_exec(uint32_t c, int32_t rb, const FrD& x, con
 
 // Chunks [c0, c1) of the levelled program, a chunk being 64 consecutive positions (a level is padded to whole chunks, so a chunk
 // never straddles two levels and running the chunks in order respects every dependency).  ONE WAVE PER BATCH: a level of this
-// program holds fifteen multiplications on average - there is nothing for a second wave to do, and with one wave there is no
+// program holds a few dozen independent instructions - there is nothing for a second wave to do, and with one wave there is no
 // barrier and no waiting for stores between levels.  What a level costs is then the latency of its operands, and the
 // program being static, almost all of it is taken off the critical path:
 //   * the instruction words are fetched three chunks ahead;
-//   * the last 2,048 results wait in an LDS ring (slot = position mod 2,048: the last 32 chunks) - nine operands in ten;
-//   * an older operand is loaded from the value array one chunk ahead (its store is tens of chunks old).
+//   * the last 1,024 results wait in an LDS ring (slot = position mod 1,024: the last 16 chunks) - nine operands in ten;
+//   * an older operand is loaded from the value array one chunk ahead (its store is many chunks old).
 // (A witness is cut into several launches of a few milliseconds so that the kernels of the provers that share a hardware queue
 // with it are not held up for its whole duration.)
 struct WIns { uint32_t code; int32_t a, b; };
 __device__ __forceinline__ WIns w_fetch(const WitnessProg& P, uint32_t chunk, uint32_t n_chunks, uint32_t lane) {
-  WIns r{(uint32_t)WT_NOP, 0, 0};
-  if (chunk < n_chunks) {
-    const uint32_t p = chunk * 64 + lane;
-    r.code = P.code[p]; r.a = P.a[p]; r.b = P.b[p];
-  }
+  // (no branch around the loads: the compiler counts outstanding loads exactly only in straight-line code; past the end the
+  //  last chunk is fetched again and turned into no-ops)
+  const uint32_t p = min(chunk, n_chunks - 1) * 64 + lane;
+  WIns r{P.code[p], P.a[p], P.b[p]};
+  if (chunk >= n_chunks) r.code = WT_NOP;
   return r;
 }
-__device__ __forceinline__ bool w_binary(uint32_t c) { return c == WT_ADD || c == WT_SUB || c == WT_MUL; }
-// issue the loads of the operands of `in` that are complete in memory (constants; positions below lim)
-__device__ __forceinline__ void w_prefetch(const WitnessProg& P, const uint32_t* __restrict__ vals, const WIns& in, uint32_t lim, uint4 (&px)[3], uint4 (&py)[3]) {
-  if (in.code == WT_NOP || in.code == WT_INPUT) return;
-  if (in.a < 0 || (uint32_t)in.a < lim) {
-    const uint4* q = reinterpret_cast<const uint4*>(in.a < 0 ? P.consts + (size_t)(-1 - in.a) * 12 : vals + (size_t)in.a * 12);
-    px[0] = q[0]; px[1] = q[1]; px[2] = q[2];
-  }
-  if (w_binary(in.code) && (in.b < 0 || (uint32_t)in.b < lim)) {
-    const uint4* q = reinterpret_cast<const uint4*>(in.b < 0 ? P.consts + (size_t)(-1 - in.b) * 12 : vals + (size_t)in.b * 12);
-    py[0] = q[0]; py[1] = q[1]; py[2] = q[2];
-  }
-}
-__device__ __forceinline__ FrD w_from3(const uint4 (&v)[3]) {
-  uint32_t w[12] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w};
-  return fp_unpack32<FrParams>(w);
+// issue the loads of the operands of `in` that are complete in memory (constants; positions below lim).  ALWAYS two loads per lane,
+// from a harmless address (constant 0) when there is nothing to fetch: a branch here would make the compiler wait for every
+// outstanding memory operation - the previous chunk's stores included - at its join (measured: 1.2 us per chunk, whatever it held).
+__device__ __forceinline__ void w_prefetch(const WitnessProg& P, const uint32_t* __restrict__ vals, const WIns& in, uint32_t lim, WVal& px, WVal& py) {
+  const bool has_a = in.code != WT_NOP && in.code != WT_INPUT, has_b = w_binary(in.code);
+  const uint32_t* pa = P.consts;
+  const uint32_t* pb = P.consts;
+  if (has_a && in.a < 0) pa = P.consts + (size_t)(-1 - in.a) * WSLOT;
+  if (has_a && in.a >= 0 && (uint32_t)in.a < lim) pa = vals + (size_t)in.a * WSLOT;
+  if (has_b && in.b < 0) pb = P.consts + (size_t)(-1 - in.b) * WSLOT;
+  if (has_b && in.b >= 0 && (uint32_t)in.b < lim) pb = vals + (size_t)in.b * WSLOT;
+  px = w_ld(reinterpret_cast<const uint4*>(pa));
+  py = w_ld(reinterpret_cast<const uint4*>(pb));
 }
 
-constexpr uint32_t WIT_RING = 2048;      // 96 KiB of the CU's 160
+constexpr uint32_t WIT_RING = 1024;      // 64 KiB of the CU's 160
 __global__ void __launch_bounds__(64) k_witness(WitnessProg P, uint32_t c0, uint32_t c1, const uint64_t* __restrict__ inputs /* batches x n_inputs x 6, ABI */,
-                                                 uint32_t* __restrict__ values /* batches x n_pos x 12 */, uint32_t* __restrict__ flags) {
-  __shared__ uint4 ring[WIT_RING * 3];
+                                                 uint32_t* __restrict__ values /* batches x n_pos x 16 */, uint32_t* __restrict__ flags) {
+  __shared__ uint4 ring[WIT_RING * 4];
+  __shared__ uint4 subk[WT_SUBK_LEVELS * 4];
   const uint32_t batch = blockIdx.x, lane = threadIdx.x;
+  if (lane < WT_SUBK_LEVELS * 4) subk[lane] = reinterpret_cast<const uint4*>(P.subk)[lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   const uint64_t* in = inputs + (size_t)batch * P.n_inputs * 6;
-  uint32_t* vals = values + (size_t)batch * P.n_pos * 12;
+  uint32_t* vals = values + (size_t)batch * P.n_pos * WSLOT;
   uint32_t bad = 0;
   // one chunk: `cur` with its prefetched operands (cx, cy); `nxt` is the chunk after it, whose operands are requested here
-  auto step = [&](uint32_t j, const WIns& cur, uint4 (&cx)[3], uint4 (&cy)[3], const WIns& nxt, uint4 (&nx)[3], uint4 (&ny)[3]) {
+  auto step = [&](uint32_t j, const WIns& cur, WVal& cx, WVal& cy, const WIns& nxt, WVal& nx, WVal& ny) {
     // chunk i finds in the ring what this launch wrote and chunk i itself does not overwrite: positions from ring_lo(i) on
     auto ring_lo = [&](uint32_t i) { const uint32_t w = (i + 1) * 64; return max(c0 * 64, w > WIT_RING ? w - WIT_RING : 0u); };
     w_prefetch(P, vals, nxt, ring_lo(j + 1), nx, ny);
@@ -140,21 +172,13 @@ __global__ void __launch_bounds__(64) k_witness(WitnessProg P, uint32_t c0, uint
     if (c != WT_NOP) {
       FrD x = fp_zero<FrParams>(), y = x, r = x;
       if (c != WT_INPUT) {
-        if (cur.a < 0 || (uint32_t)cur.a < lim) x = w_from3(cx);
-        else { const uint4* q = &ring[((uint32_t)cur.a % WIT_RING) * 3]; uint4 t[3] = {q[0], q[1], q[2]}; x = w_from3(t); }
-        if (w_binary(c)) {
-          if (cur.b < 0 || (uint32_t)cur.b < lim) y = w_from3(cy);
-          else { const uint4* q = &ring[((uint32_t)cur.b % WIT_RING) * 3]; uint4 t[3] = {q[0], q[1], q[2]}; y = w_from3(t); }
-        }
+        x = w_from((cur.a < 0 || (uint32_t)cur.a < lim) ? cx : w_ld(&ring[((uint32_t)cur.a % WIT_RING) * 4]));
+        if (w_binary(c)) y = w_from((cur.b < 0 || (uint32_t)cur.b < lim) ? cy : w_ld(&ring[((uint32_t)cur.b % WIT_RING) * 4]));
       }
-      if (w_exec(c, cur.b, x, y, in, cur.a, r)) bad = 1;
-      uint32_t w[12];
-      fp_pack32<FrParams>(r, w);
-      const uint4 v0 = make_uint4(w[0], w[1], w[2], w[3]), v1 = make_uint4(w[4], w[5], w[6], w[7]), v2 = make_uint4(w[8], w[9], w[10], w[11]);
-      uint4* g = reinterpret_cast<uint4*>(vals + ((size_t)j * 64 + lane) * 12);
-      g[0] = v0; g[1] = v1; g[2] = v2;
-      uint4* q = &ring[((j * 64 + lane) % WIT_RING) * 3];
-      q[0] = v0; q[1] = v1; q[2] = v2;
+      if (w_exec(c, cur.b, x, y, in, cur.a, r, subk, P.mu)) bad = 1;
+      const WVal v = w_to(r);
+      w_st(reinterpret_cast<uint4*>(vals + ((size_t)j * 64 + lane) * WSLOT), v);
+      w_st(&ring[((j * 64 + lane) % WIT_RING) * 4], v);
     }
     // the ring: this chunk's reads above come before its writes in program order, the next chunk's reads after them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -162,8 +186,8 @@ __global__ void __launch_bounds__(64) k_witness(WitnessProg P, uint32_t c0, uint
   };
   const uint32_t n_chunks = c1;
   WIns i0 = w_fetch(P, c0, n_chunks, lane), i1 = w_fetch(P, c0 + 1, n_chunks, lane), i2 = w_fetch(P, c0 + 2, n_chunks, lane), i3 = w_fetch(P, c0 + 3, n_chunks, lane);
-  uint4 ax[3], ay[3], bx[3], by[3];
-  for (int k = 0; k < 3; k++) ax[k] = ay[k] = bx[k] = by[k] = make_uint4(0, 0, 0, 0);
+  WVal ax, ay, bx, by;
+  for (int k = 0; k < 4; k++) ax.q[k] = ay.q[k] = bx.q[k] = by.q[k] = make_uint4(0, 0, 0, 0);
   w_prefetch(P, vals, i0, c0 * 64, ax, ay);                            // everything before this launch is in memory (ring_lo(c0))
 #pragma unroll 1
   for (uint32_t j = c0; j < c1; j += 2) {
@@ -180,10 +204,14 @@ __global__ void __launch_bounds__(64) k_witness(WitnessProg P, uint32_t c0, uint
 // words are fetched 64 at a time, a lane each, and broadcast.
 __global__ void __launch_bounds__(64) k_witness_chain(WitnessProg P, uint32_t chain_start, const uint64_t* __restrict__ inputs,
                                                        uint32_t* __restrict__ values, uint32_t* __restrict__ flags) {
-  __shared__ uint4 ring[64 * 3];
+  __shared__ uint4 ring[64 * 4];
+  __shared__ uint4 subk[WT_SUBK_LEVELS * 4];
   const uint32_t batch = blockIdx.x, lane = threadIdx.x;
+  if (lane < WT_SUBK_LEVELS * 4) subk[lane] = reinterpret_cast<const uint4*>(P.subk)[lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
   const uint64_t* in = inputs + (size_t)batch * P.n_inputs * 6;
-  uint32_t* vals = values + (size_t)batch * P.n_pos * 12;
+  uint32_t* vals = values + (size_t)batch * P.n_pos * WSLOT;
   uint32_t bad = 0;
 #pragma unroll 1
   for (uint32_t base = chain_start; base < P.n_pos; base += 64) {
@@ -198,27 +226,18 @@ __global__ void __launch_bounds__(64) k_witness_chain(WitnessProg P, uint32_t ch
       const int32_t ra = __shfl(my_a, (int)i), rb = __shfl(my_b, (int)i);
       if (c == WT_NOP) continue;
       auto load = [&](int32_t ref) -> FrD {
-        if (ref < 0) return w_load12(P.consts + (size_t)(-1 - ref) * 12);
-        if ((uint32_t)ref + 64 > p) {                     // one of the last 64 results
-          const uint4* q = &ring[((uint32_t)ref % 64) * 3];
-          uint4 x = q[0], y = q[1], z = q[2];
-          uint32_t w[12] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w, z.x, z.y, z.z, z.w};
-          return fp_unpack32<FrParams>(w);
-        }
-        return w_load12(vals + (size_t)ref * 12);            // older: its store is long complete (fenced below every 64 instructions)
+        if (ref < 0) return w_from(w_ld(reinterpret_cast<const uint4*>(P.consts + (size_t)(-1 - ref) * WSLOT)));
+        if ((uint32_t)ref + 64 > p) return w_from(w_ld(&ring[((uint32_t)ref % 64) * 4]));     // one of the last 64 results
+        return w_from(w_ld(reinterpret_cast<const uint4*>(vals + (size_t)ref * WSLOT)));       // older: its store is long complete
       };
       FrD x = fp_zero<FrParams>(), y = x, r = x;
       if (c != WT_INPUT) x = load(ra);
-      if (c == WT_ADD || c == WT_SUB || c == WT_MUL) y = load(rb);
-      if (w_exec(c, rb, x, y, in, ra, r)) bad = 1;
-      uint32_t w[12];
-      fp_pack32<FrParams>(r, w);
-      const uint4 v0 = make_uint4(w[0], w[1], w[2], w[3]), v1 = make_uint4(w[4], w[5], w[6], w[7]), v2 = make_uint4(w[8], w[9], w[10], w[11]);
+      if (w_binary(c)) y = load(rb);
+      if (w_exec(c, rb, x, y, in, ra, r, subk, P.mu)) bad = 1;
+      const WVal v = w_to(r);
       if (lane == 0) {
-        uint4* g = reinterpret_cast<uint4*>(vals + (size_t)p * 12);
-        g[0] = v0; g[1] = v1; g[2] = v2;
-        uint4* q = &ring[(p % 64) * 3];
-        q[0] = v0; q[1] = v1; q[2] = v2;
+        w_st(reinterpret_cast<uint4*>(vals + (size_t)p * WSLOT), v);
+        w_st(&ring[(p % 64) * 4], v);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // LDS write visible to the wave's next read
       __builtin_amdgcn_wave_barrier();
@@ -233,11 +252,11 @@ __global__ void __launch_bounds__(256) k_witness_out(WitnessProg P, const uint32
   const uint32_t batch = blockIdx.y;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_vars) return;
-  const uint32_t* vals = values + (size_t)batch * P.n_pos * 12;
+  const uint32_t* vals = values + (size_t)batch * P.n_pos * WSLOT;
   const int32_t ref = P.out_ref[i];
-  FrD v = w_load12(ref >= 0 ? vals + (size_t)ref * 12 : P.consts + (size_t)(-1 - ref) * 12);
+  FrD v = w_from(w_ld(reinterpret_cast<const uint4*>(ref >= 0 ? vals + (size_t)ref * WSLOT : P.consts + (size_t)(-1 - ref) * WSLOT)));
   uint64_t w[6];
-  fp_to_abi<FrParams>(v, w);
+  fp_to_abi<FrParams>(v, w);                                       // (a full reduction: any bound below 2^10 r)
   uint64_t* z = z_out + ((size_t)batch * P.n_vars + i) * 6;
 #pragma unroll
   for (int k = 0; k < 6; k++) z[k] = w[k];
@@ -246,7 +265,7 @@ __global__ void __launch_bounds__(256) k_witness_out(WitnessProg P, const uint32
 // ------------------------------------------------------------------------------------------------ host side
 struct ProgDev {
   WitnessProg prog;
-  void* bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* bufs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 struct GpuWitnessState {
   WitnessTape tape;
@@ -292,7 +311,28 @@ int witness_prog(zkhip_aggregator* a, WitnessProg* out, const WitnessTape** tape
     };
     up(0, T.code.data(), n); up(1, T.a.data(), n * 4); up(2, T.b.data(), n * 4);
     up(3, T.level_start.data(), T.level_start.size() * 4); up(4, T.out_ref.data(), T.out_ref.size() * 4);
-    if (e == hipSuccess) e = hipMalloc(&pd.bufs[5], nc * 48 + 48);
+    if (e == hipSuccess) e = hipMalloc(&pd.bufs[5], nc * 64 + 64);
+    // K r (K = 2^k, k < WT_SUBK_LEVELS) in subtraction-safe limbs: every limb but the top raised by 2^29 at its upper neighbour's expense
+    uint32_t subk[WT_SUBK_LEVELS][16];
+    memset(subk, 0, sizeof subk);
+    for (int k = 0; k < WT_SUBK_LEVELS; k++) {
+      uint64_t c = 0;
+      for (int i = 0; i < 14; i++) {
+        c += (uint64_t)FrParams::P[i] << k;
+        subk[k][i] = (i < 13) ? (uint32_t)(c & M29) : (uint32_t)c;
+        c >>= 29;
+      }
+      for (int i = 0; i < 13; i++) { subk[k][i] += 1u << 29; subk[k][i + 1] -= 1u; }
+    }
+    up(6, subk, sizeof subk);
+    // mu <= floor(2^390 / r), from the top 64 bits of r (bits 313 .. 376)
+    uint32_t mu = 0;
+    {
+      unsigned __int128 top = 0;                 // r >> 290 (limbs 10 .. 13), then >> 23
+      for (int i = 13; i >= 10; i--) top = (top << 29) | FrParams::P[i];
+      const uint64_t p_hi = (uint64_t)(top >> 23);
+      mu = (uint32_t)((((unsigned __int128)1) << 77) / ((unsigned __int128)p_hi + 1));
+    }
     if (e == hipSuccess) e = hipMalloc(&d_c64, nc * 48 + 48);
     if (e == hipSuccess) e = hipMemcpy(d_c64, T.consts.data(), nc * 48, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -307,7 +347,7 @@ int witness_prog(zkhip_aggregator* a, WitnessProg* out, const WitnessTape** tape
     }
     pd.prog = WitnessProg{(const uint8_t*)pd.bufs[0], (const int32_t*)pd.bufs[1], (const int32_t*)pd.bufs[2], (const uint32_t*)pd.bufs[3],
                           (const int32_t*)pd.bufs[4], (const uint32_t*)pd.bufs[5], (uint32_t)(T.level_start.size() - 1), (uint32_t)n,
-                          (uint32_t)T.n_vars, (uint32_t)T.n_inputs, T.chain_start};
+                          (uint32_t)T.n_vars, (uint32_t)T.n_inputs, T.chain_start, (const uint32_t*)pd.bufs[6], mu};
     it = st->dev.emplace(device, pd).first;
   }
   *out = it->second.prog;

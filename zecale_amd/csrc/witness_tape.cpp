@@ -232,7 +232,7 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
       R.ops.swap(ops2);
       h0 = nh0; h1 = nh1;
     }
-    const size_t n_ops = R.ops.size();
+    size_t n_ops = R.ops.size();
     // prune: keep what the assignment depends on
     std::vector<uint8_t> live(n_ops, 0);
     for (int32_t r : out_ref) if (r >= 0) live[r] = 1;
@@ -242,6 +242,71 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
       if (op.code == WT_INPUT) continue;
       if (op.a >= 0) live[op.a] = 1;
       if ((op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) && op.b >= 0) live[op.b] = 1;
+    }
+    // Lazy reduction.  The device keeps a value as its 14 limbs and does NOT reduce after an addition or a subtraction (a
+    // conditional subtraction of r costs more than the addition it follows): every value carries an upper bound here, a multiple
+    // of r.  A product is below 2r whatever it multiplies (operands below 2^12 r), a sum is bounded by the sum, a - b becomes
+    // a - b + K r with K the power of two that covers b's bound (WT_SUBK + log2 K), and where a bound would pass 2^12 r - or an
+    // inversion's operand 4 r - a WT_RED brings the operand back below 4 r (an estimated multiple of r subtracted: an addition's
+    // cost, not a multiplication's; 9 k of them in the batch-2 program, most in doubling chains).  (Dead instructions go here too.)
+    {
+      const uint32_t CAP = 4096, KMAX = 2048;      // (operands of a product below 2^12 r each: a b < 2^24 r^2 < R r)
+      std::vector<Recorder::Op> ops3;
+      std::vector<uint32_t> bound3;
+      std::vector<int32_t> remap(n_ops, -1);
+      ops3.reserve(n_ops); bound3.reserve(n_ops);
+      auto bnd = [&](int32_t r3) -> uint32_t { return r3 < 0 ? 1u : bound3[r3]; };
+      auto push = [&](uint8_t code, int32_t a, int32_t b, uint32_t bound) { ops3.push_back({code, a, b}); bound3.push_back(bound); return (int32_t)ops3.size() - 1; };
+      auto reduce = [&](int32_t r3) { return push(WT_RED, r3, 0, 3); };       // (witness.hip, w_reduce: below 3r)
+      auto rm = [&](int32_t ref) { return ref >= 0 ? remap[ref] : ref; };
+      size_t nh0 = 0, nh1 = 0, n_red0 = 0;
+      for (size_t i = 0; i < n_ops; i++) {
+        if (i == h0) nh0 = ops3.size();
+        if (i == h1) nh1 = ops3.size();
+        if (!live[i]) continue;
+        const auto& op = R.ops[i];
+        const size_t before = ops3.size();
+        switch (op.code) {
+          case WT_INPUT: remap[i] = push(WT_INPUT, op.a, 0, 1); break;
+          case WT_ADD: {
+            int32_t a = rm(op.a), b = rm(op.b);
+            while (bnd(a) + bnd(b) > CAP) { if (bnd(a) >= bnd(b)) a = reduce(a); else b = reduce(b); }
+            remap[i] = push(WT_ADD, a, b, bnd(a) + bnd(b));
+            break;
+          }
+          case WT_SUB: {
+            int32_t a = rm(op.a), b = rm(op.b);
+            if (bnd(b) > KMAX) b = reduce(b);
+            uint32_t k = 2;
+            while (k < bnd(b)) k <<= 1;
+            if (bnd(a) + k > CAP) a = reduce(a);
+            uint8_t lg = 0;
+            while ((1u << lg) < k) lg++;
+            const uint8_t code = (uint8_t)(WT_SUBK + lg);                  // WT_SUBK + log2 K
+            remap[i] = push(code, a, b, bnd(a) + k);
+            break;
+          }
+          case WT_MUL: remap[i] = push(WT_MUL, rm(op.a), rm(op.b), 2); break;
+          case WT_INV:
+          case WT_INV0: {
+            int32_t a = rm(op.a);
+            if (bnd(a) > 4) a = reduce(a);
+            remap[i] = push(op.code, a, 0, 2);
+            break;
+          }
+          case WT_BIT: remap[i] = push(WT_BIT, rm(op.a), op.b, 1); break;
+          default: throw std::runtime_error("witness tape: unknown instruction");
+        }
+        n_red0 += ops3.size() - before - 1;
+      }
+      if (h0 >= n_ops) nh0 = ops3.size();
+      if (h1 >= n_ops) nh1 = ops3.size();
+      for (auto& r : out_ref) if (r >= 0) r = remap[r];
+      R.ops.swap(ops3);
+      n_ops = R.ops.size();
+      live.assign(n_ops, 1);
+      h0 = nh0; h1 = nh1;
+      out->n_reductions = n_red0;
     }
     // The key hash (MiMC, Miyaguchi-Preneel chaining: 13 absorptions x 93 rounds x 7 dependent operations) is one long chain with
     // nothing to run beside it: as levels of the common program it would be 8,500 of its 9,800 levels, each paying a barrier and a
@@ -264,7 +329,7 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
         d[0] = d[1] = -1;
         if (op.code == WT_INPUT) return;
         if (op.a >= 0) d[0] = op.a;
-        if ((op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) && op.b >= 0 && op.b != op.a) d[1] = op.b;
+        if (wt_binary(op.code) && op.b >= 0 && op.b != op.a) d[1] = op.b;
       };
       for (size_t i = 0; i < n_ops; i++) {
         if (!live[i] || in_chain(i)) continue;
@@ -311,7 +376,7 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
     });
     std::vector<int32_t> pos_of(n_ops, -1);
     WitnessTape& T = *out;
-    T = WitnessTape();
+    { const size_t nr = out->n_reductions; T = WitnessTape(); T.n_reductions = nr; }
     T.level_start.push_back(0);
     int32_t cur = 0;
     for (uint32_t i : order) {
@@ -338,7 +403,7 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
         const auto& op = R.ops[i];
         if (op.code == WT_INPUT) continue;
         need_input(op.a);
-        if (op.code == WT_ADD || op.code == WT_SUB || op.code == WT_MUL) need_input(op.b);
+        if (wt_binary(op.code)) need_input(op.b);
       }
       for (auto& kv : input_copy) {
         kv.second = (int32_t)T.code.size();
@@ -359,7 +424,7 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
           return input_copy.at((uint32_t)ref);
         };
         T.a[p] = fix(T.a[p]);
-        if (c == WT_ADD || c == WT_SUB || c == WT_MUL) T.b[p] = fix(T.b[p]);
+        if (wt_binary(c)) T.b[p] = fix(T.b[p]);
       }
     }
     // operands: instruction ids -> positions
@@ -367,7 +432,7 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
       const uint8_t c = T.code[p];
       if (c == WT_NOP || c == WT_INPUT) continue;
       if (T.a[p] >= 0) T.a[p] = pos_of[T.a[p]];
-      if ((c == WT_ADD || c == WT_SUB || c == WT_MUL) && T.b[p] >= 0) T.b[p] = pos_of[T.b[p]];
+      if (wt_binary(c) && T.b[p] >= 0) T.b[p] = pos_of[T.b[p]];
     }
     T.out_ref.resize(n_vars);
     for (size_t i = 0; i < n_vars; i++) T.out_ref[i] = out_ref[i] >= 0 ? pos_of[out_ref[i]] : out_ref[i];

@@ -12,11 +12,16 @@ namespace zkhip {
 enum : uint8_t {
   WT_NOP = 0,
   WT_INPUT = 1,   // a: index of the input element (nested key | nested proofs | nested inputs, 6 limbs each)
-  WT_ADD = 2, WT_SUB = 3, WT_MUL = 4,
+  WT_ADD = 2,     // a + b, NOT reduced: the builder tracks an upper bound (a multiple of r) for every value
+  WT_SUB = 3,     // a - b as recorded; the laid-out program holds WT_SUBK + log2 K instead
+  WT_MUL = 4,     // Montgomery product: below 2r whatever the operands' bounds (they stay below 2^10 r)
   WT_INV = 5,     // inversion of a value that is never zero for well-formed inputs (the device raises a flag if it is)
   WT_INV0 = 6,    // inversion that maps 0 to 0 by design (the is-zero gadget's hint)
   WT_BIT = 7,     // bit b of the canonical integer of a, as a field element
+  WT_RED = 8,     // a brought below 4r by subtracting an estimated multiple of r (no multiplication: the cheap kind of reduction)
+  WT_SUBK = 16,   // WT_SUBK + k: a - b + 2^k r, for b below 2^k r (k = 1 .. 11)
 };
+inline bool wt_binary(uint8_t c) { return c == WT_ADD || c == WT_SUB || c == WT_MUL || c >= WT_SUBK; }
 
 struct WitnessTape {
   std::vector<uint8_t> code;
@@ -26,7 +31,7 @@ struct WitnessTape {
   std::vector<int32_t> out_ref;          // assignment entry i = value at this reference
   std::vector<uint64_t> consts;          // 6 limbs each, ABI form (Montgomery 2^384)
   size_t n_vars = 0, n_inputs = 0, vk_words = 0, proofs_words = 0, inputs_words = 0;
-  size_t n_recorded = 0, n_mul = 0, n_inv = 0;
+  size_t n_recorded = 0, n_mul = 0, n_inv = 0, n_reductions = 0;      // n_reductions: multiplications by one inserted to keep the bounds
 };
 
 // 0 on success

@@ -1028,7 +1028,7 @@ int zkhip_gpu_witness_new_batched(zkhip_aggregator* a, size_t max_batches, zkhip
   if (rc != ZKHIP_OK) { delete w; return rc; }
   w->in_words = (size_t)w->prog.n_inputs * 6;
   hipError_t e = hipMalloc(&w->d_in, max_batches * w->in_words * 8);
-  if (e == hipSuccess) e = hipMalloc(&w->d_vals, max_batches * (size_t)w->prog.n_pos * 48);
+  if (e == hipSuccess) e = hipMalloc(&w->d_vals, max_batches * (size_t)w->prog.n_pos * witness_value_bytes);
   if (e == hipSuccess) e = hipMalloc(&w->d_flag, max_batches * 4 + 64);
   if (e == hipSuccess) e = hipHostMalloc(&w->h_in, max_batches * (w->in_words + 1 + a->n_primary * 6) * 8);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking);
