@@ -31,6 +31,7 @@ struct MsmCtx {
   uint16_t win_off[96];
   uint8_t win_bits[96];
   size_t B, max_n;
+  uint32_t quad_below;  // reduction launches with fewer outputs than this spread an addition over four lanes (latency) instead of one (total work)
   uint32_t S, T, slot_stride;   // slice length, slice count, words per row of the slot array
   hipStream_t stream, stream2;
   hipEvent_t ev, ev2, ev_acc0, ev_acc1, ev_done;

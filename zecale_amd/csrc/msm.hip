@@ -898,6 +898,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   memset(ctx, 0, sizeof *ctx);
   if (K < 1 || K > MSM_MAX_JOBS || (!merged && K != 1)) return ZKHIP_ERR_ARG;
   ctx->K = K;
+  ctx->quad_below = (uint32_t)env_int("ZKHIP_QUAD_BELOW", 65536, 1, 1 << 30);
   // 108 * (W * 2^(c-1) + 2T) * 4 bytes must stay below 4 GiB (buffer descriptor); checked below
   if (c < 4 || c > (merged ? 22 : 18)) return ZKHIP_ERR_ARG;
   ctx->c = c;
@@ -909,7 +910,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   window_layout(c, ctx->win_off, ctx->win_bits);
   ctx->B = (size_t)1 << (c - 1);
   ctx->max_n = max_n;
-  ctx->L = 4; ctx->logL = 2;
+  ctx->logL = env_int("ZKHIP_SUM_LOGL", 2, 1, 5); ctx->L = 1 << ctx->logL;      // fan-in of the reduction trees (tuning knob)
   size_t nb = ctx->B * ctx->W;
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));   // no implicit ordering against the null stream (the host application's, e.g. torch's)
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -1152,7 +1153,9 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   //     F(items) = sum_t R_t + L * F0(S); the k_seg chain (stream 1) produces one R array per level, reducing
   //     each R array to one point per group (k_sum chain) is independent of the later levels: stream 2,
   // (3) per group Horner over the levels, then per window R * hi + lo.
-  const size_t QUAD_BELOW = 65536;   // fewer additions than half the chip's lanes: latency-bound, use quads
+  // fewer additions than this: the launch is latency-bound, a quad of lanes per addition finishes it sooner (at ~twice the lane-cycles:
+  // a prover that shares the chip with others lowers the threshold, msm.h quad_below)
+  const size_t QUAD_BELOW = ctx->quad_below;
   hipStream_t st2 = ctx->stream2;
   const int lo_bits = (c - 1 + 1) / 2, hi_bits = (c - 1) - lo_bits;
   const uint32_t Rr = 1u << lo_bits, Hh = 1u << hi_bits, Nn = Rr > Hh ? Rr : Hh;

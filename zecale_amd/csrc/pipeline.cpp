@@ -219,6 +219,7 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
   for (int i = 0; i < gpu_slots; i++) {
     zkhip_prover* pr = nullptr;
     rc = zkhip_prover_new(crs, &desc, &pr);
+    if (rc == ZKHIP_OK) (void)zkhip_prover_set_streaming(pr, 1);
     if (rc != ZKHIP_OK) {
       for (zkhip_prover* q : p->provers) zkhip_prover_free(q);
       for (auto& q : p->slabs) zkhip_device_free(q.base);

@@ -16,7 +16,7 @@ EXPORTS = [
     "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window", "zkhip_set_batch_msms",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_msm_submit", "zkhip_msm_collect",
     "zkhip_device_alloc", "zkhip_device_free", "zkhip_device_copy_in", "zkhip_last_accumulate_ms",
-    "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
+    "zkhip_prover_set_streaming", "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
     "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings", "zkhip_groth16_verify",
     "zkhip_crs_upload_slice", "zkhip_groth16_prove_partial", "zkhip_groth16_finish",
@@ -111,6 +111,7 @@ def load():
     lib.zkhip_keypair_write.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
     lib.zkhip_keypair_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
     lib.zkhip_prover_new.argtypes = [ctypes.c_void_p, ctypes.POINTER(R1csDesc), ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_prover_set_streaming.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.zkhip_prover_prove.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
     lib.zkhip_prover_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.zkhip_prover_free.argtypes = [ctypes.c_void_p]
@@ -558,6 +559,10 @@ class Prover:
         out = np.zeros(72, dtype=np.uint64)
         _check(load().zkhip_prover_prove(self.handle, _p(z), _p(r), _p(s), _p(out)))
         return out
+
+    def set_streaming(self, on=True):
+        """this instance shares the GPU with others: total work over single-proof latency (zkhip_prover_set_streaming)"""
+        _check(load().zkhip_prover_set_streaming(self.handle, int(bool(on))))
 
     def last_accumulate_ms(self):
         return float(load().zkhip_prover_last_accumulate_ms(self.handle))
