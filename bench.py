@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="override the MSM window c (tuning; 0 = automatic, at most 18)")
     ap.add_argument("--no-batch-msms", action="store_true", help="one launch sequence per MSM instead of one per proof")
     ap.add_argument("--serial", action="store_true", help="one MSM / one proof in flight (per-phase timings) instead of the streaming forms")
-    ap.add_argument("--gpu-slots", type=int, default=6, help="aggregator pipeline: proofs in flight on the GPU")
+    ap.add_argument("--gpu-slots", type=int, default=14, help="aggregator pipeline: proofs in flight on the GPU")
     ap.add_argument("--witness-workers", type=int, default=8, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
     ap.add_argument("--gpu-witness", action="store_true", help="aggregator pipeline: the witness workers generate the assignment on the GPU")
     ap.add_argument("--cpu-sample-log", type=int, default=20)

@@ -177,7 +177,7 @@ class aggregator_circuit {
     zkhip_pipeline* p_ = nullptr;
   };
   // witness_on_gpu: the assignments are generated by a device kernel (zkhip_gpu_witness_*): fewer host cores, a deeper stream
-  std::unique_ptr<stream> open_stream(const keypair& kp, int gpu_slots = 4, int witness_workers = 6, bool witness_on_gpu = false) {
+  std::unique_ptr<stream> open_stream(const keypair& kp, int gpu_slots = 14, int witness_workers = 8, bool witness_on_gpu = false) {
     return std::unique_ptr<stream>(new stream(*this, kp, gpu_slots, witness_workers, witness_on_gpu));
   }
 

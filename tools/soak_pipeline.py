@@ -19,7 +19,7 @@ agg = zkhip.AggregatorCircuit(2, 1)
 kp = zkhip.Keypair(zkhip.r1cs_desc_from_aggregator(agg), *trapdoor)
 vk, crs = kp.vk(), kp.upload_crs()
 GPU_WITNESS = "gpu" in sys.argv[2:]
-pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=6, witness_workers=2 if GPU_WITNESS else 8, gpu_witness=GPU_WITNESS)
+pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=14, witness_workers=2 if GPU_WITNESS else 8, gpu_witness=GPU_WITNESS)
 rng = np.random.default_rng(1)
 rs = bench.random_fr_canonical(77, 2 * N)
 jobs, bad, t0 = [], 0, time.time()

@@ -187,7 +187,7 @@ int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int
 }
 
 int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, unsigned flags, zkhip_pipeline** out) {
-  if (!a || !crs || !out || gpu_slots < 1 || gpu_slots > 8 || witness_workers < 1 || witness_workers > 64) return ZKHIP_ERR_ARG;
+  if (!a || !crs || !out || gpu_slots < 1 || gpu_slots > 32 || witness_workers < 1 || witness_workers > 64) return ZKHIP_ERR_ARG;
   zkhip_r1cs_desc desc;
   int rc = zkhip_aggregator_get_r1cs(a, &desc);
   if (rc != ZKHIP_OK) return rc;

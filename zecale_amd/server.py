@@ -215,7 +215,7 @@ class GpuProver:
     """The wrapping prover behind the service: circuit, keypair (file or fresh setup), HBM-resident key, streaming pipeline."""
     snark_name = "GROTH16"
 
-    def __init__(self, keypair_file=None, device=0, gpu_slots=4, witness_workers=6, gpu_witness=False):
+    def __init__(self, keypair_file=None, device=0, gpu_slots=14, witness_workers=8, gpu_witness=False):
         from . import zkhip
         self.zk = zkhip
         zkhip.init(device)
