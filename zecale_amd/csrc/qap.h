@@ -16,6 +16,7 @@ struct CsrDev {
 };
 
 struct R1csDev {
+  int spmv_log_lanes = 4;      // lanes per row of the sparse products: 2^4 (a proof alone) or 2^2 (a prover that shares the chip)
   size_t n_constraints = 0, n_vars = 0, n_primary = 0;   // n_vars counts the constant ONE
   int log_d = 0;
   CsrDev A, B, C;

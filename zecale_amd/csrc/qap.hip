@@ -39,33 +39,38 @@ __device__ __forceinline__ void q_store12(uint32_t* p, const FrD& v) {
 // shifts.  (One lane per row is latency-bound by the longest rows - a packing constraint has 253 terms, an Fq12
 // multiplication constraint 47 - and a wrapping circuit has fewer rows than the chip has lanes.)
 // Products are accumulated lazily (each < 2r) and folded every 32 terms.
-__device__ __forceinline__ FrD fr_shfl_down16(const FrD& v, int delta) {
+template <int LANES>
+__device__ __forceinline__ FrD fr_shfl_down(const FrD& v, int delta) {
   FrD r;
 #pragma unroll
-  for (int i = 0; i < 14; i++) r.l[i] = (uint32_t)__shfl_down((int)v.l[i], delta, 16);
+  for (int i = 0; i < 14; i++) r.l[i] = (uint32_t)__shfl_down((int)v.l[i], delta, LANES);
   return r;
 }
 
+// LG: log2 of the lanes per row - 4 for a proof alone (latency), 2 for a prover that shares the chip (a quarter of the lane-cycles:
+// every lane of a row's group runs the fold and the final normalisations whether it had terms or not).
+template <int LG>
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                const uint32_t* __restrict__ val, const uint32_t* __restrict__ z,
                                                uint32_t n, uint32_t extra /* n_primary + 1 for A, else 0 */, uint32_t d,
                                                int log_k, int log_n2 /* log_k != 0: out in the NTT's transposed order */,
                                                uint32_t* __restrict__ out) {
   uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t i = gt >> 4, sub = gt & 15u;
+  constexpr uint32_t LANES = 1u << LG;
+  uint32_t i = gt >> LG, sub = gt & (LANES - 1);
   if (i >= d) return;                       // whole 16-lane groups leave together
   FrD acc = fp_zero<FrParams>();
   if (i < n) {
     uint32_t k0 = row_ptr[i], k1 = row_ptr[i + 1];
     uint32_t cnt = 0;
-    for (uint32_t k = k0 + sub; k < k1; k += 16) {
+    for (uint32_t k = k0 + sub; k < k1; k += LANES) {
       FrD p = fp_mul(q_load12(val + (size_t)k * 12), q_load12(z + (size_t)col[k] * 12));
       acc = fp_add(acc, p);
       if ((++cnt & 31u) == 0) acc = fp_mul(acc, fp_one<FrParams>());   // back to < 2r
     }
     if (cnt > 1) acc = fp_mul(acc, fp_one<FrParams>());                 // every partial sum < 2r
     // fold the 16 partial sums (each < 2r; the total < 32r fits the lazy bound; one final fold below)
-    for (int delta = 8; delta >= 1; delta >>= 1) acc = fp_add(acc, fr_shfl_down16(acc, delta));
+    for (int delta = LANES / 2; delta >= 1; delta >>= 1) acc = fp_add(acc, fr_shfl_down<LANES>(acc, delta));
     if (sub == 0) acc = fp_mul(acc, fp_one<FrParams>());                // stored values are always < 2r
   } else if (i < n + extra) {
     acc = q_load12(z + (size_t)(i - n) * 12);
@@ -182,11 +187,16 @@ void r1cs_free(R1csDev* r) {
 // the three products, in the order the first transform wants (transposed for 2^12 rows and more, see ntt.h)
 static void spmv3(R1csDev* r, hipStream_t st) {
   uint32_t n = (uint32_t)r->n_constraints, d = 1u << r->log_d;
-  unsigned nb = (unsigned)(((size_t)d * 16 + 255) / 256);
   const int lk = ntt_layout_logk(r->log_d), ln = lk ? r->log_d - lk : 0;
-  hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->A.row_ptr, r->A.col, r->A.val, r->z, n, (uint32_t)r->n_primary + 1, d, lk, ln, r->bufA);
-  hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->B.row_ptr, r->B.col, r->B.val, r->z, n, 0u, d, lk, ln, r->bufB);
-  hipLaunchKernelGGL(k_spmv, dim3(nb), dim3(256), 0, st, r->C.row_ptr, r->C.col, r->C.val, r->z, n, 0u, d, lk, ln, r->bufC);
+  const CsrDev* M[3] = {&r->A, &r->B, &r->C};
+  uint32_t* out[3] = {r->bufA, r->bufB, r->bufC};
+  for (int k = 0; k < 3; k++) {
+    const uint32_t extra = k == 0 ? (uint32_t)r->n_primary + 1 : 0u;
+    if (r->spmv_log_lanes == 2)
+      hipLaunchKernelGGL(k_spmv<2>, dim3((unsigned)(((size_t)d * 4 + 255) / 256)), dim3(256), 0, st, M[k]->row_ptr, M[k]->col, M[k]->val, r->z, n, extra, d, lk, ln, out[k]);
+    else
+      hipLaunchKernelGGL(k_spmv<4>, dim3((unsigned)(((size_t)d * 16 + 255) / 256)), dim3(256), 0, st, M[k]->row_ptr, M[k]->col, M[k]->val, r->z, n, extra, d, lk, ln, out[k]);
+  }
 }
 
 int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, size_t errlen) {
