@@ -3,14 +3,15 @@
 // aggregator_gadget.tcc:87-112) for a server that keeps many batches in flight: the host generator (aggregator.cpp) takes 8 ms on
 // three cores per batch - 25 core-ms, five busy cores at 200 proofs/s, and a one-GPU job gets sixteen.
 //
-// The assignment is a straight-line program over Fr recorded from the circuit's own template code (witness_tape.cpp): ~370 k
-// field operations, 1,334 of them inversions, ~9,800 dependent levels deep (the MiMC chain of the key hash is the longest path,
-// the 253-step input accumulator with one inversion per step the slowest).  k_witness interprets it with ONE WORKGROUP PER BATCH:
-// the instructions of a level are independent and spread over the workgroup's 256 lanes; a level ends with __syncthreads (results
-// travel through the value array in global memory, which is coherent inside a CU); every lane inverts with fp_inv (division
-// steps), all lanes of a wave at once.  There is nothing to fill a chip with inside one witness - the parallelism is ACROSS
-// batches: each batch in flight costs four waves out of the chip's 2,048+ wave slots, so witness generation rides along under
-// the provers' kernels and the host cores are free for the tails.
+// The assignment is a straight-line program over Fr recorded from the circuit's own template code (witness_tape.cpp): 327 k field
+// operations for a batch of two, 144 k of them multiplications and 326 inversions, laid out in levels of ONE KIND of instruction
+// each.  A level holds a few dozen independent instructions - nothing to fill a chip with, hardly a wave: k_witness interprets the
+// program with ONE WAVE PER BATCH, 64 instructions (a "chunk") at a time, no barriers; instruction words and old operands are
+// prefetched, recent results wait in an LDS ring; values are lazily reduced under bounds the tape builder tracks; every lane
+// inverts with fp_inv (division steps), all lanes of a wave at once.  The key hash (a strictly sequential MiMC chain) is a second
+// program run by a second wave on a second stream (k_witness_chain).  The parallelism is ACROSS batches: each batch in flight costs
+// two waves out of the chip's 2,048+ wave slots, so witness generation rides along under the provers' kernels and the host cores
+// are free for the tails.  27.7 ms per witness, sixteen witnesses per launch in the streaming prover.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>

@@ -5,12 +5,17 @@
 // the circuit is ONE body of template code (circuit/*.hpp) and this translation unit compiles it a second time over a
 // RECORDING scalar: every field operation on a value that depends on the inputs appends an instruction to a tape instead of
 // computing; operations on constants are folded.  The tape is then
-//   pruned      instructions no assignment entry depends on are dropped,
-//   levelled    an instruction's level is one more than its operands' - all instructions of a level are independent,
-//   laid out    level by level, inversions first, each level padded to whole 64-lane chunks; an instruction's position is also
-//               the slot its result is stored in, so a level's stores are contiguous.
-// The device interprets it with one workgroup per batch (witness.hip); the host generator (aggregator.cpp) stays the reference
-// for parity: tests compare the two assignments limb for limb.
+//   re-associated  chains of additions nobody else reads become balanced trees,
+//   pruned         instructions no assignment entry depends on are dropped,
+//   bounded        every value gets a static upper bound (a multiple of r): the device does not reduce after additions; subtractions
+//                  pick their K r, cheap reductions are inserted where a bound would pass 2^12 r,
+//   split          the key hash (one sequential MiMC chain) becomes a program of its own,
+//   levelled       by KIND: a level of additions while any is ready, else all ready multiplications, else all ready inversions,
+//   laid out       level by level, each level padded to whole 64-lane chunks; an instruction's position is also the slot its result
+//                  is stored in.
+// The device interprets it with one wave per batch (witness.hip); the host generator (aggregator.cpp) stays the reference for
+// parity: tests compare the two assignments limb for limb, on the GPU (tests/test_witness_gpu.py) and, interpreting the tape with
+// the host field arithmetic, on the CPU (tools/sanitize/tape_check.cpp).
 #include <stdint.h>
 #include <string.h>
 
