@@ -14,6 +14,7 @@
 // are free for the tails.  27.7 ms per witness, sixteen witnesses per launch in the streaming prover.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -363,7 +364,8 @@ void witness_launch(const WitnessProg& P, const uint64_t* d_inputs, uint32_t* d_
   (void)hipStreamWaitEvent(st_chain, ev_fork, 0);
   if (P.chain_start < P.n_pos) hipLaunchKernelGGL(k_witness_chain, dim3(batches), dim3(64), 0, st_chain, P, P.chain_start, d_inputs, d_values, d_flags);
   (void)hipEventRecord(ev_join, st_chain);
-  const uint32_t n_chunks = P.chain_start / 64, seg = 2048;       // chunks per launch: a few milliseconds
+  static const uint32_t seg_env = [] { const char* e = getenv("ZKHIP_WITNESS_SEGMENT"); int v = e ? atoi(e) : 0; return (uint32_t)(v >= 64 && v <= (1 << 20) ? v : 2048); }();
+  const uint32_t n_chunks = P.chain_start / 64, seg = seg_env;       // chunks per launch: a few milliseconds (tuning knob: ZKHIP_WITNESS_SEGMENT)
   for (uint32_t c0 = 0; c0 < n_chunks; c0 += seg)
     hipLaunchKernelGGL(k_witness, dim3(batches), dim3(64), 0, st, P, c0, (c0 + seg < n_chunks ? c0 + seg : n_chunks), d_inputs, d_values, d_flags);
   (void)hipStreamWaitEvent(st, ev_join, 0);
