@@ -37,6 +37,7 @@ struct MsmCtx {
   hipEvent_t ev, ev2, ev_acc0, ev_acc1, ev_done;
   int32_t* digits;
   uint32_t *counts, *offsets, *cursor, *block_tot, *entries;
+  uint2* fix_list;      // (first, last) boundary slot of the buckets cut into more than two pieces (k_fixup_round -> k_fixup_tree)
   uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels, *colS[2], *hilo;
   uint64_t *win_abi, *win_host;
   // batched-affine levels in front of the XYZZ accumulation (k_affine_level): per level the bucket counts / offsets of its output,

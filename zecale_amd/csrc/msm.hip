@@ -74,10 +74,24 @@ struct WindowPlan {
 // merged != 0 (precomputed table): every digit position uses the SAME bucket window (bucket = bucket_base + |d| - 1)
 // because the entry will point at 2^(c w) P_i instead of P_i; inf_flags then has one row of `tab_stride` flags per
 // level.  bucket_base = k * B selects the bucket window of job k when several MSMs share one launch sequence (0 otherwise).
-__global__ void __launch_bounds__(256) k_scalar_digits(const uint64_t* __restrict__ scalars, size_t n, int c, int W,
-                                                        WindowPlan plan, int montgomery, const uint8_t* __restrict__ inf_flags,
-                                                        int merged, size_t tab_stride, uint32_t bucket_base,
-                                                        int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
+// The MSMs of one launch sequence share the launch: blockIdx.y is the job, its parameters come from the table.
+struct DigitJobs {
+  const uint64_t* scalars[MSM_MAX_JOBS];
+  const uint8_t* inf_flags[MSM_MAX_JOBS];
+  size_t n[MSM_MAX_JOBS], tab_stride[MSM_MAX_JOBS];
+  int mode[MSM_MAX_JOBS];
+};
+__global__ void __launch_bounds__(256) k_scalar_digits(DigitJobs jobs, int c, int W, WindowPlan plan, int merged, uint32_t B_per_job,
+                                                        size_t digits_per_job, int32_t* __restrict__ digits_all, uint32_t* __restrict__ counts) {
+  const uint32_t job = blockIdx.y;
+  const size_t n = jobs.n[job];
+  if ((size_t)blockIdx.x * blockDim.x >= n) return;             // (whole blocks: the wave-aggregated atomics below need whole waves)
+  const uint64_t* __restrict__ scalars = jobs.scalars[job];
+  const uint8_t* __restrict__ inf_flags = jobs.inf_flags[job];
+  const int montgomery = jobs.mode[job];
+  const size_t tab_stride = jobs.tab_stride[job];
+  const uint32_t bucket_base = job * B_per_job;
+  int32_t* __restrict__ digits = digits_all + (size_t)job * digits_per_job;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   if (!live) i = n - 1;                    // keep whole waves in the loop: the hot-bucket atomics are wave-aggregated
@@ -179,10 +193,16 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ out, co
   for (int k = 0; k < 4; k++) if (base + k < m) out[base + k] += add;
 }
 
-__global__ void __launch_bounds__(256) k_scatter(const int32_t* __restrict__ digits, size_t n, int c, int W,
-                                                  int merged, size_t tab_stride, uint32_t bucket_base,
+__global__ void __launch_bounds__(256) k_scatter(DigitJobs jobs, const int32_t* __restrict__ digits_all, size_t digits_per_job, int c, int W,
+                                                  int merged, uint32_t B_per_job,
                                                   const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                                                   uint32_t* __restrict__ entries) {
+  const uint32_t job = blockIdx.y;
+  const size_t n = jobs.n[job];
+  if ((size_t)blockIdx.x * blockDim.x >= n) return;
+  const int32_t* __restrict__ digits = digits_all + (size_t)job * digits_per_job;
+  const size_t tab_stride = jobs.tab_stride[job];
+  const uint32_t bucket_base = job * B_per_job;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   if (!live) i = n - 1;
@@ -548,7 +568,7 @@ template <bool QUAD>
 __global__ void __launch_bounds__(256, 2) k_fixup_round(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                          uint32_t nb, uint32_t S, uint32_t T, uint32_t d,
                                                          const uint32_t* __restrict__ max_span, uint32_t* __restrict__ slots,
-                                                         uint32_t stride) {
+                                                         uint32_t stride, uint32_t* __restrict__ work_cnt, uint2* __restrict__ work_list) {
   ADD_SCRATCH_DECL(QUAD);
   if (d >= *max_span) return;
   uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt, q = gt & 3u;   // one lane or one quad per slice
@@ -558,8 +578,31 @@ __global__ void __launch_bounds__(256, 2) k_fixup_round(const uint32_t* __restri
   uint32_t b = bucket_of(offsets, nb, pos0);
   if (offsets[b] >= pos0) return;                       // slice does not start inside a bucket
   uint32_t tF0 = offsets[b] / S + 1, tF1 = (offsets[b] + counts[b] - 1) / S;
+  // a bucket of more than two pieces goes on the list of k_fixup_tree (first round only; at most T / 3 of them)
+  if (work_list && t == tF0 && tF1 - tF0 >= 2 && (!QUAD || q == 0)) work_list[atomicAdd(work_cnt, 1u)] = make_uint2(tF0, tF1);
   if ((t - tF0) % (2 * d) != 0 || t + d > tF1) return;
   pt_add<QUAD>(make_ref(slots, stride, nb + t), make_ref(slots, stride, nb + t + d), q, sc);
+}
+
+// Rounds d = 2, 4, ... of the stitching for the buckets of more than two pieces (the list the first round made), ALL rounds in
+// one launch: a workgroup takes a bucket, its 64 quads fold the pieces pairwise, a barrier between rounds (the pieces live in
+// global memory, coherent inside a CU).  Such buckets are few ("scalar = 1" in a boolean-heavy witness) but long: one launch per
+// round meant sixteen launches per MSM that mostly found nothing to do.
+__global__ void __launch_bounds__(256, 2) k_fixup_tree(const uint32_t* __restrict__ work_cnt, const uint2* __restrict__ work_list, uint32_t nb,
+                                                        uint32_t* __restrict__ slots, uint32_t stride) {
+  ADD_SCRATCH_DECL(true);
+  const uint32_t n = *work_cnt;
+  const uint32_t quad = threadIdx.x >> 2, q = threadIdx.x & 3u;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint2 w = work_list[i];                     // first and last F piece of the bucket
+#pragma unroll 1
+    for (uint32_t d = 2; d <= w.y - w.x; d <<= 1) {
+      for (uint64_t t = (uint64_t)w.x + (uint64_t)quad * 2 * d; t + d <= w.y; t += (uint64_t)64 * 2 * d)
+        pt_add<true>(make_ref(slots, stride, nb + (uint32_t)t), make_ref(slots, stride, nb + (uint32_t)t + d), q, sc);
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
 }
 
 // final stitch: the slice in which a cut bucket STARTS owns it: bucket = L[t0] + F[t0+1] (folded).
@@ -910,7 +953,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   window_layout(c, ctx->win_off, ctx->win_bits);
   ctx->B = (size_t)1 << (c - 1);
   ctx->max_n = max_n;
-  ctx->logL = env_int("ZKHIP_SUM_LOGL", 2, 1, 5); ctx->L = 1 << ctx->logL;      // fan-in of the reduction trees (tuning knob)
+  ctx->logL = env_int("ZKHIP_SUM_LOGL", 2, 2, 5); ctx->L = 1 << ctx->logL;      // fan-in of the reduction trees (tuning knob; the R arrays are sized for L >= 4)
   size_t nb = ctx->B * ctx->W;
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));   // no implicit ordering against the null stream (the host application's, e.g. torch's)
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -974,6 +1017,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
     if ((size_t)ctx->slot_stride * 108 * 4 >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;
   }
   HIP_TRY(hipMalloc(&ctx->buckets, (size_t)ctx->slot_stride * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->fix_list, ((size_t)ctx->T / 3 + 2) * sizeof(uint2)));     // buckets cut into more than two pieces: at most T / 3
   // reduction scratch: S ping-pong (<= nb/L each) and R arrays (sum over levels <= nb/L * L/(L-1)), R sums
   HIP_TRY(hipMalloc(&ctx->segS[0], (nb / 2 + 1) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->segS[1], (nb / 2 + 1) * 108 * 4));
@@ -993,7 +1037,8 @@ void msm_plan_free(MsmCtx* ctx) {
   void* ptrs[] = {ctx->digits, ctx->counts, ctx->offsets, ctx->cursor, ctx->block_tot, ctx->entries, ctx->buckets,
                   ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi,
                   ctx->colS[0], ctx->colS[1], ctx->hilo, ctx->pbuf[0], ctx->pbuf[1], ctx->aff_scratch,
-                  ctx->lcnt[0], ctx->lcnt[1], ctx->lcnt[2], ctx->lcnt[3], ctx->loff[0], ctx->loff[1], ctx->loff[2], ctx->loff[3]};
+                  ctx->lcnt[0], ctx->lcnt[1], ctx->lcnt[2], ctx->lcnt[3], ctx->loff[0], ctx->loff[1], ctx->loff[2], ctx->loff[3],
+                  ctx->fix_list};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->win_host) (void)hipHostFree(ctx->win_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1052,24 +1097,25 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   WindowPlan plan;
   memset(&plan, 0, sizeof plan);
   for (int w = 0; w < Wd; w++) { plan.off[w] = ctx->win_off[w]; plan.bits[w] = ctx->win_bits[w]; }
+  DigitJobs dj;
+  memset(&dj, 0, sizeof dj);
+  size_t n_max = 0;
   for (int k = 0; k < K; k++) {
-    const MsmJob& jb = jobs[k];
-    if (jb.n == 0) continue;
-    hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(jb.n, 256)), dim3(256), 0, st, jb.scalars, jb.n, c, Wd, plan, jb.scalars_mode,
-                       jb.inf_flags, merged, jb.table_stride, (uint32_t)(k * B), ctx->digits + (size_t)k * Wd * ctx->max_n, ctx->counts);
+    dj.scalars[k] = jobs[k].scalars; dj.inf_flags[k] = jobs[k].inf_flags; dj.n[k] = jobs[k].n; dj.tab_stride[k] = jobs[k].table_stride;
+    dj.mode[k] = jobs[k].scalars_mode;
+    if (jobs[k].n > n_max) n_max = jobs[k].n;
   }
+  const size_t digits_per_job = (size_t)Wd * ctx->max_n;
+  hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(n_max, 256), K), dim3(256), 0, st, dj, c, Wd, plan, merged, (uint32_t)B, digits_per_job, ctx->digits,
+                     ctx->counts);
   unsigned sb = nblk(nb, 1024);
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->counts, ctx->offsets, ctx->block_tot, nb);
   hipLaunchKernelGGL(k_scan_tot, dim3(1), dim3(1024), 0, st, ctx->block_tot, (size_t)sb);
   hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, ctx->offsets, ctx->block_tot, nb);
   BasePtrs bp;
   for (int k = 0; k < MSM_MAX_JOBS; k++) bp.p[k] = jobs[k < K ? k : 0].bases;
-  for (int k = 0; k < K; k++) {
-    const MsmJob& jb = jobs[k];
-    if (jb.n == 0) continue;
-    hipLaunchKernelGGL(k_scatter, dim3(nblk(jb.n, 256)), dim3(256), 0, st, ctx->digits + (size_t)k * Wd * ctx->max_n, jb.n, c, Wd, merged,
-                       jb.table_stride, (uint32_t)(k * B), ctx->offsets, ctx->cursor, ctx->entries);
-  }
+  hipLaunchKernelGGL(k_scatter, dim3(nblk(n_max, 256), K), dim3(256), 0, st, dj, ctx->digits, digits_per_job, c, Wd, merged, (uint32_t)B, ctx->offsets,
+                     ctx->cursor, ctx->entries);
   const int bshift = merged ? c - 1 : 31;     // bucket -> job
   if (ctx->aff_levels > 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));     // the timed accumulation includes the affine levels
   // ---- batched-affine levels: the sorted list is summed pairwise inside every bucket, ctx->aff_levels times
@@ -1111,7 +1157,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   }
   const bool dense = ctx->aff_levels > 0;
   if (dense) bp.p[0] = ctx->pbuf[(ctx->aff_levels - 1) & 1];
-  HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 4, st));   // block_tot[0] is reused as the max-span cell (scans are done)
+  HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 8, st));   // block_tot[0] is reused as the max-span cell, [1] as the length of fix_list (scans are done)
   // slice length for THIS n (the plan's slot array is sized for max_n)
   uint32_t S_run, T_run;
   {
@@ -1133,16 +1179,13 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     hipLaunchKernelGGL(k_accumulate<MSM_MAX_JOBS>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off,
                        cur_cnt, (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
-  for (uint32_t d = 1; d < T_run; d <<= 1) {
-    // d = 1 touches up to every slice (throughput-bound: one lane per addition); later rounds only serve
-    // oversized buckets and are latency-bound (a quad per addition)
-    if (d == 1)
-      hipLaunchKernelGGL(k_fixup_round<false>, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, T_run,
-                         d, ctx->block_tot + 0, ctx->buckets, ctx->slot_stride);
-    else
-      hipLaunchKernelGGL(k_fixup_round<true>, dim3(nblk((size_t)T_run * 4, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run,
-                         T_run, d, ctx->block_tot + 0, ctx->buckets, ctx->slot_stride);
-  }
+  // the first round touches up to every slice (throughput-bound: one lane per addition) and lists the buckets of more than two
+  // pieces; their remaining rounds are latency-bound (a quad per addition) and run in one launch
+  if (T_run > 1)
+    hipLaunchKernelGGL(k_fixup_round<false>, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, T_run,
+                       1u, ctx->block_tot + 0, ctx->buckets, ctx->slot_stride, ctx->block_tot + 1, ctx->fix_list);
+  if (T_run > 2)
+    hipLaunchKernelGGL(k_fixup_tree, dim3(128), dim3(256), 0, st, ctx->block_tot + 1, ctx->fix_list, (uint32_t)nb, ctx->buckets, ctx->slot_stride);
   hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, T_run,
                      ctx->buckets, ctx->slot_stride);
   HIP_TRY(hipGetLastError());

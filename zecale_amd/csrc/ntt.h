@@ -12,6 +12,7 @@ namespace zkhip {
 // other: with K = 2^ntt_layout_logk(log_d) and N2 = 2^log_d / K, element k1 + K*k2 lives at k1*N2 + k2.  in_transposed says on
 // which side the input is (smaller vectors: natural on both sides, ntt_layout_logk = 0).
 int ntt_dev_packed(uint32_t* d_data, int log_d, int inverse, int coset, int in_transposed, hipStream_t st, char* err, size_t errlen);
+int ntt_dev_packed_batch(uint32_t* const* d_bufs, int nbuf, int log_d, int inverse, int coset, int in_transposed, hipStream_t st, char* err, size_t errlen);   // up to 3 vectors, same launches
 int ntt_layout_logk(int log_d);
 int ntt_dev_abi(uint64_t* d_data, int log_d, int inverse, int coset, char* err, size_t errlen);
 void fr_abi_to_dev(const uint64_t* d_in, uint32_t* d_out, size_t n, hipStream_t st);

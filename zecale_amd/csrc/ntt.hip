@@ -88,8 +88,9 @@ __device__ __forceinline__ FrD pow_tab(const uint32_t* __restrict__ lo, const ui
   return fp_mul(fr_load14(lo + (size_t)(e & 1023u) * 14), fr_load14(hi + (size_t)(e >> 10) * 14));
 }
 
+constexpr int NTT_MAX_BATCH = 3;
 struct PassArgs {
-  uint32_t* data;           // packed elements, transformed in place
+  uint32_t* data[NTT_MAX_BATCH];   // packed elements, transformed in place; blockIdx.y picks the vector (same transform on each)
   uint32_t strided;         // 1: sub-transform q is column q (element j at q + j*S); 0: row q (element j at q*K + j)
   uint32_t S;               // row length of the strided pass
   const uint32_t* tw;       // stage twiddles, heap order: stage s (butterflies of span 2^s) entry jj at 2^(s-1) + jj (14 limbs each)
@@ -108,6 +109,7 @@ __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs 
   __shared__ uint32_t lds[14 * E];
   const uint32_t tid = threadIdx.x;
   const uint32_t q0 = blockIdx.x * C;
+  uint32_t* const data = a.data[blockIdx.y];
   constexpr uint32_t EPT = (E + T - 1) / T;
   // ---- load: C*48 contiguous bytes per row in the strided pass, the whole tile contiguous in the other
 #pragma unroll
@@ -118,7 +120,7 @@ __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs 
     if (a.strided) { cc = e & (C - 1); j = e >> LOGC; } else { j = e & (K - 1); cc = e >> LOGK; }
     const uint32_t q = q0 + cc;
     const size_t loc = a.strided ? (size_t)q + (size_t)j * a.S : ((size_t)q << LOGK) + j;
-    const FrD v = fr_load12(a.data + loc * 12);
+    const FrD v = fr_load12(data + loc * 12);
     const uint32_t rj = LOGK ? (__brev(j) >> ((32 - LOGK) & 31)) : 0u;     // (LOGK = 0: a transform of size 1)
 #pragma unroll
     for (int i = 0; i < 14; i++) lds[i * E + cc * K + rj] = v.l[i];
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs 
     if (a.mid) v = fp_mul(v, fr_load12(a.mid + loc * 12));
     if (a.post_k) v = fp_mul(v, fr_load14(a.post_k + (size_t)k * 14));
     if (a.post_const) v = fp_mul(v, fr_load14(a.post_const));
-    fr_store12(a.data + loc * 12, v);
+    fr_store12(data + loc * 12, v);
   }
 }
 
@@ -346,7 +348,9 @@ static int get_tables(int log_d, int inverse, NttTables** out, char* err, size_t
 
 template <int LOGK, int LOGC>
 static void launch_pass(const PassArgs& a, uint32_t groups, hipStream_t st) {
-  hipLaunchKernelGGL((k_ntt_pass<LOGK, LOGC>), dim3(groups), dim3(pass_threads(LOGK, LOGC)), 0, st, a);
+  uint32_t nbuf = 1;
+  while (nbuf < NTT_MAX_BATCH && a.data[nbuf]) nbuf++;
+  hipLaunchKernelGGL((k_ntt_pass<LOGK, LOGC>), dim3(groups, nbuf), dim3(pass_threads(LOGK, LOGC)), 0, st, a);
 }
 // One workgroup per sub-transform up to 2^18 elements (the passes are latency-bound there: as many workgroups as possible);
 // beyond, 2048 elements per workgroup (adjacent sub-transforms: C * 48 contiguous bytes per row of the strided pass).
@@ -405,14 +409,22 @@ static int get_mid_full(NttTables* t, int inverse, int coset, int in_transposed,
 // Transform `d_data` (packed device form, 2^log_d elements) in place.  Vectors of 2^12 elements and more are in natural order on
 // one side and in transposed order on the other (ntt_layout_logk): in_transposed says which side the input is.
 int ntt_dev_packed(uint32_t* d_data, int log_d, int inverse, int coset, int in_transposed, hipStream_t st, char* err, size_t errlen) {
+  uint32_t* one[1] = {d_data};
+  return ntt_dev_packed_batch(one, 1, log_d, inverse, coset, in_transposed, st, err, errlen);
+}
+
+// the same transform on up to NTT_MAX_BATCH vectors in the same launches (the A, B, C vectors of the QAP map)
+int ntt_dev_packed_batch(uint32_t* const* d_bufs, int nbuf, int log_d, int inverse, int coset, int in_transposed, hipStream_t st, char* err, size_t errlen) {
+  if (nbuf < 1 || nbuf > NTT_MAX_BATCH) { snprintf(err, errlen, "ntt: 1 to %d vectors per call", NTT_MAX_BATCH); return ZKHIP_ERR_ARG; }
   if (log_d < 0 || log_d > 22) { snprintf(err, errlen, "ntt: log_d must be in [0, 22]"); return ZKHIP_ERR_ARG; }
   NttTables* t;
   int rc = get_tables(log_d, inverse, &t, err, errlen);
   if (rc != ZKHIP_OK) return rc;
   const uint32_t K = 1u << t->log_k, N2 = 1u << t->log_n2;
   PassArgs a;
+  auto set_data = [&](PassArgs& p) { for (int i = 0; i < nbuf; i++) p.data[i] = d_bufs[i]; };
   memset(&a, 0, sizeof a);
-  a.data = d_data;
+  set_data(a);
   if (t->log_n2 == 0) {
     // one workgroup: the whole transform in LDS
     a.strided = 0; a.tw = t->twA;
@@ -432,7 +444,7 @@ int ntt_dev_packed(uint32_t* d_data, int log_d, int inverse, int coset, int in_t
       launch_pass_dyn(t->log_k, log_d <= 18, a, N2, st);
       // pass 2: rows k1 (contiguous); output k2 is X[k1 + K*k2], left in the row
       memset(&a, 0, sizeof a);
-      a.data = d_data; a.strided = 0; a.tw = t->twB;
+      set_data(a); a.strided = 0; a.tw = t->twB;
       if (inverse && coset) a.post_k = t->post_k[0];
       launch_pass_dyn(t->log_n2, log_d <= 18, a, K, st);
     } else {
@@ -441,7 +453,7 @@ int ntt_dev_packed(uint32_t* d_data, int log_d, int inverse, int coset, int in_t
       launch_pass_dyn(t->log_n2, log_d <= 18, a, K, st);
       // pass 2: columns k1' (stride N2); output k2' is X[k1' + N2*k2'] at k2'*N2 + k1'
       memset(&a, 0, sizeof a);
-      a.data = d_data; a.strided = 1; a.S = N2; a.tw = t->twA;
+      set_data(a); a.strided = 1; a.S = N2; a.tw = t->twA;
       if (inverse && coset) a.post_k = t->post_k[1];
       launch_pass_dyn(t->log_k, log_d <= 18, a, N2, st);
     }

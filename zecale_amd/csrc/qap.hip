@@ -49,12 +49,20 @@ __device__ __forceinline__ FrD fr_shfl_down(const FrD& v, int delta) {
 
 // LG: log2 of the lanes per row - 4 for a proof alone (latency), 2 for a prover that shares the chip (a quarter of the lane-cycles:
 // every lane of a row's group runs the fold and the final normalisations whether it had terms or not).
+// the three matrices of a system in one launch: blockIdx.y selects A, B or C
+struct Spmv3 {
+  const uint32_t *row_ptr[3], *col[3], *val[3];
+  uint32_t* out[3];
+  uint32_t extra[3];        // n_primary + 1 for A, else 0
+};
 template <int LG>
-__global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-                                               const uint32_t* __restrict__ val, const uint32_t* __restrict__ z,
-                                               uint32_t n, uint32_t extra /* n_primary + 1 for A, else 0 */, uint32_t d,
-                                               int log_k, int log_n2 /* log_k != 0: out in the NTT's transposed order */,
-                                               uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_spmv(Spmv3 m, const uint32_t* __restrict__ z, uint32_t n, uint32_t d,
+                                               int log_k, int log_n2 /* log_k != 0: out in the NTT's transposed order */) {
+  const uint32_t* __restrict__ row_ptr = m.row_ptr[blockIdx.y];
+  const uint32_t* __restrict__ col = m.col[blockIdx.y];
+  const uint32_t* __restrict__ val = m.val[blockIdx.y];
+  uint32_t* __restrict__ out = m.out[blockIdx.y];
+  const uint32_t extra = m.extra[blockIdx.y];
   uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
   constexpr uint32_t LANES = 1u << LG;
   uint32_t i = gt >> LG, sub = gt & (LANES - 1);
@@ -189,14 +197,13 @@ static void spmv3(R1csDev* r, hipStream_t st) {
   uint32_t n = (uint32_t)r->n_constraints, d = 1u << r->log_d;
   const int lk = ntt_layout_logk(r->log_d), ln = lk ? r->log_d - lk : 0;
   const CsrDev* M[3] = {&r->A, &r->B, &r->C};
-  uint32_t* out[3] = {r->bufA, r->bufB, r->bufC};
-  for (int k = 0; k < 3; k++) {
-    const uint32_t extra = k == 0 ? (uint32_t)r->n_primary + 1 : 0u;
-    if (r->spmv_log_lanes == 2)
-      hipLaunchKernelGGL(k_spmv<2>, dim3((unsigned)(((size_t)d * 4 + 255) / 256)), dim3(256), 0, st, M[k]->row_ptr, M[k]->col, M[k]->val, r->z, n, extra, d, lk, ln, out[k]);
-    else
-      hipLaunchKernelGGL(k_spmv<4>, dim3((unsigned)(((size_t)d * 16 + 255) / 256)), dim3(256), 0, st, M[k]->row_ptr, M[k]->col, M[k]->val, r->z, n, extra, d, lk, ln, out[k]);
-  }
+  Spmv3 m;
+  for (int k = 0; k < 3; k++) { m.row_ptr[k] = M[k]->row_ptr; m.col[k] = M[k]->col; m.val[k] = M[k]->val; m.extra[k] = k == 0 ? (uint32_t)r->n_primary + 1 : 0u; }
+  m.out[0] = r->bufA; m.out[1] = r->bufB; m.out[2] = r->bufC;
+  if (r->spmv_log_lanes == 2)
+    hipLaunchKernelGGL(k_spmv<2>, dim3((unsigned)(((size_t)d * 4 + 255) / 256), 3), dim3(256), 0, st, m, r->z, n, d, lk, ln);
+  else
+    hipLaunchKernelGGL(k_spmv<4>, dim3((unsigned)(((size_t)d * 16 + 255) / 256), 3), dim3(256), 0, st, m, r->z, n, d, lk, ln);
 }
 
 int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, size_t errlen) {
@@ -206,10 +213,8 @@ int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, si
   spmv3(r, st);
   int rc;
   uint32_t* bufs[3] = {r->bufA, r->bufB, r->bufC};
-  for (int k = 0; k < 3; k++) {
-    if ((rc = ntt_dev_packed(bufs[k], lg, 1, 0, 1, st, err, errlen)) != ZKHIP_OK) return rc;   // iFFT: transposed -> natural
-    if ((rc = ntt_dev_packed(bufs[k], lg, 0, 1, 0, st, err, errlen)) != ZKHIP_OK) return rc;   // cosetFFT: natural -> transposed
-  }
+  if ((rc = ntt_dev_packed_batch(bufs, 3, lg, 1, 0, 1, st, err, errlen)) != ZKHIP_OK) return rc;   // iFFT of A, B, C: transposed -> natural
+  if ((rc = ntt_dev_packed_batch(bufs, 3, lg, 0, 1, 0, st, err, errlen)) != ZKHIP_OK) return rc;   // cosetFFT: natural -> transposed
   hipLaunchKernelGGL(k_h_pointwise, dim3((d + 255) / 256), dim3(256), 0, st, r->bufA, r->bufB, r->bufC, r->zinv, d);   // (any order)
   if ((rc = ntt_dev_packed(r->bufA, lg, 1, 1, 1, st, err, errlen)) != ZKHIP_OK) return rc;       // icosetFFT: transposed -> natural
   Q_HIP(hipGetLastError());
