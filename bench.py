@@ -656,7 +656,7 @@ def prover_secondary(zkhip, args, steps=6, warmup=1):
     return out
 
 
-def wrapping_prover_secondary(zkhip, args, steps=240, warmup=24, cpu=True):
+def wrapping_prover_secondary(zkhip, args, steps=480, warmup=48, cpu=True):
     """The other half of BASELINE.json's metric, measured in the same run after the MSM's timed region (N = 1 only): wrapping
     proofs/s of the real batch-2 aggregator circuit through the streaming prover, witness generation included, nothing cached.
     The same loop as `--workload aggregator`; the last proof is verified (host pairing check) before the number is reported.
