@@ -31,6 +31,7 @@ struct MsmCtx {
   uint16_t win_off[96];
   uint8_t win_bits[96];
   size_t B, max_n;
+  int one_stream;       // 1: the whole launch sequence on `stream` (a prover that shares the chip); 0: row / column trees side by side
   uint32_t quad_below;  // reduction launches with fewer outputs than this spread an addition over four lanes (latency) instead of one (total work)
   uint32_t S, T, slot_stride;   // slice length, slice count, words per row of the slot array
   hipStream_t stream, stream2;

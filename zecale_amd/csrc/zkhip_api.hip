@@ -605,7 +605,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     // lists, one reduction chain with a bucket window per MSM) - a fifth of the launches, five times the lanes in each.
     // (A plan that does not fit the engine's 32-bit entry positions is refused with ZKHIP_ERR_ARG: one sequence per MSM then.)
     rc = ensure_ctx(&ps.ctx[4], &ps.ready[4], maxlen, tc, 5);
-    if (rc == ZKHIP_OK && ps.quad_below) ps.ctx[4].quad_below = ps.quad_below;
+    if (rc == ZKHIP_OK && ps.quad_below) { ps.ctx[4].quad_below = ps.quad_below; ps.ctx[4].one_stream = 1; }
     if (rc == ZKHIP_ERR_ARG) batched = false;
     else if (rc != ZKHIP_OK) return rc;
   }
@@ -629,7 +629,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   MsmCtx* ctxs[5];
   for (int k = 0; k < nctx; k++) {
     if ((rc = ensure_ctx(&ps.ctx[k], &ps.ready[k], maxlen, tc)) != ZKHIP_OK) return rc;
-    if (ps.quad_below) ps.ctx[k].quad_below = ps.quad_below;
+    if (ps.quad_below) { ps.ctx[k].quad_below = ps.quad_below; ps.ctx[k].one_stream = 1; }
     ctxs[k] = &ps.ctx[k];
   }
   clk::time_point tl[5];
@@ -781,7 +781,7 @@ int zkhip_prover_set_streaming(zkhip_prover* p, int on) {
   // measured on the wrapping circuit: 212 -> 228 proofs/s with six provers in flight, 107 -> 98 one at a time
   p->ps.quad_below = on ? 1024u : 0u;
   p->rd->spmv_log_lanes = on ? 2 : 4;
-  for (int k = 0; k < 5; k++) if (p->ps.ready[k]) p->ps.ctx[k].quad_below = on ? 1024u : 65536u;
+  for (int k = 0; k < 5; k++) if (p->ps.ready[k]) { p->ps.ctx[k].quad_below = on ? 1024u : 65536u; p->ps.ctx[k].one_stream = on ? 1 : 0; }
   return ZKHIP_OK;
 }
 
