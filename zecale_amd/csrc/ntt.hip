@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <mutex>
@@ -352,6 +353,7 @@ static void launch_pass(const PassArgs& a, uint32_t groups, hipStream_t st) {
   while (nbuf < NTT_MAX_BATCH && a.data[nbuf]) nbuf++;
   hipLaunchKernelGGL((k_ntt_pass<LOGK, LOGC>), dim3(groups, nbuf), dim3(pass_threads(LOGK, LOGC)), 0, st, a);
 }
+static int one_each_max() { static const int v = [] { const char* e = getenv("ZKHIP_NTT_ONE_EACH_MAX"); int x = e ? atoi(e) : 18; return x < 0 || x > 22 ? 18 : x; }(); return v; }
 // One workgroup per sub-transform up to 2^18 elements (the passes are latency-bound there: as many workgroups as possible);
 // beyond, 2048 elements per workgroup (adjacent sub-transforms: C * 48 contiguous bytes per row of the strided pass).
 static void launch_pass_dyn(int log_k, bool one_each, const PassArgs& a, uint32_t n_sub, hipStream_t st) {
@@ -441,21 +443,21 @@ int ntt_dev_packed_batch(uint32_t* const* d_bufs, int nbuf, int log_d, int inver
       // pass 1: columns c (elements c + N2*j), twiddle omega^(c*k1)
       a.strided = 1; a.S = N2; a.tw = t->twA;
       if (!inverse && coset) { a.tw = t->twA_coset; a.tw_scaled = 1; }
-      launch_pass_dyn(t->log_k, log_d <= 18, a, N2, st);
+      launch_pass_dyn(t->log_k, log_d <= one_each_max(), a, N2, st);
       // pass 2: rows k1 (contiguous); output k2 is X[k1 + K*k2], left in the row
       memset(&a, 0, sizeof a);
       set_data(a); a.strided = 0; a.tw = t->twB;
       if (inverse && coset) a.post_k = t->post_k[0];
-      launch_pass_dyn(t->log_n2, log_d <= 18, a, K, st);
+      launch_pass_dyn(t->log_n2, log_d <= one_each_max(), a, K, st);
     } else {
       // pass 1: rows i2 (element i1*K + i2 of the input lives at i2*N2 + i1), twiddle omega^(i2*k1')
       a.strided = 0; a.tw = t->twB;
-      launch_pass_dyn(t->log_n2, log_d <= 18, a, K, st);
+      launch_pass_dyn(t->log_n2, log_d <= one_each_max(), a, K, st);
       // pass 2: columns k1' (stride N2); output k2' is X[k1' + N2*k2'] at k2'*N2 + k1'
       memset(&a, 0, sizeof a);
       set_data(a); a.strided = 1; a.S = N2; a.tw = t->twA;
       if (inverse && coset) a.post_k = t->post_k[1];
-      launch_pass_dyn(t->log_k, log_d <= 18, a, N2, st);
+      launch_pass_dyn(t->log_k, log_d <= one_each_max(), a, N2, st);
     }
   }
   hipError_t e = hipGetLastError();
