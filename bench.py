@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one MSM / one proof in flight (per-phase timings) instead of the streaming forms")
     ap.add_argument("--gpu-slots", type=int, default=14, help="aggregator pipeline: proofs in flight on the GPU")
     ap.add_argument("--witness-workers", type=int, default=8, help="aggregator pipeline: witnesses generated side by side (3 host threads each)")
+    ap.add_argument("--nested-inputs", type=int, default=1, help="aggregator workload: inputs per nested proof (9 = the shape of a Zeth proof, BASELINE configs[4])")
     ap.add_argument("--gpu-witness", action="store_true", help="aggregator pipeline: the witness workers generate the assignment on the GPU")
     ap.add_argument("--cpu-sample-log", type=int, default=20)
     ap.add_argument("--no-secondary", action="store_true", help="msm workload: skip the measurements that follow the timed region")
@@ -276,8 +277,8 @@ def main():
         units_per_step = n * world
     elif args.workload == "aggregator":
         # the real wrapping circuit on the committed nested fixtures (reference testdata/dummy_app: vk.json, extproof1/2.json)
-        nvk_l, npr, nin, trapdoor = aggregator_inputs()
-        agg = zkhip.AggregatorCircuit(2, 1)
+        nvk_l, npr, nin, trapdoor = aggregator_inputs(args.nested_inputs)
+        agg = zkhip.AggregatorCircuit(2, args.nested_inputs)
         desc = zkhip.r1cs_desc_from_aggregator(agg)
         kp = zkhip.Keypair(desc, *trapdoor)
         crs, r1 = kp.upload_crs(), zkhip.r1cs_from_desc(desc)
@@ -396,8 +397,12 @@ def main():
         elif args.workload == "aggregator":
             value, unit = units_per_step * args.steps / dt, "proofs/s"
             metric = "wrapping proofs/sec (batch-2 BLS12_377 -> BW6_761 aggregation, %d constraints)" % n
-            workload = ("BASELINE configs[0]/[2] shape: aggregator circuit batch=2 dummy_app proofs (reference fixtures), host witness "
-                        "generation + Groth16 BW6_761 prover on the GPU, end to end")
+            workload = ("BASELINE configs[0]/[2] shape: aggregator circuit batch=2 dummy_app proofs (reference fixtures), %s witness "
+                        "generation + Groth16 BW6_761 prover on the GPU, end to end" % ("GPU" if args.gpu_witness else "host"))
+            if args.nested_inputs > 1:
+                workload = ("BASELINE configs[4] shape on one GPU: aggregator circuit batch=2 with %d inputs per nested proof (a Zeth proof has 9; "
+                            "fixture points, result bits 0 - same circuit, witness and prover work as valid proofs), %s witness generation + "
+                            "Groth16 BW6_761 prover on the GPU, end to end" % (args.nested_inputs, "GPU" if args.gpu_witness else "host"))
             m_, l_, d_ = agg.num_variables, agg.num_primary_inputs(), 1 << r1.log_d
             terms_in_kernel = (3 * m_ + (d_ - 1) + (m_ - l_ - 1)) if (tw_batched(extra, args)) else m_ - l_ - 1
             if args.serial:
@@ -604,9 +609,12 @@ class FullSizeProver:
         self.crs.free(); self.kp.free(); self.r1.free()
 
 
-def aggregator_inputs():
+def aggregator_inputs(inputs_per_proof=1):
     """Nested key and two nested proofs from the reference's data fixtures (tests/golden/dummy_app = testdata/dummy_app: vk.json,
-    extproof1.json, extproof2.json), decoded by the package's own JSON codec; toxic waste and (r, s) of the synthetic wrapping key."""
+    extproof1.json, extproof2.json), decoded by the package's own JSON codec; toxic waste and (r, s) of the synthetic wrapping key.
+    inputs_per_proof = 9 gives the SHAPE of a Zeth nested proof (aggregator_test.cpp:222-254; no Zeth fixtures exist): the key's
+    ABC vector is padded with other curve points of the fixtures and every proof gets nine inputs, so the nested proofs do not
+    verify (result bits 0) - the wrapping circuit, its witness and its proof cost exactly what valid ones would."""
     from zecale_amd import encoding as E
     gold = os.path.join(ROOT, "tests", "golden", "dummy_app")
     load = lambda name: json.load(open(os.path.join(gold, name)))
@@ -614,6 +622,14 @@ def aggregator_inputs():
     txs = [E.nested_transaction_from_json(load("extproof%d.json" % k)) for k in (1, 2)]
     npr = np.concatenate([t[1] for t in txs])
     nin = np.concatenate([t[2] for t in txs])
+    if inputs_per_proof > 1:
+        k = inputs_per_proof
+        more = [E.nested_transaction_from_json(load("extproof%d.json" % j)) for j in range(1, 7)]
+        g1_points = [t[1][:12] for t in more] + [t[1][36:48] for t in more]          # A and C of the six fixtures: points of G1
+        abc = np.concatenate([nvk_l[60:]] + g1_points)[: 12 * (k + 1)]
+        assert len(abc) == 12 * (k + 1), "not enough fixture points for that many inputs"
+        nvk_l = np.concatenate([nvk_l[:60], abc])
+        nin = np.concatenate([np.concatenate([(t[2].reshape(-1, 6)[0] + np.array([j, 0, 0, 0, 0, 0], dtype=np.uint64)).reshape(1, 6) for j in range(k)]) for t in txs])
     fr = lambda x: np.array(E.fr_from_json(hex(x)), dtype=np.uint64)
     trapdoor = [fr(0x1234567), fr(0x2345678), fr(0x3456789), fr(0x456789a)]
     return nvk_l, npr, nin, trapdoor
