@@ -687,7 +687,7 @@ def wrapping_prover_secondary(zkhip, args, steps=480, warmup=48, cpu=True):
     pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers)
     depth = args.gpu_slots + args.witness_workers + 2
 
-    def run(k):
+    def run(k):                                        # (reads `pipe` and `depth` of the enclosing scope at call time)
         tickets, last = [], None
         for _ in range(k):
             tickets.append(pipe.submit(nvk_l, npr, nin, rr, ss))
@@ -709,6 +709,24 @@ def wrapping_prover_secondary(zkhip, args, steps=480, warmup=48, cpu=True):
            "host_cores_busy": round(((c1.user + c1.system) - (c0.user + c0.system)) / dt, 2),
            "includes": "host witness generation + QAP + 5 MSMs + host tail per proof, reference dummy_app fixtures, nothing cached"}
     pipe.free()
+    # the same stream with the assignment generated ON THE GPU (SURVEY 8 rows a2-a5 as a kernel: witness.hip), two batcher threads
+    try:
+        gpipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=2, gpu_witness=True)
+        pipe, depth_host, depth = gpipe, depth, 96              # (launches of 16 witnesses: the stream is kept several launches deep)
+        run(2 * warmup)
+        c0g, t0g = os.times(), time.time()
+        prim_g, proof_g = run(steps)
+        dtg = time.time() - t0g
+        c1g = os.times()
+        out["gpu_witness"] = {"value": round(steps / dtg, 3), "unit": "proofs/s", "steps": steps, "ms_per_step": round(dtg / steps * 1e3, 3),
+                              "host_cores_busy": round(((c1g.user + c1g.system) - (c0g.user + c0g.system)) / dtg, 2),
+                              "last_proof_verifies": bool(zkhip.groth16_verify(kp.vk(), prim_g, proof_g)),
+                              "proof_equals_host_witness_proof": bool((proof_g == proof).all()),
+                              "includes": "GPU witness generation (k_witness, 16 witnesses per launch) + QAP + 5 MSMs + host tail per proof"}
+        gpipe.free()
+        depth = depth_host
+    except Exception as e:                                      # (reported, never silently dropped)
+        out["gpu_witness"] = {"error": str(e)}
     # one proof on its own: the accumulation kernel's time and the terms it processed
     r1 = zkhip.r1cs_from_desc(desc)
     t = time.time()
