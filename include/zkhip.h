@@ -74,6 +74,10 @@ void zkhip_bases_free(zkhip_bases* b);
 int zkhip_bases_precompute(zkhip_bases* b, int c);
 int zkhip_bases_table_window(const zkhip_bases* b);      /* 0: no table */
 int zkhip_set_crs_precompute(int on);
+/* on = 1: window tables built from now on hold EVERY bit position (378 levels, sixteen times the memory) and scalars are recoded in
+   non-adjacent form: an eighth fewer point additions per scalar, but measured slower once the tables outgrow the TLB (DESIGN.md
+   section 5) - off by default; 0: one level per window; -1: the environment's ZKHIP_TABLE_NAF decides.  Results are identical. */
+int zkhip_set_table_naf(int on);
 /* Table-backed keys of up to 2^20 points per query vector: the five MSMs of a proof go through one launch sequence
  * (default on; off = one launch sequence per MSM, 2 or 5 of them in flight).  A tuning / comparison switch. */
 int zkhip_set_batch_msms(int on);

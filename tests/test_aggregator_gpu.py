@@ -73,6 +73,29 @@ def test_prover_instances_match_the_plain_entry_point(zk):
     crs.free(); r1.free(); kp.free(); agg.free()
 
 
+def test_naf_table_key_proves_the_same(zk):
+    """The proving key's window tables with every bit position and the scalars in non-adjacent form (zkhip_set_table_naf): the five
+    MSMs of a wrapping proof - real witness scalars, a B query with points at infinity, the H coefficients - give the same proof
+    as the default tables, through the plain entry point and through a streaming prover instance."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    (pa, ia), (pb, ib) = proofs[0], proofs[1]
+    z = agg.witness(nvk_l, np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)]), np.array([fr_limbs(ia[0]), fr_limbs(ib[0])]))
+    r, s_ = fr_limbs(0xabc), fr_limbs(0xdef)
+    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
+    expected = zk.groth16_prove(crs, r1, z, r, s_)
+    crs.free()
+    zk.set_table_naf(1)
+    try:
+        crs2 = kp.upload_crs()
+    finally:
+        zk.set_table_naf(-1)
+    assert (zk.groth16_prove(crs2, r1, z, r, s_) == expected).all()
+    p = zk.Prover(crs2, desc)
+    p.set_streaming(True)
+    assert (p.prove(z, r, s_) == expected).all()
+    p.free(); crs2.free(); r1.free(); kp.free(); agg.free()
+
+
 @pytest.mark.parametrize("slots,workers", [(1, 1), (3, 2)])
 def test_pipeline_matches_serial_path(zk, slots, workers):
     """Streaming aggregator (zkhip_aggregator_pipeline_*): every extended proof equals witness + groth16_prove done one

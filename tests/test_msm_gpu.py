@@ -26,6 +26,15 @@ def affine_levels(request, zk):
     zk.set_affine_levels(-1)
 
 
+@pytest.fixture(params=[0, 1], ids=["windows", "naf"])
+def table_kind(request, zk):
+    """The table-backed cases run with both kinds of table: one level per window (default), and every bit position with the scalars
+    recoded in non-adjacent form (zkhip_set_table_naf: odd signed digits at arbitrary positions, the same group element)."""
+    zk.set_table_naf(request.param)
+    yield request.param
+    zk.set_table_naf(-1)
+
+
 def _msm_aff(zk, bases, scal, montgomery=True, window=0):
     zk.set_msm_window(window)
     return zk.jac_to_affine(zk.msm_raw(bases, scal, montgomery=montgomery))
@@ -159,6 +168,7 @@ def test_heavy_buckets_are_stitched(zk, oracle_lib):
 
 # ---- window tables (zkhip_bases_precompute): same group element as the plain path and as the oracle ----
 
+@pytest.mark.usefixtures("table_kind")
 @pytest.mark.parametrize("window", [0, 5, 9, 13])
 def test_table_golden_vectors(zk, window):
     """Every golden MSM vector through a table-backed base set (includes infinity bases, P + (-P), r - 1)."""
@@ -172,6 +182,7 @@ def test_table_golden_vectors(zk, window):
         assert got == pt_from_json(case["result"]), case["name"]
 
 
+@pytest.mark.usefixtures("table_kind")
 @pytest.mark.parametrize("n,window", [(1 << 10, 0), (5000, 11), (1 << 14, 0), (1 << 14, 17), (3001, 20)])
 def test_table_random_vs_oracle(zk, oracle_lib, n, window):
     O = oracle_lib
@@ -191,6 +202,7 @@ def test_table_random_vs_oracle(zk, oracle_lib, n, window):
     b.free()
 
 
+@pytest.mark.usefixtures("table_kind")
 def test_table_g2_and_witness_like(zk, oracle_lib):
     O = oracle_lib
     n = 4096
@@ -205,6 +217,7 @@ def test_table_g2_and_witness_like(zk, oracle_lib):
     b.free()
 
 
+@pytest.mark.usefixtures("table_kind")
 def test_table_point_of_order_two(zk, oracle_lib):
     """(1, 0) lies on G1's curve y^2 = x^3 - 1 and has order 2: every table level above 0 is the point at infinity.
     Not a proving-key element, but zkhip_msm is a general group operation."""
@@ -233,6 +246,7 @@ def test_table_full_size_2_20_matches_plain_path(zk):
     b.free()
 
 
+@pytest.mark.usefixtures("table_kind")
 def test_submit_collect_two_in_flight(zk, oracle_lib):
     """zkhip_msm_submit / zkhip_msm_collect: two MSMs in flight on two slots return what the blocking call returns;
     a busy slot refuses a second submit, an idle slot has nothing to collect."""

@@ -1,7 +1,7 @@
 """Randomised soak of the MSM against the CPU oracle (test infrastructure: run by hand on the GPU box, like the tests).
 Adversarial mixes: repeated points (doubling inside buckets), P / -P pairs (cancellation to infinity), bases at infinity,
 scalars 0 / 1 / r-1 / equal scalars (heavy buckets), random sizes, plain and table-backed base sets with random windows,
-sub-ranges.  Usage: python tools/soak_msm.py [cases]"""
+sub-ranges, both kinds of window table (one level per window / every bit position with NAF scalars).  Usage: python tools/soak_msm.py [cases]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -40,7 +40,9 @@ for case in range(cases):
     if mode == 0:
         zkhip.set_msm_window(int(rng.choice([0, 4, 7, 11, 14])))
     else:
-        b.precompute(int(rng.choice([0, 4, 9, 13, 17, 20])))
+        zkhip.set_table_naf(int(rng.integers(0, 2)))                                       # either kind of window table
+        b.precompute(int(rng.choice([0, 4, 9, 13, 17, 20, 22])))
+        zkhip.set_table_naf(-1)
     got = zkhip.jac_to_affine(b.msm(scal, montgomery=False))
     ok = (got == exp).all()
     if ok and n > 10:                                                                   # a sub-range too

@@ -26,7 +26,9 @@ struct MsmJob {
 struct MsmCtx {
   int c, W, L, logL;   // W: bucket windows (each owns 2^(c-1) buckets)
   int Wd;              // digits per scalar: W without a table; with a precomputed table all Wd digit positions share ONE bucket window
-  int merged;          // 1: bases are a table  table[w * stride + i] = 2^(c w) P_i  (msm_table_build)
+  int merged;          // 1: bases are a table  table[w * stride + i] = 2^(off_w) P_i  (msm_table_build), one digit per window;
+                       // 2: a table with EVERY bit position, table[j * stride + i] = 2^j P_i: scalars are recoded in width-(c+1)
+                       //    non-adjacent form (odd signed digits at arbitrary positions, 378 / (c + 2) of them on average)
   int K;               // merged plans: MSMs per launch sequence, one bucket window each (W == K); plain plans: 1
   uint16_t win_off[96];
   uint8_t win_bits[96];
@@ -73,10 +75,10 @@ int msm_finish_multi(MsmCtx* ctx, int K, uint64_t* out_jac);
 int msm_run(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
             int scalars_montgomery, size_t table_stride, uint64_t out_jac[36]);
 // levels of a window table for window size c
-static inline int msm_table_levels(int c) { return (378 + c - 1) / c; }
+static inline int msm_table_levels(int c, int naf = 0) { return naf ? 378 : (378 + c - 1) / c; }
 // d_table: levels x n points, level 0 (= the n base points) already in place; d_tinf: levels x n flags, level 0 in place.
 // Fills levels 1 .. levels-1:  table[w * n + i] = 2^(c w) P_i  in affine packed form.
-int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, char* errbuf, size_t errlen);
+int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, int naf, char* errbuf, size_t errlen);
 
 int fixed_base_mul(const uint64_t base_aff[24], const uint64_t* d_scalars, size_t n, int montgomery, uint64_t* d_out,
                    char* errbuf, size_t errlen);

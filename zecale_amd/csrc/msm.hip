@@ -113,6 +113,47 @@ __global__ void __launch_bounds__(256) k_scalar_digits(DigitJobs jobs, int c, in
   }
   w32[12] = 0;
   const uint32_t B = 1u << (c - 1);
+  if (merged == 2) {
+    // Width-(c+1) non-adjacent form: ODD signed digits |d| < 2^c at arbitrary bit positions, at least c+1 bits apart - 378 / (c + 2)
+    // digits on average instead of 378 / c, over the same 2^(c-1) buckets (bucket = (|d| - 1) / 2, weight 2 * bucket + 1: the
+    // reduction returns sum (bucket + 1) S_b and sum S_b, the finish makes 2 F - S of them).  The entry of a digit at bit position
+    // j points at level j of the table (2^j P_i).  A digit is stored as sign | position << 22 | magnitude (|d| < 2^22, position < 2^9).
+    __shared__ uint32_t s_w[13][256];
+#pragma unroll
+    for (int k = 0; k < 13; k++) s_w[k][threadIdx.x] = w32[k];
+    const int wbits = c + 1;
+    int pos = 0, slot = 0;
+    uint32_t carry = 0;
+    while (pos < 379 && slot < W) {
+      const int j = pos >> 5, sh = pos & 31;
+      uint64_t v = (uint64_t)s_w[j < 13 ? j : 12][threadIdx.x] >> sh;
+      if (j < 12) v |= (uint64_t)s_w[j + 1][threadIdx.x] << (32 - sh);
+      if (j >= 12) v = 0;
+      const uint32_t v32 = (uint32_t)v;
+      // bits + carry: skip the run that produces zeros (zeros without a carry, ones with it)
+      const uint32_t run = carry ? ~v32 : v32;
+      if ((run & 1u) == 0) { pos += run ? (__ffs((int)run) - 1) : 32; continue; }
+      uint32_t win = (v32 & ((1u << wbits) - 1)) + carry;            // odd
+      int32_t d;
+      if (win > (1u << (wbits - 1))) { d = (int32_t)win - (int32_t)(1u << wbits); carry = 1; }
+      else { d = (int32_t)win; carry = 0; }
+      const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+      const bool skip = skip0 || (inf_flags && pos > 0 && inf_flags[(size_t)pos * tab_stride + i]);      // 2^pos P_i = O
+      int32_t packed = 0;
+      if (!skip) packed = (int32_t)(mag | ((uint32_t)pos << 22) | (d < 0 ? 0x80000000u : 0u));
+      if (live) digits[(size_t)slot * n + i] = packed;
+      const bool hot = !skip && pos == 0 && d == 1;                  // "scalar == 1": one atomic per wave (see below)
+      const unsigned long long hot_mask = __ballot(hot);
+      if (hot_mask) {
+        if (hot && (__ffsll((long long)hot_mask) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&counts[bucket_base], (uint32_t)__popcll(hot_mask));
+      }
+      if (!skip && !hot) atomicAdd(&counts[(size_t)bucket_base + ((mag - 1) >> 1)], 1u);
+      slot++;
+      pos += wbits;
+    }
+    if (live) for (; slot < W; slot++) digits[(size_t)slot * n + i] = 0;
+    return;
+  }
   uint32_t carry = 0;
   for (int w = 0; w < W; w++) {
     const int bit = plan.off[w], cw = plan.bits[w];
@@ -208,6 +249,26 @@ __global__ void __launch_bounds__(256) k_scatter(DigitJobs jobs, const int32_t* 
   if (!live) i = n - 1;
   const uint32_t B = 1u << (c - 1);
   const uint32_t lane = threadIdx.x & 63;
+  if (merged == 2) {                                   // NAF digits: sign | position << 22 | magnitude (k_scalar_digits)
+    for (int w = 0; w < W; w++) {
+      const uint32_t pk = live ? (uint32_t)digits[(size_t)w * n + i] : 0u;
+      const uint32_t mag = pk & 0x3fffffu, pos_bit = (pk >> 22) & 0x1ffu;
+      const bool hot = mag == 1 && pos_bit == 0 && !(pk >> 31);
+      const unsigned long long hot_mask = __ballot(hot);
+      if (hot_mask) {
+        const int leader = __ffsll((long long)hot_mask) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&cursor[bucket_base], (uint32_t)__popcll(hot_mask));
+        base = __shfl(base, leader);
+        if (hot) entries[offsets[bucket_base] + base + (uint32_t)__popcll(hot_mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
+      }
+      if (mag == 0 || hot) continue;
+      const size_t b = (size_t)bucket_base + ((mag - 1) >> 1);
+      const uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
+      entries[pos] = (uint32_t)((size_t)pos_bit * tab_stride + i) | (pk & 0x80000000u);
+    }
+    return;
+  }
   for (int w = 0; w < W; w++) {
     int32_t sd = live ? digits[(size_t)w * n + i] : 0;
     const bool hot = (w == 0) && (sd == 1);            // wave-aggregated slot allocation for the hot bucket
@@ -698,8 +759,11 @@ __global__ void __launch_bounds__(64, 2) k_window_combine(uint32_t* __restrict__
 }
 
 // per window: R * (hi part) + (lo part), converted to ABI limbs
+// total (optional): the plain sums of the 2W groups (the last S of the k_seg chain); the lo group's is sum_b S_b of the window and
+// goes out behind the W weighted sums (the NAF finish needs it)
 __global__ void __launch_bounds__(64, 2) k_hilo_combine(uint32_t* __restrict__ work /* 2W */, int W, int lo_bits,
-                                                         uint64_t* __restrict__ out_abi /* W x 4 x 12 u64 */) {
+                                                         uint64_t* __restrict__ out_abi /* W x 4 x 12 u64 (+ W more with total) */,
+                                                         uint32_t* __restrict__ total /* 2W or null */) {
   int gt = blockIdx.x * blockDim.x + threadIdx.x, w = gt >> 2;
   const uint32_t q = (uint32_t)(gt & 3);
   if (w >= W) return;
@@ -708,6 +772,7 @@ __global__ void __launch_bounds__(64, 2) k_hilo_combine(uint32_t* __restrict__ w
   add_mem_quad(hi, lo, q);
   uint64_t* o = out_abi + (size_t)w * 48;
   fp_to_abi<FqParams>(mem_ld_lane(hi, q), o + 12 * q);            // lane q converts coordinate q
+  if (total) fp_to_abi<FqParams>(mem_ld_lane(make_ref(total, (uint32_t)(2 * W), (uint32_t)(W + w)), q), out_abi + (size_t)(W + w) * 48 + 12 * q);
 }
 
 // ---- batch fixed-base scalar multiplication: out[i] = k_i * G (the inner loop of Groth16 setup:
@@ -816,7 +881,7 @@ __device__ __forceinline__ XyzzRef make_ref5(uint32_t* base, uint32_t stride, ui
 }
 
 __global__ void __launch_bounds__(256, 2) k_table_build(AffPacked* __restrict__ table, uint8_t* __restrict__ tinf, size_t n, size_t i0,
-                                                         uint32_t cn, WindowPlan plan, int levels, uint32_t* __restrict__ work, uint32_t stride) {
+                                                         uint32_t cn, WindowPlan plan, int levels, int every_bit, uint32_t* __restrict__ work, uint32_t stride) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cn) return;
   const size_t i = i0 + t;
@@ -841,7 +906,7 @@ __global__ void __launch_bounds__(256, 2) k_table_build(AffPacked* __restrict__ 
     } else {
       mem_copy(r, make_ref5(work, stride, (uint32_t)(w - 2) * cn + t));
     }
-    const int nd = plan.bits[w - 1];       // level w = 2^(off_w) P, off_w - off_(w-1) = bits of window w-1
+    const int nd = every_bit ? 1 : plan.bits[w - 1];       // level w = 2^(off_w) P, off_w - off_(w-1) = bits of window w-1 (every_bit: level w = 2^w P)
 #pragma unroll 1
     for (int d = 0; d < nd; d++) dbl_mem(r);
   }
@@ -946,8 +1011,9 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   // 108 * (W * 2^(c-1) + 2T) * 4 bytes must stay below 4 GiB (buffer descriptor); checked below
   if (c < 4 || c > (merged ? 22 : 18)) return ZKHIP_ERR_ARG;
   ctx->c = c;
-  ctx->merged = merged ? 1 : 0;
+  ctx->merged = merged;
   ctx->Wd = (378 + c - 1) / c;   // scalars < 2^377, +1 bit for the signed-digit carry
+  if (merged == 2) ctx->Wd = 378 / (c + 1) + 2;      // width-(c+1) NAF: digits at least c+1 bits apart, +1 for the final carry
   ctx->W = merged ? K : ctx->Wd;
   // plain and merged plans share the balanced layout: a table's level w is 2^(off_w) P.  (A short top window would also
   // hurt a merged plan: its n digits of a few bits would all land in a handful of the shared buckets.)
@@ -1029,8 +1095,8 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   HIP_TRY(hipMalloc(&ctx->colS[0], (nb / 2 + 1) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->colS[1], (nb / 2 + 1) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->hilo, ((size_t)2 * ctx->W * ((size_t)1 << ((c - 1 + 1) / 2)) + 8) * 108 * 4));
-  HIP_TRY(hipMalloc(&ctx->win_abi, (size_t)ctx->W * 48 * 8));
-  HIP_TRY(hipHostMalloc(&ctx->win_host, (size_t)ctx->W * 48 * 8));
+  HIP_TRY(hipMalloc(&ctx->win_abi, (size_t)ctx->W * 48 * 8 * 2));       // (the second half: the plain totals of a NAF plan)
+  HIP_TRY(hipHostMalloc(&ctx->win_host, (size_t)ctx->W * 48 * 8 * 2));
   return ZKHIP_OK;
 }
 
@@ -1086,7 +1152,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   for (int k = 0; k < K; k++) {
     if (jobs[k].n > ctx->max_n) return ZKHIP_ERR_ARG;
     n_eff += (jobs[k].n_finite && jobs[k].n_finite < jobs[k].n) ? jobs[k].n_finite : jobs[k].n;
-    if (merged && jobs[k].n && (jobs[k].table_stride < jobs[k].n || (size_t)Wd * jobs[k].table_stride >= ((size_t)1 << 31))) return ZKHIP_ERR_ARG;
+    if (merged && jobs[k].n && (jobs[k].table_stride < jobs[k].n || (size_t)(merged == 2 ? 378 : Wd) * jobs[k].table_stride >= ((size_t)1 << 31))) return ZKHIP_ERR_ARG;
     n_tot += jobs[k].n;
   }
   const size_t B = ctx->B, nb = B * W;
@@ -1282,9 +1348,10 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   HIP_TRY(hipStreamWaitEvent(st, ctx->ev2, 0));
   // the last S (one item per group) has weight 0 at its level (o = 0 for level >= 1) and is dropped.
   hipLaunchKernelGGL(k_window_combine, dim3(nblk((size_t)G * 4, 64)), dim3(64), 0, st, ctx->Rlevels, level, G, ls, ctx->sumR[0]);
-  hipLaunchKernelGGL(k_hilo_combine, dim3(nblk((size_t)W * 4, 64)), dim3(64), 0, st, ctx->sumR[0], W, lo_bits, ctx->win_abi);
+  hipLaunchKernelGGL(k_hilo_combine, dim3(nblk((size_t)W * 4, 64)), dim3(64), 0, st, ctx->sumR[0], W, lo_bits, ctx->win_abi,
+                     ctx->merged == 2 ? cur : (uint32_t*)nullptr);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(ctx->win_host, ctx->win_abi, (size_t)W * 48 * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->win_host, ctx->win_abi, (size_t)W * 48 * 8 * (ctx->merged == 2 ? 2 : 1), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(ctx->ev_done, st));
   ctx->pending = true;        // only a completely enqueued sequence is collectable; a failed launch leaves the context reusable
   return ZKHIP_OK;
@@ -1315,6 +1382,12 @@ int msm_finish_multi(MsmCtx* ctx, int K, uint64_t* out_jac) {
   for (int k = 0; k < K; k++) {
     HJac q = HJac::infinity();
     if (ctx->pending_n) xyzz_abi_to_jac(ctx->win_host + (size_t)k * 48, q);    // one bucket window per job: nothing to combine
+    if (ctx->pending_n && ctx->merged == 2) {                                  // odd digits: sum (2 b + 1) S_b = 2 F - sum S_b
+      HJac tot;
+      xyzz_abi_to_jac(ctx->win_host + (size_t)(ctx->K + k) * 48, tot);
+      if (!tot.is_inf()) tot.Y = tot.Y.neg();
+      q = q.dbl().add(tot);
+    }
     q.X.to_limbs(out_jac + 36 * k); q.Y.to_limbs(out_jac + 36 * k + 12); q.Z.to_limbs(out_jac + 36 * k + 24);
   }
   return ZKHIP_OK;
@@ -1348,8 +1421,8 @@ int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]) {
   return ZKHIP_OK;
 }
 
-int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, char* errbuf, size_t errlen) {
-  const int levels = msm_table_levels(c);
+int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, int naf, char* errbuf, size_t errlen) {
+  const int levels = msm_table_levels(c, naf);
   if (n == 0 || levels < 2) return ZKHIP_OK;
   WindowPlan plan;
   memset(&plan, 0, sizeof plan);
@@ -1363,7 +1436,7 @@ int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, char* 
   hipError_t e = hipMalloc(&work, (size_t)stride * 135 * 4);
   for (size_t i0 = 0; e == hipSuccess && i0 < n; i0 += chunk) {
     uint32_t cn = (uint32_t)((n - i0 < chunk) ? n - i0 : chunk);
-    hipLaunchKernelGGL(k_table_build, dim3(nblk(cn, 256)), dim3(256), 0, 0, d_table, d_tinf, n, i0, cn, plan, levels, work, stride);
+    hipLaunchKernelGGL(k_table_build, dim3(nblk(cn, 256)), dim3(256), 0, 0, d_table, d_tinf, n, i0, cn, plan, levels, naf ? 1 : 0, work, stride);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
   }

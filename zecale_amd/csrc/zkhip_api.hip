@@ -23,6 +23,7 @@ struct zkhip_bases {
   uint8_t* d_inf;    // 1 where the base (or its table level) is the point at infinity; same shape as d_pts
   size_t len;
   int table_c;       // 0: plain base set
+  int table_naf;     // 1: the table holds EVERY bit position (378 levels): scalars are recoded in non-adjacent form (msm.h, merged == 2)
   size_t n_finite;   // bases that are not the point at infinity (counted at upload)
   int device;        // the GPU that holds them
 };
@@ -137,8 +138,8 @@ int auto_table_window(size_t n) {
 }
 
 // table_c = 0: plain plan with the automatic window;  > 0: merged plan (bases are a window table built for table_c)
-int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1) {
-  const int c = table_c ? table_c : auto_window(n), merged = table_c ? 1 : 0;
+int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1, int naf = 0) {
+  const int c = table_c ? table_c : auto_window(n), merged = table_c ? (naf ? 2 : 1) : 0;
   if (*ready && cx->pending) return fail(ZKHIP_ERR_STATE, "an MSM submitted on this context has not been collected (zkhip_msm_collect)");
   if (*ready && cx->max_n >= n && cx->c == c && cx->merged == merged && cx->K == K && cx->aff_forced == msm_forced_aff_levels()) return ZKHIP_OK;
   if (*ready) { msm_plan_free(cx); *ready = false; }
@@ -251,7 +252,7 @@ int zkhip_bases_upload_dev(const void* d_bases_affine, size_t len, zkhip_bases**
   if (!out || (len && !d_bases_affine)) return fail(ZKHIP_ERR_ARG, "null pointer");
   const int dev = cur_dev();
   std::lock_guard<std::mutex> lk(g.dev[dev].mu);
-  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len, 0, len, dev};
+  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len, 0, 0, len, dev};
   int rc = bases_upload_dev_impl(d_bases_affine, len, b);
   if (rc != ZKHIP_OK) { zkhip_bases_free(b); return rc; }      // whatever was allocated before the failure
   *out = b;
@@ -278,17 +279,37 @@ int zkhip_set_affine_levels(int levels) {
   return ZKHIP_OK;
 }
 int zkhip_set_crs_precompute(int on) { g.crs_tables = on ? 1 : 0; return ZKHIP_OK; }
+static int g_table_naf = -1;       // -1: the environment decides (default off); see naf_tables_wanted
+int zkhip_set_table_naf(int on) { g_table_naf = on < 0 ? -1 : (on ? 1 : 0); return ZKHIP_OK; }
 int zkhip_set_batch_msms(int on) { g.batch_msms = on ? 1 : 0; return ZKHIP_OK; }
 
+// Which kind of table: one level per window (default), or every bit position (378 levels) with the scalars recoded in width-(c+1)
+// non-adjacent form - an eighth fewer additions per scalar over the same buckets, sixteen times the table.  MEASURED (DESIGN.md
+// section 5): the wrapping key (17.6 GB of tables instead of 1.2) gains 4.5 % in a stream of proofs and loses 5 % alone - its
+// accumulation launch shrinks by 2 %, not 12: every addition gathers its point from a table that no longer fits the TLB's reach;
+// a 2^20-point set (76 GB) LOSES 24 %.  So it is an option (zkhip_set_table_naf / ZKHIP_TABLE_NAF=1, within ZKHIP_NAF_TABLE_GB,
+// default 24 GB per base set or proving key), off by default, tested like the default.
+static bool naf_tables_wanted(size_t total_points) {
+  static const int env_on = [] { const char* e = getenv("ZKHIP_TABLE_NAF"); return e ? atoi(e) : 0; }();
+  static const double cap_gb = [] { const char* e = getenv("ZKHIP_NAF_TABLE_GB"); double v = e ? atof(e) : 24.0; return v > 0 ? v : 24.0; }();
+  const int on = g_table_naf >= 0 ? g_table_naf : env_on;
+  if (!on) return false;
+  return (double)total_points * 378.0 * (double)(sizeof(AffPacked) + 1) <= cap_gb * 1e9 && total_points * 378 < ((size_t)1 << 31);
+}
+static int bases_precompute_mode(zkhip_bases* b, int c, int naf);
 int zkhip_bases_precompute(zkhip_bases* b, int c) {
+  if (!b) return fail(ZKHIP_ERR_ARG, "null pointer");
+  return bases_precompute_mode(b, c, naf_tables_wanted(b->len) ? 1 : 0);
+}
+static int bases_precompute_mode(zkhip_bases* b, int c, int naf) {
   if (!b) return fail(ZKHIP_ERR_ARG, "null pointer");
   BIND(b);
   std::lock_guard<std::mutex> lk(g.dev[b->device].mu);
   if (b->table_c) return fail(ZKHIP_ERR_STATE, "base set already has a window table");
   if (c == 0) c = auto_table_window(b->len);
   if (c < 4 || c > 22) return fail(ZKHIP_ERR_ARG, "table window must be 0 (automatic) or in [4, 22]");
-  if (b->len == 0) { b->table_c = c; return ZKHIP_OK; }
-  const size_t levels = (size_t)msm_table_levels(c);
+  if (b->len == 0) { b->table_c = c; b->table_naf = naf; return ZKHIP_OK; }
+  const size_t levels = (size_t)msm_table_levels(c, naf);
   if (levels * b->len >= ((size_t)1 << 31)) return fail(ZKHIP_ERR_ARG, "table too large (levels * len must stay below 2^31)");
   AffPacked* tab = nullptr;
   uint8_t* tinf = nullptr;
@@ -298,10 +319,10 @@ int zkhip_bases_precompute(zkhip_bases* b, int c) {
   if (e == hipSuccess) e = hipMemcpy(tinf, b->d_inf, b->len, hipMemcpyDeviceToDevice);
   int rc = ZKHIP_OK;
   if (e != hipSuccess) { snprintf(t_err, sizeof t_err, "window table allocation: %s", hipGetErrorString(e)); rc = ZKHIP_ERR_HIP; }
-  else rc = msm_table_build(tab, tinf, b->len, c, t_err, sizeof t_err);
+  else rc = msm_table_build(tab, tinf, b->len, c, naf, t_err, sizeof t_err);
   if (rc != ZKHIP_OK) { if (tab) (void)hipFree(tab); if (tinf) (void)hipFree(tinf); return rc; }
   (void)hipFree(b->d_pts); (void)hipFree(b->d_inf);
-  b->d_pts = tab; b->d_inf = tinf; b->table_c = c;
+  b->d_pts = tab; b->d_inf = tinf; b->table_c = c; b->table_naf = naf;
   return ZKHIP_OK;
 }
 int zkhip_bases_table_window(const zkhip_bases* b) { return b ? b->table_c : 0; }
@@ -321,7 +342,7 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
   ProveState& ps = g.dev[bases->device].ps;
   std::lock_guard<std::mutex> lk(g.dev[bases->device].mu);
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
-  int rc = ensure_ctx(&ps.ctx[0], &ps.ready[0], len ? len : 1, bases->table_c);
+  int rc = ensure_ctx(&ps.ctx[0], &ps.ready[0], len ? len : 1, bases->table_c, 1, bases->table_naf);
   if (rc != ZKHIP_OK) return rc;
   rc = msm_run(&ps.ctx[0], bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                scalars_montgomery, bases->len, out_jac);
@@ -342,7 +363,7 @@ int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scal
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
   MsmCtx* cx = &ps.ctx[slot];
   if (ps.ready[slot] && cx->pending) return fail(ZKHIP_ERR_STATE, "slot busy: collect its result first");
-  int rc = ensure_ctx(cx, &ps.ready[slot], len ? len : 1, bases->table_c);
+  int rc = ensure_ctx(cx, &ps.ready[slot], len ? len : 1, bases->table_c, 1, bases->table_naf);
   if (rc != ZKHIP_OK) return rc;
   rc = msm_launch(cx, bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                   scalars_montgomery, bases->len);
@@ -488,8 +509,11 @@ static int crs_build_tables(zkhip_crs* c) {
   size_t maxlen = c->A->len > c->H->len ? c->A->len : c->H->len;
   const int tc = g.forced_c ? g.forced_c : auto_table_window(maxlen);
   zkhip_bases* all[5] = {c->A, c->B2, c->B1, c->H, c->L};
+  size_t total = 0;
+  for (zkhip_bases* b : all) total += b->len;
+  const int naf = naf_tables_wanted(total) ? 1 : 0;            // one kind of table for the whole key
   for (zkhip_bases* b : all) {
-    int rc = zkhip_bases_precompute(b, tc);
+    int rc = bases_precompute_mode(b, tc, naf);
     if (rc != ZKHIP_OK) return rc;
   }
   return ZKHIP_OK;
@@ -571,6 +595,9 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   if (crs->B2->len != a_len || crs->B1->len != a_len || a_lo + a_len > m || h_lo + h_len > d - 1 || l_lo + l_len > m - l - 1)
     return fail(ZKHIP_ERR_ARG, "key slice out of range");
   const int tc = crs->A->table_c;
+  if (crs->B2->table_naf != crs->A->table_naf || crs->B1->table_naf != crs->A->table_naf || crs->H->table_naf != crs->A->table_naf ||
+      crs->L->table_naf != crs->A->table_naf)
+    return fail(ZKHIP_ERR_ARG, "the five query vectors of a proving key must share one kind of table");
   if (crs->B2->table_c != tc || crs->B1->table_c != tc || crs->H->table_c != tc || crs->L->table_c != tc)
     return fail(ZKHIP_ERR_ARG, "the five query vectors of a proving key must share one table window");
   auto t0 = clk::now();
@@ -604,7 +631,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     // table-backed key: the five MSMs share ONE launch sequence (one sort, one accumulation launch over all five entry
     // lists, one reduction chain with a bucket window per MSM) - a fifth of the launches, five times the lanes in each.
     // (A plan that does not fit the engine's 32-bit entry positions is refused with ZKHIP_ERR_ARG: one sequence per MSM then.)
-    rc = ensure_ctx(&ps.ctx[4], &ps.ready[4], maxlen, tc, 5);
+    rc = ensure_ctx(&ps.ctx[4], &ps.ready[4], maxlen, tc, 5, crs->A->table_naf);
     if (rc == ZKHIP_OK && ps.quad_below) { ps.ctx[4].quad_below = ps.quad_below; ps.ctx[4].one_stream = 1; }
     if (rc == ZKHIP_ERR_ARG) batched = false;
     else if (rc != ZKHIP_OK) return rc;
@@ -628,7 +655,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   const int nctx = (maxlen <= ((size_t)1 << 18)) ? 5 : 2;
   MsmCtx* ctxs[5];
   for (int k = 0; k < nctx; k++) {
-    if ((rc = ensure_ctx(&ps.ctx[k], &ps.ready[k], maxlen, tc)) != ZKHIP_OK) return rc;
+    if ((rc = ensure_ctx(&ps.ctx[k], &ps.ready[k], maxlen, tc, 1, crs->A->table_naf)) != ZKHIP_OK) return rc;
     if (ps.quad_below) { ps.ctx[k].quad_below = ps.quad_below; ps.ctx[k].one_stream = 1; }
     ctxs[k] = &ps.ctx[k];
   }

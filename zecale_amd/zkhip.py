@@ -16,7 +16,7 @@ EXPORTS = [
     "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window", "zkhip_set_batch_msms",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_msm_submit", "zkhip_msm_collect",
     "zkhip_device_alloc", "zkhip_device_free", "zkhip_device_copy_in", "zkhip_last_accumulate_ms",
-    "zkhip_prover_set_streaming", "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
+    "zkhip_prover_set_streaming", "zkhip_set_table_naf", "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
     "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings", "zkhip_groth16_verify",
     "zkhip_crs_upload_slice", "zkhip_groth16_prove_partial", "zkhip_groth16_finish",
@@ -171,6 +171,11 @@ def set_affine_levels(levels):
 def set_batch_msms(on):
     """Table-backed keys: run the five MSMs of a proof through one launch sequence (default) or one each."""
     _check(load().zkhip_set_batch_msms(int(bool(on))))
+
+
+def set_table_naf(on):
+    """window tables with every bit position + non-adjacent-form scalars (zkhip_set_table_naf): 1 on, 0 off, -1 environment"""
+    _check(load().zkhip_set_table_naf(int(on)))
 
 
 def set_crs_precompute(on):
