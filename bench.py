@@ -281,7 +281,14 @@ def main():
         agg = zkhip.AggregatorCircuit(2, args.nested_inputs)
         desc = zkhip.r1cs_desc_from_aggregator(agg)
         kp = zkhip.Keypair(desc, *trapdoor)
+        # a STREAM of proofs gains from the larger kind of window table (every bit position + NAF scalars: DESIGN.md section 5);
+        # one proof at a time keeps the default
+        naf_key = (not args.serial) and not args.no_table and os.environ.get("ZKHIP_TABLE_NAF") is None
+        if naf_key:
+            zkhip.set_table_naf(1)
         crs, r1 = kp.upload_crs(), zkhip.r1cs_from_desc(desc)
+        zkhip.set_table_naf(-1)
+        extra["table_kind"] = "every bit position, scalars in non-adjacent form (zkhip_set_table_naf)" if naf_key else "one level per window (default)"
         rr, ss = random_fr_uniform(5, 1)[0], random_fr_uniform(6, 1)[0]
         wit_ms = []
         if args.serial:
@@ -425,6 +432,9 @@ def main():
         tw_batched_flag = tw_batched(extra, args)
         tw = extra.pop("table_window", None)
         digits = -(-378 // tw) if tw else 24 if terms_in_kernel > (1 << 18) else None
+        naf_tables = str(extra.get("table_kind", "")).startswith("every bit") and bool(tw)
+        if naf_tables:
+            digits = round(378.0 / (tw + 2), 2)          # width-(tw+1) non-adjacent form: one digit per tw + 2 bits on average
         timed = k_ms > 0
         if not timed:
             k_ms = float("nan")
@@ -435,7 +445,9 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "terms_per_gpu": n,
                        "scalars": "uniform in [0, r), Montgomery residues as libff holds them" if args.workload == "msm" else "the circuit's witness",
-                       "bases": ("resident in HBM (proving key) with window tables: 2^(%d w) P_i for the %d window positions, built at "
+                       "bases": ("resident in HBM (proving key) with window tables: 2^j P_i for EVERY bit position j (378 levels, 378 x the key's "
+                                 "memory), scalars in width-%d non-adjacent form, built at key-load time" % (tw + 1)) if naf_tables else
+                                ("resident in HBM (proving key) with window tables: 2^(%d w) P_i for the %d window positions, built at "
                                  "key-load time, %d x the key's memory" % (tw, digits, digits)) if tw else "resident in HBM (proving key)",
                        "arithmetic": "761-bit Montgomery integers as 27 x 29-bit limbs in u32, products via v_mad_u64_u32",
                        "parallelism": "point-partitioned x%d, RCCL all-gather of 288-byte partial sums" % world},
@@ -682,7 +694,11 @@ def wrapping_prover_secondary(zkhip, args, steps=480, warmup=48, cpu=True):
     agg = zkhip.AggregatorCircuit(2, 1)
     desc = zkhip.r1cs_desc_from_aggregator(agg)
     kp = zkhip.Keypair(desc, *trapdoor)
+    naf_key = os.environ.get("ZKHIP_TABLE_NAF") is None        # the streaming prover's key: the larger kind of window table
+    if naf_key:
+        zkhip.set_table_naf(1)
     crs = kp.upload_crs()
+    zkhip.set_table_naf(-1)
     rr, ss = random_fr_uniform(5, 1)[0], random_fr_uniform(6, 1)[0]
     pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers)
     depth = args.gpu_slots + args.witness_workers + 2
@@ -707,7 +723,8 @@ def wrapping_prover_secondary(zkhip, args, steps=480, warmup=48, cpu=True):
            "value": round(steps / dt, 3), "unit": "proofs/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
            "last_proof_verifies": ok, "gpu_slots": args.gpu_slots, "witness_workers": args.witness_workers,
            "host_cores_busy": round(((c1.user + c1.system) - (c0.user + c0.system)) / dt, 2),
-           "includes": "host witness generation + QAP + 5 MSMs + host tail per proof, reference dummy_app fixtures, nothing cached"}
+           "includes": "host witness generation + QAP + 5 MSMs + host tail per proof, reference dummy_app fixtures, nothing cached",
+           "table_kind": "every bit position, scalars in non-adjacent form (zkhip_set_table_naf)" if naf_key else "one level per window"}
     pipe.free()
     # the same stream with the assignment generated ON THE GPU (SURVEY 8 rows a2-a5 as a kernel: witness.hip), two batcher threads
     try:
@@ -741,6 +758,8 @@ def wrapping_prover_secondary(zkhip, args, steps=480, warmup=48, cpu=True):
     terms = sum(finite(pk[k]) for k in ("A", "B2", "B1", "H", "L"))
     tw = crs.table_window
     digits = -(-378 // tw) if tw else 24
+    if naf_key and tw:
+        digits = round(378.0 / (tw + 2), 2)              # non-adjacent form: one digit per tw + 2 bits on average
     out["roofline"] = roofline_obj("zkhip::k_accumulate<5>", terms, digits, acc_ms, None)
     out["roofline"]["terms"] = "the finite bases of the five query vectors of this key (a base at infinity produces no entry)"
     out["one_proof_alone_ms"] = {"witness_host": round(wit_ms, 3), **{k: round(v, 3) for k, v in phases.items()}}

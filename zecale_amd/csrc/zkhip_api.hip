@@ -288,10 +288,11 @@ int zkhip_set_batch_msms(int on) { g.batch_msms = on ? 1 : 0; return ZKHIP_OK; }
 // section 5): the wrapping key (17.6 GB of tables instead of 1.2) gains 4.5 % in a stream of proofs and loses 5 % alone - its
 // accumulation launch shrinks by 2 %, not 12: every addition gathers its point from a table that no longer fits the TLB's reach;
 // a 2^20-point set (76 GB) LOSES 24 %.  So it is an option (zkhip_set_table_naf / ZKHIP_TABLE_NAF=1, within ZKHIP_NAF_TABLE_GB,
-// default 24 GB per base set or proving key), off by default, tested like the default.
+// default 48 GB per base set or proving key), off by default in the library (the streaming bench and the gRPC server
+// switch it on for their key), tested like the default.
 static bool naf_tables_wanted(size_t total_points) {
   static const int env_on = [] { const char* e = getenv("ZKHIP_TABLE_NAF"); return e ? atoi(e) : 0; }();
-  static const double cap_gb = [] { const char* e = getenv("ZKHIP_NAF_TABLE_GB"); double v = e ? atof(e) : 24.0; return v > 0 ? v : 24.0; }();
+  static const double cap_gb = [] { const char* e = getenv("ZKHIP_NAF_TABLE_GB"); double v = e ? atof(e) : 48.0; return v > 0 ? v : 48.0; }();
   const int on = g_table_naf >= 0 ? g_table_naf : env_on;
   if (!on) return false;
   return (double)total_points * 378.0 * (double)(sizeof(AffPacked) + 1) <= cap_gb * 1e9 && total_points * 378 < ((size_t)1 << 31);

@@ -232,7 +232,11 @@ class GpuProver:
         self.vk = self.kp.vk()
         if self.vk["ABC"].shape[0] != self.agg.num_primary_inputs() + 1:      # the server's "invalid VK" check (:490, :504)
             raise ValueError("invalid VK")
-        self.crs = self.kp.upload_crs()
+        zkhip.set_table_naf(1)              # a server proves a stream of batches: the larger kind of window table pays
+        try:
+            self.crs = self.kp.upload_crs()
+        finally:
+            zkhip.set_table_naf(-1)
         self.pipe = zkhip.AggregatorPipeline(self.agg, self.crs, gpu_slots=gpu_slots, witness_workers=witness_workers, gpu_witness=gpu_witness)
 
     def verification_key_json(self):
