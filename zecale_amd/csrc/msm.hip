@@ -1034,9 +1034,9 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   if ((size_t)ctx->Wd * max_n >= ((size_t)1 << 31)) return ZKHIP_ERR_ARG;   // entry = 31-bit point index + sign
   if ((size_t)ctx->Wd * max_n * K >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;  // positions in the entry list are 32-bit
   HIP_TRY(hipMalloc(&ctx->digits, (size_t)K * ctx->Wd * max_n * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&ctx->counts, nb * 4));
+  HIP_TRY(hipMalloc(&ctx->counts, 2 * nb * 4));          // counts | cursor: one allocation, cleared by one fill per MSM
+  ctx->cursor = ctx->counts + nb;
   HIP_TRY(hipMalloc(&ctx->offsets, nb * 4));
-  HIP_TRY(hipMalloc(&ctx->cursor, nb * 4));
   HIP_TRY(hipMalloc(&ctx->block_tot, (nb / 1024 + 2) * 4));
   HIP_TRY(hipMalloc(&ctx->entries, (size_t)K * ctx->Wd * max_n * 4));
   // batched-affine levels: bounds on the level sizes, the buffers of their outputs
@@ -1101,7 +1101,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
 }
 
 void msm_plan_free(MsmCtx* ctx) {
-  void* ptrs[] = {ctx->digits, ctx->counts, ctx->offsets, ctx->cursor, ctx->block_tot, ctx->entries, ctx->buckets,
+  void* ptrs[] = {ctx->digits, ctx->counts, ctx->offsets, ctx->block_tot, ctx->entries, ctx->buckets,
                   ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi,
                   ctx->colS[0], ctx->colS[1], ctx->hilo, ctx->pbuf[0], ctx->pbuf[1], ctx->aff_scratch,
                   ctx->lcnt[0], ctx->lcnt[1], ctx->lcnt[2], ctx->lcnt[3], ctx->loff[0], ctx->loff[1], ctx->loff[2], ctx->loff[3],
@@ -1159,8 +1159,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   hipStream_t st = ctx->stream;
   ctx->pending_n = n_tot;
   if (n_tot == 0) { ctx->pending = true; return ZKHIP_OK; }
-  HIP_TRY(hipMemsetAsync(ctx->counts, 0, nb * 4, st));
-  HIP_TRY(hipMemsetAsync(ctx->cursor, 0, nb * 4, st));
+  HIP_TRY(hipMemsetAsync(ctx->counts, 0, 2 * nb * 4, st));      // counts and cursor
   WindowPlan plan;
   memset(&plan, 0, sizeof plan);
   for (int w = 0; w < Wd; w++) { plan.off[w] = ctx->win_off[w]; plan.bits[w] = ctx->win_bits[w]; }
