@@ -74,6 +74,7 @@ struct WindowPlan {
 // merged != 0 (precomputed table): every digit position uses the SAME bucket window (bucket = bucket_base + |d| - 1)
 // because the entry will point at 2^(c w) P_i instead of P_i; inf_flags then has one row of `tab_stride` flags per
 // level.  bucket_base = k * B selects the bucket window of job k when several MSMs share one launch sequence (0 otherwise).
+constexpr uint32_t NAF_LOW_BUCKETS = 64;      // buckets of the magnitudes 1 .. 127: aggregated per block (k_scalar_digits, k_scatter)
 // The MSMs of one launch sequence share the launch: blockIdx.y is the job, its parameters come from the table.
 struct DigitJobs {
   const uint64_t* scalars[MSM_MAX_JOBS];
@@ -118,9 +119,14 @@ __global__ void __launch_bounds__(256) k_scalar_digits(DigitJobs jobs, int c, in
     // digits on average instead of 378 / c, over the same 2^(c-1) buckets (bucket = (|d| - 1) / 2, weight 2 * bucket + 1: the
     // reduction returns sum (bucket + 1) S_b and sum S_b, the finish makes 2 F - S of them).  The entry of a digit at bit position
     // j points at level j of the table (2^j P_i).  A digit is stored as sign | position << 22 | magnitude (|d| < 2^22, position < 2^9).
+    // The LAST digit of a scalar covers only the bits that are left, so small magnitudes are over-represented: the counters of the
+    // low buckets would take thousands of same-address atomics (serialised in L2).  They are counted per block in LDS first.
     __shared__ uint32_t s_w[13][256];
+    __shared__ uint32_t s_low[NAF_LOW_BUCKETS];
+    if (threadIdx.x < NAF_LOW_BUCKETS) s_low[threadIdx.x] = 0;
 #pragma unroll
     for (int k = 0; k < 13; k++) s_w[k][threadIdx.x] = w32[k];
+    __syncthreads();
     const int wbits = c + 1;
     int pos = 0, slot = 0;
     uint32_t carry = 0;
@@ -142,16 +148,17 @@ __global__ void __launch_bounds__(256) k_scalar_digits(DigitJobs jobs, int c, in
       int32_t packed = 0;
       if (!skip) packed = (int32_t)(mag | ((uint32_t)pos << 22) | (d < 0 ? 0x80000000u : 0u));
       if (live) digits[(size_t)slot * n + i] = packed;
-      const bool hot = !skip && pos == 0 && d == 1;                  // "scalar == 1": one atomic per wave (see below)
-      const unsigned long long hot_mask = __ballot(hot);
-      if (hot_mask) {
-        if (hot && (__ffsll((long long)hot_mask) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&counts[bucket_base], (uint32_t)__popcll(hot_mask));
+      if (!skip) {
+        const uint32_t bl = (mag - 1) >> 1;
+        if (bl < NAF_LOW_BUCKETS) atomicAdd(&s_low[bl], 1u);
+        else atomicAdd(&counts[(size_t)bucket_base + bl], 1u);
       }
-      if (!skip && !hot) atomicAdd(&counts[(size_t)bucket_base + ((mag - 1) >> 1)], 1u);
       slot++;
       pos += wbits;
     }
     if (live) for (; slot < W; slot++) digits[(size_t)slot * n + i] = 0;
+    __syncthreads();
+    if (threadIdx.x < NAF_LOW_BUCKETS && s_low[threadIdx.x]) atomicAdd(&counts[(size_t)bucket_base + threadIdx.x], s_low[threadIdx.x]);
     return;
   }
   uint32_t carry = 0;
@@ -250,21 +257,32 @@ __global__ void __launch_bounds__(256) k_scatter(DigitJobs jobs, const int32_t* 
   const uint32_t B = 1u << (c - 1);
   const uint32_t lane = threadIdx.x & 63;
   if (merged == 2) {                                   // NAF digits: sign | position << 22 | magnitude (k_scalar_digits)
+    // the low buckets (over-represented: see k_scalar_digits) get their places per BLOCK: count in LDS, one global atomic per block
+    // and bucket, then ranks from a second LDS counter
+    __shared__ uint32_t s_cnt[NAF_LOW_BUCKETS], s_base[NAF_LOW_BUCKETS];
+    if (threadIdx.x < NAF_LOW_BUCKETS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int w = 0; w < W; w++) {
+      const uint32_t pk = live ? (uint32_t)digits[(size_t)w * n + i] : 0u;
+      const uint32_t mag = pk & 0x3fffffu;
+      if (mag != 0 && ((mag - 1) >> 1) < NAF_LOW_BUCKETS) atomicAdd(&s_cnt[(mag - 1) >> 1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < NAF_LOW_BUCKETS) {
+      const uint32_t cnt = s_cnt[threadIdx.x];
+      s_base[threadIdx.x] = cnt ? atomicAdd(&cursor[(size_t)bucket_base + threadIdx.x], cnt) : 0u;
+      s_cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
     for (int w = 0; w < W; w++) {
       const uint32_t pk = live ? (uint32_t)digits[(size_t)w * n + i] : 0u;
       const uint32_t mag = pk & 0x3fffffu, pos_bit = (pk >> 22) & 0x1ffu;
-      const bool hot = mag == 1 && pos_bit == 0 && !(pk >> 31);
-      const unsigned long long hot_mask = __ballot(hot);
-      if (hot_mask) {
-        const int leader = __ffsll((long long)hot_mask) - 1;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&cursor[bucket_base], (uint32_t)__popcll(hot_mask));
-        base = __shfl(base, leader);
-        if (hot) entries[offsets[bucket_base] + base + (uint32_t)__popcll(hot_mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
-      }
-      if (mag == 0 || hot) continue;
-      const size_t b = (size_t)bucket_base + ((mag - 1) >> 1);
-      const uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
+      if (mag == 0) continue;
+      const uint32_t bl = (mag - 1) >> 1;
+      const size_t b = (size_t)bucket_base + bl;
+      uint32_t pos;
+      if (bl < NAF_LOW_BUCKETS) pos = offsets[b] + s_base[bl] + atomicAdd(&s_cnt[bl], 1u);
+      else pos = offsets[b] + atomicAdd(&cursor[b], 1u);
       entries[pos] = (uint32_t)((size_t)pos_bit * tab_stride + i) | (pk & 0x80000000u);
     }
     return;
