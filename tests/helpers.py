@@ -73,6 +73,32 @@ def random_fr_canonical(seed, n):
     return a
 
 
+_R_LIMBS = [(R.R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]
+
+
+def random_fr_uniform(seed, n):
+    """n x 6 limbs of CANONICAL scalars UNIFORM in [0, r) (bench.py draws its scalars the same way): 377-bit draws
+    from a splitmix64 stream, redrawn while >= r (16 % are).  Unlike random_fr_canonical the top bit of r's range is exercised."""
+    a = splitmix64(seed, n * 6).reshape(n, 6)
+    a[:, 5] &= np.uint64((1 << 57) - 1)
+    rnd = 0
+    while True:
+        ge = np.zeros(n, dtype=bool)          # lexicographic a >= r from the top limb down
+        undecided = np.ones(n, dtype=bool)
+        for k in range(5, -1, -1):
+            rk = np.uint64(_R_LIMBS[k])
+            ge |= undecided & (a[:, k] > rk)
+            undecided &= a[:, k] == rk
+        ge |= undecided
+        bad = np.nonzero(ge)[0]
+        if bad.size == 0:
+            return a
+        rnd += 1
+        fresh = splitmix64(seed ^ (0xD1B54A32D192ED03 * rnd & 0xFFFFFFFFFFFFFFFF), bad.size * 6).reshape(bad.size, 6)
+        fresh[:, 5] &= np.uint64((1 << 57) - 1)
+        a[bad] = fresh
+
+
 # ---------------------------------------------------------------- synthetic R1CS / CRS (tests + bench)
 def make_r1cs(seed, n_constraints, n_primary, n_aux, bool_frac=0.0):
     """Satisfiable-by-construction R1CS in Python ints: rows are lists of (var, coeff).

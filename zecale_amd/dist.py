@@ -82,10 +82,13 @@ def key_slices(n_vars, n_primary, domain_size, world, rank):
     return (partition(n_vars, world, rank), partition(domain_size - 1, world, rank), partition(n_vars - n_primary - 1, world, rank))
 
 
-def prove_distributed(crs_slice, r1cs, pk_consts, z, r, s, group=None, device=None):
+def prove_distributed(crs_slice, r1cs, pk_consts, z, r, s, group=None, device=None, backend=None):
     """One Groth16 proof with the proving key partitioned over the ranks of `group`: every rank runs the (cheap, replicated)
     QAP map and the five MSMs over its slice, the 5 x 288-byte partial sums are all-gathered and added in rank order on
-    every rank, and every rank finishes the same proof.  Collective."""
-    sums = zkhip.groth16_prove_partial(crs_slice, r1cs, z)
+    every rank, and every rank finishes the same proof.  Collective.
+    backend: the object that provides groth16_prove_partial / groth16_finish (default: the HIP library; the gloo tests pass a
+    stand-in for the partial sums so that the partition + exchange + finish logic runs without a GPU)."""
+    be = zkhip if backend is None else backend
+    sums = be.groth16_prove_partial(crs_slice, r1cs, z)
     total = combine_partial_sums(sums, group=group, device=device)
-    return zkhip.groth16_finish(pk_consts, total, r, s)
+    return be.groth16_finish(pk_consts, total, r, s)
