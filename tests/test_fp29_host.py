@@ -37,6 +37,7 @@ def test_fp29_against_golden_and_random(shim, name, p, n):
     rng = random.Random(11)
     vecs = [(h2i(v["a"]), h2i(v["b"])) for v in golden("field_vectors.json")[name]]
     vecs += [(rng.randrange(p), rng.randrange(p)) for _ in range(200)]
+    vecs += [(p - 1, p - 1), (p - 1, 1), (0, p - 1), (p - 2, p - 3)]
     for a, b in vecs:
         getattr(shim, name + "_mul")(_arr(tm(a), n), _arr(tm(b), n), out)
         assert fm(R.limbs_to_int(out)) == a * b % p
@@ -44,6 +45,12 @@ def test_fp29_against_golden_and_random(shim, name, p, n):
         assert fm(R.limbs_to_int(out)) == a * a % p
         getattr(shim, name + "_add")(_arr(tm(a), n), _arr(tm(b), n), out)
         assert fm(R.limbs_to_int(out)) == (a + b) % p
+        # the dual product (one reduction for a b + c d): plain operands, then lazily bounded ones with every limb near its maximum
+        c, d = (a * 3 + 1) % p, (b * b + 7) % p
+        getattr(shim, name + "_mul2")(_arr(tm(a), n), _arr(tm(b), n), _arr(tm(c), n), _arr(tm(d), n), out)
+        assert fm(R.limbs_to_int(out)) == (a * b + c * d) % p
+        getattr(shim, name + "_mul2_lazy")(_arr(tm(a), n), _arr(tm(b), n), out)
+        assert fm(R.limbs_to_int(out)) == ((3 * a + b) * (3 * a - b) - a * 2 * b) % p
         getattr(shim, name + "_sub")(_arr(tm(a), n), _arr(tm(b), n), out)
         assert fm(R.limbs_to_int(out)) == (a - b) % p
         getattr(shim, name + "_roundtrip")(_arr(tm(a), n), out)
@@ -75,3 +82,27 @@ def test_safegcd_inversion(shim, name, p, n):
         getattr(shim, name + "_inv")(_arr(tm(a), n), out)
         got = fm(R.limbs_to_int(out))
         assert got == (pow(a, -1, p) if a else 0), hex(a)
+
+
+@pytest.mark.parametrize("name,p,nl", [("fq", R.Q_MOD, 27), ("fr", R.R_MOD, 14)])
+def test_dual_product_at_its_column_bound(shim, name, p, nl):
+    """fp_mul2 sums the 2 x NL products of a column in one 64-bit accumulator before the reduction terms join: operands with EVERY limb
+    at 2^29 - 1 and the top limb as large as the lazy bound (2^10 p) allows are the worst case of that sum."""
+    rng = random.Random(3)
+    top_max = ((p << 10) >> (29 * (nl - 1)))            # top limb of values below 2^10 p
+    full = [(1 << 29) - 1] * (nl - 1)
+    val = lambda limbs: sum(v << (29 * i) for i, v in enumerate(limbs))
+    Rdev = 1 << (29 * nl)
+    cases = [[full + [top_max - 1]] * 4]
+    for _ in range(50):
+        cases.append([[rng.choice([(1 << 29) - 1, rng.randrange(1 << 29)]) for _ in range(nl - 1)] + [rng.randrange(top_max)] for _ in range(4)])
+    for a, b, c, d in cases:
+        if val(a) * val(b) + val(c) * val(d) >= (Rdev * p) << 10:
+            a = a[:-1] + [a[-1] >> 6]; c = c[:-1] + [c[-1] >> 6]          # keep a b + c d below 2^10 R p
+        arrs = [(ctypes.c_uint32 * nl)(*x) for x in (a, b, c, d)]
+        out = (ctypes.c_uint32 * nl)()
+        getattr(shim, name + "_mul2_raw")(*arrs, out)
+        got = val(list(out))
+        assert all(v < (1 << 29) for v in list(out)[:-1])
+        assert got % p == (val(a) * val(b) + val(c) * val(d)) * pow(Rdev, -1, p) % p
+        assert got < (val(a) * val(b) + val(c) * val(d)) // Rdev + p + 1

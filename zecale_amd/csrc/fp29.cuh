@@ -113,6 +113,49 @@ ZK_HD ZK_MULATTR Fp<PR> fp_sqr(Fp<PR> a) {
   return r;
 }
 
+// r = (a*b + c*d)/R mod p with ONE Montgomery reduction: 2 * NL^2 product terms and NL^2 reduction terms instead of 2 * (NL^2 + NL^2).
+// (The y coordinate of every addition formula has this shape: Y3 = R (Q - X3) - Y1 PPP.)  A column now holds up to 2 * NL products
+// of < 2^58 plus NL reduction terms: 3 * 27 * 2^58 > 2^64.  So the products of a column are summed on their own (< 2^64: at most 26 pairs
+// of full 29-bit limbs per product - a pair that involves a top limb is small), their upper part goes straight to the next
+// column's carry, and only their low 29 bits meet the reduction terms: three more shift / add operations per column.
+// Requires normalised limbs and a*b + c*d < 2^10 R p; result < (a*b + c*d)/R + p.
+template <class PR>
+ZK_HD ZK_MULATTR Fp<PR> fp_mul2(Fp<PR> a, Fp<PR> b, Fp<PR> c, Fp<PR> d) {
+  constexpr int N = PR::NL;
+  Fp<PR> r;
+  uint32_t m[N];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    uint64_t t = 0;
+#pragma unroll
+    for (int i = 0; i <= k; i++) t += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i <= k; i++) t += (uint64_t)c.l[i] * d.l[k - i];
+    uint64_t acc = ((uint32_t)t & M29) + carry;
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * PR::P[k - i];
+    m[k] = ((uint32_t)acc * PR::PINV) & M29;
+    acc += (uint64_t)m[k] * PR::P[0];
+    carry = (acc >> 29) + (t >> 29);
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; k++) {
+    uint64_t t = 0;
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) t += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) t += (uint64_t)c.l[i] * d.l[k - i];
+    uint64_t acc = ((uint32_t)t & M29) + carry;
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * PR::P[k - i];
+    r.l[k - N] = (uint32_t)acc & M29;
+    carry = (acc >> 29) + (t >> 29);
+  }
+  r.l[N - 1] = (uint32_t)carry;
+  return r;
+}
+
 // carry-normalise limbs that may have grown up to 2^32-1 (top limb keeps the overflow)
 template <class PR>
 ZK_HD ZK_INL void fp_normalise(Fp<PR>& a) {

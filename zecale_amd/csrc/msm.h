@@ -38,8 +38,12 @@ struct MsmCtx {
   uint32_t S, T, slot_stride;   // slice length, slice count, words per row of the slot array
   hipStream_t stream, stream2;
   hipEvent_t ev, ev2, ev_acc0, ev_acc1, ev_done;
-  int32_t* digits;
-  uint32_t *counts, *offsets, *cursor, *block_tot, *entries;
+  // bucket sort (k_digit_pass / k_bucket_sort): hist[part][block] (+ 1: the total), (entry, low bucket bits) pairs grouped by part
+  uint32_t sort_LB, sort_NP, sort_bins, sort_tile;
+  uint32_t* hist;
+  uint2* pairs;
+  size_t hist_len;
+  uint32_t *counts, *offsets, *block_tot, *entries;
   uint2* fix_list;      // (first, last) boundary slot of the buckets cut into more than two pieces (k_fixup_round -> k_fixup_tree)
   uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels, *colS[2], *hilo;
   uint64_t *win_abi, *win_host;

@@ -5,9 +5,9 @@
 // Pipeline (all kernels hand-written for wave64; one lane owns one field element, see fp29.cuh):
 //   k_bases_to_dev      ABI affine points -> packed device-form points (once per base set)
 //   k_table_build       optional, once per resident base set: 2^(off_w) P_i for every window position (window table)
-//   k_scalar_digits     Montgomery scalars -> canonical -> signed c-bit digits + bucket histogram
-//   k_scan_*            exclusive prefix sum of the histogram (bucket offsets)
-//   k_scatter           counting-sort scatter: bucket-ordered list of (point index, sign)
+//   k_digit_pass<0/1>   Montgomery scalars -> canonical -> signed c-bit digits; counted, then placed, per PART of the bucket range (LDS)
+//   k_scan_*            exclusive prefix sum of the (part, block) histogram
+//   k_bucket_sort       a workgroup per part orders its entries by bucket: bucket-ordered list of (point index, sign), offsets, counts
 //   k_accumulate        one lane per fixed-size SLICE of the sorted list: XYZZ mixed additions   <-- dominant
 //   k_fixup_round/_fixup  stitch the buckets that slice boundaries cut
 //   k_sum / k_seg       bucket reduction  sum_j (j+1) B_j : two-level split of the bucket index, then L-ary running sums
@@ -69,122 +69,242 @@ struct WindowPlan {
   uint8_t bits[96];   // size of window w
 };
 
-// one thread per scalar.  digits[w*n + i] = signed digit of window w (|d| <= 2^(bits_w - 1));
-// counts[w*B + |d|-1] += 1 for d != 0   (B = 2^(c-1) bucket slots per window).
-// merged != 0 (precomputed table): every digit position uses the SAME bucket window (bucket = bucket_base + |d| - 1)
-// because the entry will point at 2^(c w) P_i instead of P_i; inf_flags then has one row of `tab_stride` flags per
-// level.  bucket_base = k * B selects the bucket window of job k when several MSMs share one launch sequence (0 otherwise).
-constexpr uint32_t NAF_LOW_BUCKETS = 64;      // buckets of the magnitudes 1 .. 127: aggregated per block (k_scalar_digits, k_scatter)
-// The MSMs of one launch sequence share the launch: blockIdx.y is the job, its parameters come from the table.
+// ---- bucket sort of the digits: two passes with LDS histograms, no global atomics --------------------------------------
+// A digit of a scalar is an ENTRY (which point, which sign) for a BUCKET (global index in [0, nb): window * B + |d| - 1, or
+// job * B + |d| - 1 when all digit positions of a job share one bucket window).  k_accumulate wants the entries ordered by
+// bucket.  bucket = part << LB | low:
+//   k_digit_pass<0>   a block takes a tile of scalars, extracts their digits and counts them per PART in LDS; the counts go out
+//                     as hist[part][block]
+//   k_scan_*          exclusive scan of hist in (part, block) order: where each block's entries of each part start
+//   k_digit_pass<1>   the same blocks extract the same digits again (two Fr multiplications per scalar: cheaper than storing
+//                     and re-reading 4 bytes per digit), take their ranks from an LDS counter and write (entry, low bucket
+//                     bits) pairs - one 8-byte store each -, grouped by part
+//   k_bucket_sort     a workgroup per part: LDS histogram over the low bits, scan, placement - and the per-bucket
+//                     offsets / counts the accumulation needs fall out on the way
+// (Rounds 1-2 counted in global memory: one atomic per digit in the histogram and one RETURNING atomic per digit in the
+// scatter, 1.6 ms of a 2^20-term MSM - 20 M device-scope atomics resolve in the memory-side cache, not in an XCD's L2.)
+// The order of the entries inside a bucket is not defined (the sum is).
 struct DigitJobs {
   const uint64_t* scalars[MSM_MAX_JOBS];
   const uint8_t* inf_flags[MSM_MAX_JOBS];
   size_t n[MSM_MAX_JOBS], tab_stride[MSM_MAX_JOBS];
   int mode[MSM_MAX_JOBS];
 };
-__global__ void __launch_bounds__(256) k_scalar_digits(DigitJobs jobs, int c, int W, WindowPlan plan, int merged, uint32_t B_per_job,
-                                                        size_t digits_per_job, int32_t* __restrict__ digits_all, uint32_t* __restrict__ counts) {
-  const uint32_t job = blockIdx.y;
-  const size_t n = jobs.n[job];
-  if ((size_t)blockIdx.x * blockDim.x >= n) return;             // (whole blocks: the wave-aggregated atomics below need whole waves)
-  const uint64_t* __restrict__ scalars = jobs.scalars[job];
-  const uint8_t* __restrict__ inf_flags = jobs.inf_flags[job];
-  const int montgomery = jobs.mode[job];
-  const size_t tab_stride = jobs.tab_stride[job];
-  const uint32_t bucket_base = job * B_per_job;
-  int32_t* __restrict__ digits = digits_all + (size_t)job * digits_per_job;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  if (!live) i = n - 1;                    // keep whole waves in the loop: the hot-bucket atomics are wave-aggregated
-  const bool skip0 = !live || (inf_flags && inf_flags[i]);   // a base at infinity contributes nothing: drop it here
+struct SortGeom {
+  uint32_t LB;          // low bucket bits: a part is 2^LB consecutive buckets
+  uint32_t NP;          // parts per bucket window (B >> LB)
+  uint32_t bins;        // parts a block can hit: NP (merged plans: its job's window) or W * NP (plain plans: every window)
+  uint32_t nbx;         // blocks per job = row length of hist
+  uint32_t tile;        // scalars per block
+  uint32_t nparts;      // nb >> LB
+};
+
+// canonical 32-bit words (13, the last one zero) of scalar i of a job
+__device__ __forceinline__ void scalar_words(const uint64_t* __restrict__ scalars, size_t i, int mode, uint32_t* w32) {
   uint64_t s[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) s[k] = scalars[i * 6 + k];
-  uint32_t w32[13];
-  if (montgomery == 1) {
+  if (mode == 1) {
     fp_abi_to_canonical_words<FrParams>(s, w32);
   } else {
 #pragma unroll
     for (int k = 0; k < 6; k++) { w32[2 * k] = (uint32_t)s[k]; w32[2 * k + 1] = (uint32_t)(s[k] >> 32); }
-    if (montgomery == 2) {   // packed device form (value * 2^406, < 2^384), as the NTT kernels leave it
+    if (mode == 2) {   // packed device form (value * 2^406, < 2^384), as the NTT kernels leave it
       Fp<FrParams> v = fp_unpack32<FrParams>(w32), one_raw = fp_zero<FrParams>();
       one_raw.l[0] = 1;
       fp_pack32<FrParams>(fp_cond_sub_p(fp_mul(v, one_raw)), w32);
     }
   }
   w32[12] = 0;
+}
+
+// PASS 0: count.  PASS 1: place.  NAF: scalars recoded in width-(c+1) non-adjacent form (merged == 2 plans).
+// Dynamic LDS: cnt[bins] (+ base[bins] in pass 1).
+template <int PASS, bool NAF>
+__global__ void __launch_bounds__(256) k_digit_pass(DigitJobs jobs, int c, int W, WindowPlan plan, int merged, uint32_t B_per_job, SortGeom ge,
+                                                     uint32_t* __restrict__ hist, uint2* __restrict__ pairs) {
+  extern __shared__ uint32_t sh_dyn[];
+  __shared__ uint32_t s_w[NAF ? 13 : 1][256];
+  uint32_t* s_cnt = sh_dyn;
+  uint32_t* s_base = sh_dyn + ge.bins;
+  const uint32_t job = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+  const size_t n = jobs.n[job];
+  const uint64_t* __restrict__ scalars = jobs.scalars[job];
+  const uint8_t* __restrict__ inf_flags = jobs.inf_flags[job];
+  const int mode = jobs.mode[job];
+  const size_t tab_stride = jobs.tab_stride[job];
   const uint32_t B = 1u << (c - 1);
-  if (merged == 2) {
-    // Width-(c+1) non-adjacent form: ODD signed digits |d| < 2^c at arbitrary bit positions, at least c+1 bits apart - 378 / (c + 2)
-    // digits on average instead of 378 / c, over the same 2^(c-1) buckets (bucket = (|d| - 1) / 2, weight 2 * bucket + 1: the
-    // reduction returns sum (bucket + 1) S_b and sum S_b, the finish makes 2 F - S of them).  The entry of a digit at bit position
-    // j points at level j of the table (2^j P_i).  A digit is stored as sign | position << 22 | magnitude (|d| < 2^22, position < 2^9).
-    // The LAST digit of a scalar covers only the bits that are left, so small magnitudes are over-represented: the counters of the
-    // low buckets would take thousands of same-address atomics (serialised in L2).  They are counted per block in LDS first.
-    __shared__ uint32_t s_w[13][256];
-    __shared__ uint32_t s_low[NAF_LOW_BUCKETS];
-    if (threadIdx.x < NAF_LOW_BUCKETS) s_low[threadIdx.x] = 0;
-#pragma unroll
-    for (int k = 0; k < 13; k++) s_w[k][threadIdx.x] = w32[k];
-    __syncthreads();
-    const int wbits = c + 1;
-    int pos = 0, slot = 0;
-    uint32_t carry = 0;
-    while (pos < 379 && slot < W) {
-      const int j = pos >> 5, sh = pos & 31;
-      uint64_t v = (uint64_t)s_w[j < 13 ? j : 12][threadIdx.x] >> sh;
-      if (j < 12) v |= (uint64_t)s_w[j + 1][threadIdx.x] << (32 - sh);
-      if (j >= 12) v = 0;
-      const uint32_t v32 = (uint32_t)v;
-      // bits + carry: skip the run that produces zeros (zeros without a carry, ones with it)
-      const uint32_t run = carry ? ~v32 : v32;
-      if ((run & 1u) == 0) { pos += run ? (__ffs((int)run) - 1) : 32; continue; }
-      uint32_t win = (v32 & ((1u << wbits) - 1)) + carry;            // odd
-      int32_t d;
-      if (win > (1u << (wbits - 1))) { d = (int32_t)win - (int32_t)(1u << wbits); carry = 1; }
-      else { d = (int32_t)win; carry = 0; }
-      const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-      const bool skip = skip0 || (inf_flags && pos > 0 && inf_flags[(size_t)pos * tab_stride + i]);      // 2^pos P_i = O
-      int32_t packed = 0;
-      if (!skip) packed = (int32_t)(mag | ((uint32_t)pos << 22) | (d < 0 ? 0x80000000u : 0u));
-      if (live) digits[(size_t)slot * n + i] = packed;
-      if (!skip) {
-        const uint32_t bl = (mag - 1) >> 1;
-        if (bl < NAF_LOW_BUCKETS) atomicAdd(&s_low[bl], 1u);
-        else atomicAdd(&counts[(size_t)bucket_base + bl], 1u);
-      }
-      slot++;
-      pos += wbits;
-    }
-    if (live) for (; slot < W; slot++) digits[(size_t)slot * n + i] = 0;
-    __syncthreads();
-    if (threadIdx.x < NAF_LOW_BUCKETS && s_low[threadIdx.x]) atomicAdd(&counts[(size_t)bucket_base + threadIdx.x], s_low[threadIdx.x]);
-    return;
+  const uint32_t g0 = merged ? job * ge.NP : 0u;                 // first part this block can hit
+  const uint32_t lb_mask = (1u << ge.LB) - 1u;
+  for (uint32_t j = tid; j < ge.bins; j += 256) {
+    s_cnt[j] = 0;
+    if (PASS == 1) s_base[j] = hist[(size_t)(g0 + j) * ge.nbx + bx];
   }
-  uint32_t carry = 0;
-  for (int w = 0; w < W; w++) {
-    const int bit = plan.off[w], cw = plan.bits[w];
-    const int j = bit >> 5, sh = bit & 31;
-    uint64_t v = (uint64_t)w32[j] >> sh;
-    if (j + 1 < 13) v |= (uint64_t)w32[j + 1] << (32 - sh);
-    uint32_t d = ((uint32_t)v & ((1u << cw) - 1)) + carry;
-    int32_t sd;
-    if (d > (1u << (cw - 1))) { sd = (int32_t)d - (int32_t)(1u << cw); carry = 1; }
-    else { sd = (int32_t)d; carry = 0; }
-    const bool skip = skip0 || (merged && w > 0 && inf_flags && inf_flags[(size_t)w * tab_stride + i]);   // 2^(c w) P_i = O
-    if (skip) sd = 0;
-    if (live) digits[(size_t)w * n + i] = sd;
-    // "scalar == 1" (boolean-heavy witnesses) puts a third of all points into bucket (window 0, digit 1):
-    // one atomic per wave for that bucket instead of one per lane.
-    const bool hot = (w == 0) && (sd == 1);
-    const unsigned long long hot_mask = __ballot(hot);
+  if (PASS == 0 && bx == 0 && job == 0 && tid == 0) hist[(size_t)ge.nparts * ge.nbx] = 0;     // the scan leaves the total here
+  __syncthreads();
+  // one digit: bin = part inside this block's range, low = bucket bits below the part, e = entry word
+  auto emit = [&](bool valid, bool hot, uint32_t bin, uint32_t low, uint32_t e) {
+    // "scalar == 1" (boolean-heavy witnesses) puts a third of all points into ONE bucket: its lanes share one LDS operation
+    const unsigned long long hot_mask = __ballot(valid && hot);
     if (hot_mask) {
-      if (hot && (__ffsll((long long)hot_mask) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&counts[bucket_base], (uint32_t)__popcll(hot_mask));
+      const int leader = __ffsll((long long)hot_mask) - 1;
+      const uint32_t cntw = (uint32_t)__popcll(hot_mask);
+      if (PASS == 0) {
+        if ((int)lane == leader) atomicAdd(&s_cnt[bin], cntw);
+      } else {
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&s_cnt[bin], cntw);
+        base = __shfl(base, leader);
+        if (valid && hot) {
+          const uint32_t pos = s_base[bin] + base + (uint32_t)__popcll(hot_mask & ((1ull << lane) - 1ull));
+          pairs[pos] = make_uint2(e, low);
+        }
+      }
     }
-    if (sd != 0 && !hot) {
-      uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
-      atomicAdd(&counts[(merged ? (size_t)bucket_base : (size_t)w * B) + (mag - 1)], 1u);
+    if (valid && !hot) {
+      if (PASS == 0) {
+        atomicAdd(&s_cnt[bin], 1u);
+      } else {
+        const uint32_t pos = s_base[bin] + atomicAdd(&s_cnt[bin], 1u);
+        pairs[pos] = make_uint2(e, low);
+      }
     }
+  };
+  for (uint32_t it = 0; it < ge.tile; it += 256) {
+    size_t i = (size_t)bx * ge.tile + it + tid;
+    const bool live = i < n;
+    if ((size_t)bx * ge.tile + it >= n) break;              // (block-uniform)
+    if (!live) i = n - 1;                                   // whole waves stay in the loops: the hot-bucket path is wave-wide
+    const bool skip0 = !live || (inf_flags && inf_flags[i]);   // a base at infinity contributes nothing: drop it here
+    uint32_t w32[13];
+    scalar_words(scalars, i, mode, w32);
+    if constexpr (NAF) {
+      // Width-(c+1) non-adjacent form: ODD signed digits |d| < 2^c at arbitrary bit positions, at least c+1 bits apart - 378 / (c + 2)
+      // digits on average instead of 378 / c, over the same 2^(c-1) buckets (bucket = (|d| - 1) / 2, weight 2 * bucket + 1: the
+      // reduction returns sum (bucket + 1) S_b and sum S_b, the finish makes 2 F - S of them).  The entry of a digit at bit position
+      // j points at level j of the table (2^j P_i).  The LAST digit of a scalar covers only the bits that are left, so small
+      // magnitudes are over-represented - LDS counters take that in their stride.
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 13; k++) s_w[k][tid] = w32[k];
+      __syncthreads();
+      const int wbits = c + 1;
+      int pos = 0, slot = 0;
+      uint32_t carry = 0;
+      while (pos < 379 && slot < W) {
+        const int j = pos >> 5, sh = pos & 31;
+        uint64_t v = (uint64_t)s_w[j < 13 ? j : 12][tid] >> sh;
+        if (j < 12) v |= (uint64_t)s_w[j + 1][tid] << (32 - sh);
+        if (j >= 12) v = 0;
+        const uint32_t v32 = (uint32_t)v;
+        // bits + carry: skip the run that produces zeros (zeros without a carry, ones with it)
+        const uint32_t run = carry ? ~v32 : v32;
+        if ((run & 1u) == 0) { pos += run ? (__ffs((int)run) - 1) : 32; continue; }
+        uint32_t win = (v32 & ((1u << wbits) - 1)) + carry;            // odd
+        int32_t d;
+        if (win > (1u << (wbits - 1))) { d = (int32_t)win - (int32_t)(1u << wbits); carry = 1; }
+        else { d = (int32_t)win; carry = 0; }
+        const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+        const bool skip = skip0 || (inf_flags && pos > 0 && inf_flags[(size_t)pos * tab_stride + i]);      // 2^pos P_i = O
+        if (!skip) {
+          const uint32_t bl = (mag - 1) >> 1;
+          const uint32_t e = (uint32_t)((size_t)pos * tab_stride + i) | (d < 0 ? 0x80000000u : 0u);
+          // (divergent loop: no wave-wide aggregation here)
+          if (PASS == 0) {
+            atomicAdd(&s_cnt[bl >> ge.LB], 1u);
+          } else {
+            const uint32_t p_ = s_base[bl >> ge.LB] + atomicAdd(&s_cnt[bl >> ge.LB], 1u);
+            pairs[p_] = make_uint2(e, bl & lb_mask);
+          }
+        }
+        slot++;
+        pos += wbits;
+      }
+    } else {
+      uint32_t carry = 0;
+      for (int w = 0; w < W; w++) {
+        const int bit = plan.off[w], cw = plan.bits[w];
+        const int j = bit >> 5, sh = bit & 31;
+        uint64_t v = (uint64_t)w32[j] >> sh;
+        if (j + 1 < 13) v |= (uint64_t)w32[j + 1] << (32 - sh);
+        uint32_t d = ((uint32_t)v & ((1u << cw) - 1)) + carry;
+        int32_t sd;
+        if (d > (1u << (cw - 1))) { sd = (int32_t)d - (int32_t)(1u << cw); carry = 1; }
+        else { sd = (int32_t)d; carry = 0; }
+        const bool skip = skip0 || (merged && w > 0 && inf_flags && inf_flags[(size_t)w * tab_stride + i]);   // 2^(c w) P_i = O
+        const bool valid = !skip && sd != 0;
+        const uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
+        const uint32_t bw = valid ? mag - 1 : 0u;                                   // bucket inside its window
+        const uint32_t bin = (merged ? 0u : (uint32_t)w * ge.NP) + (bw >> ge.LB);
+        const uint32_t e = (uint32_t)(merged ? (size_t)w * tab_stride + i : i) | (sd < 0 ? 0x80000000u : 0u);
+        emit(valid, mag == 1, bin, bw & lb_mask, e);
+      }
+    }
+  }
+  (void)B; (void)B_per_job;
+  if (PASS == 0) {
+    __syncthreads();
+    for (uint32_t j = tid; j < ge.bins; j += 256) hist[(size_t)(g0 + j) * ge.nbx + bx] = s_cnt[j];
+  }
+}
+
+// One workgroup per part g: its entries pairs[start, end) (grouped by part by k_digit_pass<1>) are ordered by their low bucket
+// bits.  Writes offsets / counts of the part's 2^LB buckets (an empty bucket repeats the next offset) and the sorted entries.
+__global__ void __launch_bounds__(512) k_bucket_sort(const uint32_t* __restrict__ hoff, SortGeom ge, const uint2* __restrict__ pairs,
+                                                      uint32_t* __restrict__ entries,
+                                                      uint32_t* __restrict__ offsets, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_cnt[1024], s_cur[1024], s_scan[512];
+  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t start = hoff[(size_t)g * ge.nbx], end = hoff[(size_t)(g + 1) * ge.nbx];     // (hoff has nparts * nbx + 1 elements)
+  const uint32_t NB = 1u << ge.LB;
+  for (uint32_t j = tid; j < NB; j += 512) s_cnt[j] = 0;
+  __syncthreads();
+  const uint32_t len = end - start, rounds = (len + 511) / 512;
+  for (uint32_t r = 0; r < rounds; r++) {
+    const uint32_t k = r * 512 + tid;
+    const bool valid = k < len;
+    const uint32_t lb = valid ? pairs[start + k].y : 0xffffu;
+    const unsigned long long hot_mask = __ballot(lb == 0);       // the bucket of "digit 1" may hold a third of all entries
+    if (hot_mask) {
+      if ((int)lane == __ffsll((long long)hot_mask) - 1) atomicAdd(&s_cnt[0], (uint32_t)__popcll(hot_mask));
+    }
+    if (valid && lb != 0) atomicAdd(&s_cnt[lb], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of s_cnt[0 .. NB): two counters per thread
+  const uint32_t c0 = (2 * tid < NB) ? s_cnt[2 * tid] : 0u, c1 = (2 * tid + 1 < NB) ? s_cnt[2 * tid + 1] : 0u;
+  s_scan[tid] = c0 + c1;
+  __syncthreads();
+  for (int off = 1; off < 512; off <<= 1) {
+    const uint32_t t_ = (tid >= (unsigned)off) ? s_scan[tid - off] : 0u;
+    __syncthreads();
+    s_scan[tid] += t_;
+    __syncthreads();
+  }
+  const uint32_t ex = s_scan[tid] - (c0 + c1);
+  if (2 * tid < NB) {
+    s_cur[2 * tid] = ex;
+    offsets[((size_t)g << ge.LB) + 2 * tid] = start + ex; counts[((size_t)g << ge.LB) + 2 * tid] = c0;
+  }
+  if (2 * tid + 1 < NB) {
+    s_cur[2 * tid + 1] = ex + c0;
+    offsets[((size_t)g << ge.LB) + 2 * tid + 1] = start + ex + c0; counts[((size_t)g << ge.LB) + 2 * tid + 1] = c1;
+  }
+  __syncthreads();
+  for (uint32_t r = 0; r < rounds; r++) {
+    const uint32_t k = r * 512 + tid;
+    const bool valid = k < len;
+    const uint2 pr = valid ? pairs[start + k] : make_uint2(0u, 0xffffu);
+    const uint32_t lb = pr.y, e = pr.x;
+    const unsigned long long hot_mask = __ballot(lb == 0);
+    if (hot_mask) {
+      const int leader = __ffsll((long long)hot_mask) - 1;
+      uint32_t base = 0;
+      if ((int)lane == leader) base = atomicAdd(&s_cur[0], (uint32_t)__popcll(hot_mask));
+      base = __shfl(base, leader);
+      if (lb == 0) entries[start + base + (uint32_t)__popcll(hot_mask & ((1ull << lane) - 1ull))] = e;
+    }
+    if (valid && lb != 0) entries[start + atomicAdd(&s_cur[lb], 1u)] = e;
   }
 }
 
@@ -239,71 +359,6 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ out, co
   uint32_t add = block_tot[blockIdx.x];
 #pragma unroll
   for (int k = 0; k < 4; k++) if (base + k < m) out[base + k] += add;
-}
-
-__global__ void __launch_bounds__(256) k_scatter(DigitJobs jobs, const int32_t* __restrict__ digits_all, size_t digits_per_job, int c, int W,
-                                                  int merged, uint32_t B_per_job,
-                                                  const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
-                                                  uint32_t* __restrict__ entries) {
-  const uint32_t job = blockIdx.y;
-  const size_t n = jobs.n[job];
-  if ((size_t)blockIdx.x * blockDim.x >= n) return;
-  const int32_t* __restrict__ digits = digits_all + (size_t)job * digits_per_job;
-  const size_t tab_stride = jobs.tab_stride[job];
-  const uint32_t bucket_base = job * B_per_job;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  if (!live) i = n - 1;
-  const uint32_t B = 1u << (c - 1);
-  const uint32_t lane = threadIdx.x & 63;
-  if (merged == 2) {                                   // NAF digits: sign | position << 22 | magnitude (k_scalar_digits)
-    // the low buckets (over-represented: see k_scalar_digits) get their places per BLOCK: count in LDS, one global atomic per block
-    // and bucket, then ranks from a second LDS counter
-    __shared__ uint32_t s_cnt[NAF_LOW_BUCKETS], s_base[NAF_LOW_BUCKETS];
-    if (threadIdx.x < NAF_LOW_BUCKETS) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (int w = 0; w < W; w++) {
-      const uint32_t pk = live ? (uint32_t)digits[(size_t)w * n + i] : 0u;
-      const uint32_t mag = pk & 0x3fffffu;
-      if (mag != 0 && ((mag - 1) >> 1) < NAF_LOW_BUCKETS) atomicAdd(&s_cnt[(mag - 1) >> 1], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < NAF_LOW_BUCKETS) {
-      const uint32_t cnt = s_cnt[threadIdx.x];
-      s_base[threadIdx.x] = cnt ? atomicAdd(&cursor[(size_t)bucket_base + threadIdx.x], cnt) : 0u;
-      s_cnt[threadIdx.x] = 0;
-    }
-    __syncthreads();
-    for (int w = 0; w < W; w++) {
-      const uint32_t pk = live ? (uint32_t)digits[(size_t)w * n + i] : 0u;
-      const uint32_t mag = pk & 0x3fffffu, pos_bit = (pk >> 22) & 0x1ffu;
-      if (mag == 0) continue;
-      const uint32_t bl = (mag - 1) >> 1;
-      const size_t b = (size_t)bucket_base + bl;
-      uint32_t pos;
-      if (bl < NAF_LOW_BUCKETS) pos = offsets[b] + s_base[bl] + atomicAdd(&s_cnt[bl], 1u);
-      else pos = offsets[b] + atomicAdd(&cursor[b], 1u);
-      entries[pos] = (uint32_t)((size_t)pos_bit * tab_stride + i) | (pk & 0x80000000u);
-    }
-    return;
-  }
-  for (int w = 0; w < W; w++) {
-    int32_t sd = live ? digits[(size_t)w * n + i] : 0;
-    const bool hot = (w == 0) && (sd == 1);            // wave-aggregated slot allocation for the hot bucket
-    const unsigned long long hot_mask = __ballot(hot);
-    if (hot_mask) {
-      const int leader = __ffsll((long long)hot_mask) - 1;
-      uint32_t base = 0;
-      if ((int)lane == leader) base = atomicAdd(&cursor[bucket_base], (uint32_t)__popcll(hot_mask));
-      base = __shfl(base, leader);
-      if (hot) entries[offsets[bucket_base] + base + (uint32_t)__popcll(hot_mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
-    }
-    if (sd == 0 || hot) continue;
-    uint32_t mag = sd < 0 ? (uint32_t)(-sd) : (uint32_t)sd;
-    size_t b = (merged ? (size_t)bucket_base : (size_t)w * B) + (mag - 1);
-    uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
-    entries[pos] = (uint32_t)(merged ? (size_t)w * tab_stride + i : i) | (sd < 0 ? 0x80000000u : 0u);
-  }
 }
 
 // Bucket accumulation, load-balanced: lane t owns the fixed-size slice [tS, (t+1)S) of the
@@ -390,7 +445,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
     uint32_t e = e_next;
     if (k + 1 < pos1) e_next = dense ? k + 1 : entries[k + 1];        // fetched a whole addition ahead of its use
     const AffPacked* p = (dense ? bp.p[0] : base_of<NJ>(bp, b >> bshift)) + (e & 0x7fffffffu);
-    bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_scalar_digits drops them)
+    bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_digit_pass drops them)
     if (dense && p->x[23] == ZK_AFF_INF_WORD) continue;        // a pair of the levels below cancelled
     if (inf) {
 #pragma unroll
@@ -1051,11 +1106,26 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done, hipEventBlockingSync | hipEventDisableTiming));
   if ((size_t)ctx->Wd * max_n >= ((size_t)1 << 31)) return ZKHIP_ERR_ARG;   // entry = 31-bit point index + sign
   if ((size_t)ctx->Wd * max_n * K >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;  // positions in the entry list are 32-bit
-  HIP_TRY(hipMalloc(&ctx->digits, (size_t)K * ctx->Wd * max_n * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&ctx->counts, 2 * nb * 4));          // counts | cursor: one allocation, cleared by one fill per MSM
-  ctx->cursor = ctx->counts + nb;
+  // geometry of the bucket sort: parts of 2^LB buckets (LB <= 10: k_bucket_sort keeps a part's counters in LDS); small bucket
+  // windows get smaller parts so that k_bucket_sort still has about a thousand workgroups to spread over the chip
+  {
+    uint32_t LB = (uint32_t)(c - 1 < 10 ? c - 1 : 10);
+    while (LB > 6 && (nb >> LB) < 1024 && (ctx->B >> (LB - 1)) * (merged ? 1 : (size_t)ctx->Wd) <= 4096) LB--;
+    ctx->sort_LB = LB;
+    ctx->sort_NP = (uint32_t)(ctx->B >> LB);
+    ctx->sort_bins = merged ? ctx->sort_NP : ctx->sort_NP * (uint32_t)ctx->Wd;
+    if ((size_t)ctx->sort_bins * 8 > 60 * 1024) return ZKHIP_ERR_ARG;             // LDS of k_digit_pass<1>: counters + bases
+    uint32_t tile = 1024;
+    while ((max_n + tile - 1) / tile > 1024) tile *= 2;
+    ctx->sort_tile = tile;
+    const size_t nbx = (max_n + tile - 1) / tile;
+    ctx->hist_len = (nb >> LB) * (nbx ? nbx : 1) + 1;
+  }
+  HIP_TRY(hipMalloc(&ctx->hist, ctx->hist_len * 4));
+  HIP_TRY(hipMalloc(&ctx->pairs, ((size_t)K * ctx->Wd * max_n + 1) * sizeof(uint2)));
+  HIP_TRY(hipMalloc(&ctx->counts, nb * 4));
   HIP_TRY(hipMalloc(&ctx->offsets, nb * 4));
-  HIP_TRY(hipMalloc(&ctx->block_tot, (nb / 1024 + 2) * 4));
+  HIP_TRY(hipMalloc(&ctx->block_tot, ((nb > ctx->hist_len ? nb : ctx->hist_len) / 1024 + 2) * 4));
   HIP_TRY(hipMalloc(&ctx->entries, (size_t)K * ctx->Wd * max_n * 4));
   // batched-affine levels: bounds on the level sizes, the buffers of their outputs
   {
@@ -1119,7 +1189,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
 }
 
 void msm_plan_free(MsmCtx* ctx) {
-  void* ptrs[] = {ctx->digits, ctx->counts, ctx->offsets, ctx->block_tot, ctx->entries, ctx->buckets,
+  void* ptrs[] = {ctx->hist, ctx->pairs, ctx->counts, ctx->offsets, ctx->block_tot, ctx->entries, ctx->buckets,
                   ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi,
                   ctx->colS[0], ctx->colS[1], ctx->hilo, ctx->pbuf[0], ctx->pbuf[1], ctx->aff_scratch,
                   ctx->lcnt[0], ctx->lcnt[1], ctx->lcnt[2], ctx->lcnt[3], ctx->loff[0], ctx->loff[1], ctx->loff[2], ctx->loff[3],
@@ -1177,7 +1247,6 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   hipStream_t st = ctx->stream;
   ctx->pending_n = n_tot;
   if (n_tot == 0) { ctx->pending = true; return ZKHIP_OK; }
-  HIP_TRY(hipMemsetAsync(ctx->counts, 0, 2 * nb * 4, st));      // counts and cursor
   WindowPlan plan;
   memset(&plan, 0, sizeof plan);
   for (int w = 0; w < Wd; w++) { plan.off[w] = ctx->win_off[w]; plan.bits[w] = ctx->win_bits[w]; }
@@ -1189,17 +1258,30 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     dj.mode[k] = jobs[k].scalars_mode;
     if (jobs[k].n > n_max) n_max = jobs[k].n;
   }
-  const size_t digits_per_job = (size_t)Wd * ctx->max_n;
-  hipLaunchKernelGGL(k_scalar_digits, dim3(nblk(n_max, 256), K), dim3(256), 0, st, dj, c, Wd, plan, merged, (uint32_t)B, digits_per_job, ctx->digits,
-                     ctx->counts);
-  unsigned sb = nblk(nb, 1024);
-  hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->counts, ctx->offsets, ctx->block_tot, nb);
+  // bucket sort: count per (part, block) in LDS, scan, place by part, then order every part by its low bucket bits.  The bucket
+  // windows of the jobs this call does not use (K < ctx->K) stay empty: their rows of hist are written as zeros by grid row k.
+  SortGeom ge;
+  ge.LB = ctx->sort_LB; ge.NP = ctx->sort_NP; ge.bins = ctx->sort_bins; ge.tile = ctx->sort_tile;
+  ge.nbx = (uint32_t)((n_max + ge.tile - 1) / ge.tile);
+  ge.nparts = (uint32_t)(nb >> ge.LB);
+  const size_t hist_m = (size_t)ge.nparts * ge.nbx + 1;
+  if (hist_m > ctx->hist_len) return ZKHIP_ERR_ARG;
+  const int KK = merged ? ctx->K : 1;                            // every bucket window's rows of hist are (re)written
+  for (int k = K; k < KK; k++) dj.n[k] = 0;
+  const dim3 dgrid(ge.nbx, KK);
+  const size_t lds0 = (size_t)ge.bins * 4, lds1 = (size_t)ge.bins * 8;
+  if (merged == 2) hipLaunchKernelGGL((k_digit_pass<0, true>), dgrid, dim3(256), lds0, st, dj, c, Wd, plan, merged, (uint32_t)B, ge, ctx->hist, ctx->pairs);
+  else hipLaunchKernelGGL((k_digit_pass<0, false>), dgrid, dim3(256), lds0, st, dj, c, Wd, plan, merged, (uint32_t)B, ge, ctx->hist, ctx->pairs);
+  unsigned sb = nblk(hist_m, 1024);
+  hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->hist, ctx->hist, ctx->block_tot, hist_m);
   hipLaunchKernelGGL(k_scan_tot, dim3(1), dim3(1024), 0, st, ctx->block_tot, (size_t)sb);
-  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, ctx->offsets, ctx->block_tot, nb);
+  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, ctx->hist, ctx->block_tot, hist_m);
+  if (merged == 2) hipLaunchKernelGGL((k_digit_pass<1, true>), dgrid, dim3(256), lds1, st, dj, c, Wd, plan, merged, (uint32_t)B, ge, ctx->hist, ctx->pairs);
+  else hipLaunchKernelGGL((k_digit_pass<1, false>), dgrid, dim3(256), lds1, st, dj, c, Wd, plan, merged, (uint32_t)B, ge, ctx->hist, ctx->pairs);
+  hipLaunchKernelGGL(k_bucket_sort, dim3(ge.nparts), dim3(512), 0, st, ctx->hist, ge, ctx->pairs, ctx->entries, ctx->offsets, ctx->counts);
+  sb = nblk(nb, 1024);                                            // (the batched-affine levels below scan arrays of nb counters)
   BasePtrs bp;
   for (int k = 0; k < MSM_MAX_JOBS; k++) bp.p[k] = jobs[k < K ? k : 0].bases;
-  hipLaunchKernelGGL(k_scatter, dim3(nblk(n_max, 256), K), dim3(256), 0, st, dj, ctx->digits, digits_per_job, c, Wd, merged, (uint32_t)B, ctx->offsets,
-                     ctx->cursor, ctx->entries);
   const int bshift = merged ? c - 1 : 31;     // bucket -> job
   if (ctx->aff_levels > 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));     // the timed accumulation includes the affine levels
   // ---- batched-affine levels: the sorted list is summed pairwise inside every bucket, ctx->aff_levels times
