@@ -333,8 +333,9 @@ __device__ __forceinline__ void add_mem_s(const XyzzRef& A, const XyzzRef& B, ui
   }
   Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
   bool same_x = false;
+  // twelve single products, then Y3 = R (Q - X3) + (-S1) PPP as one dual product (one reduction: fp_mul2)
 #pragma unroll 1
-  for (int step = 0; step < 14; step++) {
+  for (int step = 0; step < 12; step++) {
     Fq a, b;
     switch (step) {
       case 0: a = mem_ld(A, CX); b = mem_ld(B, CZZ); break;          // U1
@@ -348,9 +349,7 @@ __device__ __forceinline__ void add_mem_s(const XyzzRef& A, const XyzzRef& B, ui
       case 8: a = mem_ld(B, CY); b = lds_ld(zzz); break;             // S2
       case 9: a = lds_ld(zzz); b = T1; break;                        // ZZZ1 PPP
       case 10: a = lds_ld(zzz); b = mem_ld(B, CZZZ); break;          // (ZZZ1 PPP) ZZZ2
-      case 11: a = T2; b = T1; break;                                // Y3b = S1 PPP
-      case 12: a = T3; b = T3; break;                                // RR
-      default: a = T3; b = fp_sub<FqParams, 16>(T0, T1); break;      // Y3a = R (Q - X3)
+      default: a = T3; b = T3; break;                                // RR
     }
     Fq r = fp_mul(a, b);
     switch (step) {
@@ -365,21 +364,26 @@ __device__ __forceinline__ void add_mem_s(const XyzzRef& A, const XyzzRef& B, ui
       case 8: T3 = fp_sub<FqParams, 2>(r, T2); break;                // R [4]
       case 9: lds_st(zzz, r); break;
       case 10: mem_st(A, CZZZ, r); break;                            // ZZZ3
-      case 11: T2 = r; break;                                        // Y3b
-      case 12: T1 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T1), fp_dbl(T0)); mem_st(A, CX, T1); break;   // X3 [10]
-      default: mem_st(A, CY, fp_sub<FqParams, 2>(r, T2)); break;     // Y3 [4]
+      default: {
+        Fq X3 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T1), fp_dbl(T0));   // X3 [10]
+        mem_st(A, CX, X3);
+        T0 = fp_sub<FqParams, 16>(T0, X3);                           // Q - X3 [18]
+        break;
+      }
     }
     if (same_x) break;
   }
-  if (same_x) add_same_x(A, B);     // memory still holds A's original ZZ, ZZZ at this point (first stores are steps 6 and 10)
+  if (same_x) { add_same_x(A, B); return; }   // memory still holds A's original ZZ, ZZZ at this point (first stores are steps 6 and 10)
+  mem_st(A, CY, fp_mul2(T3, T0, fp_sub<FqParams, 2>(fp_zero<FqParams>(), T2), T1));   // Y3 = R (Q - X3) + (2p - S1) PPP  [2]
 }
 
 // a (memory) = 2 a.   dbl-2008-s-1 as a micro-program: 9 multiplications
 __device__ __forceinline__ void dbl_mem(const XyzzRef& A) {
   if (mem_is_inf(A)) return;
   Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
+  // seven single products, then Y3 = M (S - X3) + W (-Y1) as one dual product (fp_mul2)
 #pragma unroll 1
-  for (int step = 0; step < 9; step++) {
+  for (int step = 0; step < 7; step++) {
     Fq a, b;
     switch (step) {
       case 0: a = fp_dbl(mem_ld(A, CY)); b = a; break;               // V = U^2, U = 2 Y1 [8]
@@ -388,9 +392,7 @@ __device__ __forceinline__ void dbl_mem(const XyzzRef& A) {
       case 3: a = mem_ld(A, CZZ); b = T0; break;                     // ZZ3 = V ZZ1
       case 4: a = mem_ld(A, CZZZ); b = T1; break;                    // ZZZ3 = W ZZZ1
       case 5: a = mem_ld(A, CX); b = a; break;                       // X1^2
-      case 6: a = T3; b = T3; break;                                 // M^2
-      case 7: a = T1; b = mem_ld(A, CY); break;                      // W Y1
-      default: a = T3; b = fp_sub<FqParams, 8>(T2, T0); break;       // M (S - X3)
+      default: a = T3; b = T3; break;                                // M^2
     }
     Fq r = fp_mul(a, b);
     switch (step) {
@@ -400,11 +402,13 @@ __device__ __forceinline__ void dbl_mem(const XyzzRef& A) {
       case 3: mem_st(A, CZZ, r); break;                              // (U = 0 gives ZZ3 = 0: infinity)
       case 4: mem_st(A, CZZZ, r); break;
       case 5: T3 = fp_add(fp_dbl(r), r); break;                      // M = 3 X1^2 [6]
-      case 6: T0 = fp_sub<FqParams, 4>(r, fp_dbl(T2)); mem_st(A, CX, T0); break;   // X3 = M^2 - 2S [6]
-      case 7: T1 = r; break;                                         // W Y1
-      default: mem_st(A, CY, fp_sub<FqParams, 2>(r, T1)); break;     // Y3 [4]
+      default: T0 = fp_sub<FqParams, 4>(r, fp_dbl(T2)); break;       // X3 = M^2 - 2S [6]
     }
   }
+  // Y3 = M (S - X3) + W (4p - Y1): [6] x [10] + [2] x [4] -> [2]   (Y1 is read before X3 overwrites nothing it needs: CX only)
+  Fq Y3 = fp_mul2(T3, fp_sub<FqParams, 8>(T2, T0), T1, fp_sub<FqParams, 4>(fp_zero<FqParams>(), mem_ld(A, CY)));
+  mem_st(A, CX, T0);
+  mem_st(A, CY, Y3);
 }
 
 

@@ -9,7 +9,7 @@
 //   k_scan_*            exclusive prefix sum of the (part, block) histogram
 //   k_bucket_sort       a workgroup per part orders its entries by bucket: bucket-ordered list of (point index, sign), offsets, counts
 //   k_accumulate        one lane per fixed-size SLICE of the sorted list: XYZZ mixed additions   <-- dominant
-//   k_fixup_round/_fixup  stitch the buckets that slice boundaries cut
+//   k_fixup_short/_tree/_fixup  stitch the buckets that slice boundaries cut
 //   k_sum / k_seg       bucket reduction  sum_j (j+1) B_j : two-level split of the bucket index, then L-ary running sums
 //   k_window_combine / k_hilo_combine   per bucket window: Horner over the levels, R * hi + lo
 // Plain base sets: one bucket window per digit position, and the last step, sum_w 2^(off_w) W_w (about 380 serial
@@ -398,16 +398,41 @@ template <int NJ>
 __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, const uint32_t* __restrict__ entries,
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                         uint32_t nb, uint32_t S, uint32_t T, uint32_t* __restrict__ slots,
-                                                        uint32_t stride, uint32_t* __restrict__ max_span) {
+                                                        uint32_t stride, uint32_t* __restrict__ fix_cnt /* [2] */, uint2* __restrict__ fix_short, uint2* __restrict__ fix_long) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
   uint32_t pos0 = t * S;
   if (t >= T || pos0 >= M) return;
   uint32_t pos1 = min(pos0 + S, M);
   uint32_t b = bucket_of(offsets, nb, pos0);
-  if (offsets[b] < pos0) {   // this slice starts inside bucket b: an F piece; record how many F pieces b has
-    uint32_t span = (offsets[b] + counts[b] - 1) / S - offsets[b] / S;
-    if (span > 1) atomicMax(max_span, span);
+  {
+    // A bucket cut by slice boundaries leaves an L piece (slice t0, where it starts) and F pieces in the slices t0+1 .. t1.  The
+    // slice that holds the FIRST F piece of a bucket with several of them puts the bucket on a list: (first F slot, number of F
+    // pieces) - a short list (2 .. 4 pieces: one lane folds them, k_fixup_short) and a long one (k_fixup_tree).  One atomic per
+    // wave and list.
+    uint32_t span = 0, tF0 = 0;
+    if (offsets[b] < pos0) {
+      tF0 = offsets[b] / S + 1;
+      span = (offsets[b] + counts[b] - 1) / S - offsets[b] / S;       // number of F pieces
+      if (t != tF0) span = 0;
+    }
+    const bool is_short = span >= 2 && span <= 4, is_long = span > 4;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long ms = __ballot(is_short), ml = __ballot(is_long);
+    if (ms) {
+      const int leader = __ffsll((long long)ms) - 1;
+      uint32_t base = 0;
+      if ((int)lane == leader) base = atomicAdd(&fix_cnt[0], (uint32_t)__popcll(ms));
+      base = __shfl(base, leader);
+      if (is_short) fix_short[base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull))] = make_uint2(tF0, span);
+    }
+    if (ml) {
+      const int leader = __ffsll((long long)ml) - 1;
+      uint32_t base = 0;
+      if ((int)lane == leader) base = atomicAdd(&fix_cnt[1], (uint32_t)__popcll(ml));
+      base = __shfl(base, leader);
+      if (is_long) fix_long[base + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull))] = make_uint2(tF0, tF0 + span - 1);
+    }
   }
   uint32_t bend = pos0;            // forces the run set-up on the first iteration
   bool first = true;
@@ -693,35 +718,25 @@ template <bool QUAD> __device__ __forceinline__ void pt_set_inf(const XyzzRef& d
   if constexpr (QUAD) mem_st_lane(dst, q, fp_zero<FqParams>()); else mem_set_inf(dst);
 }
 
-// Stitch buckets that were cut by slice boundaries.  A bucket that starts in slice t0 and ends in
-// slice t1 > t0 has pieces L[t0], F[t0+1], ..., F[t1].  k_fixup_round(d), d = 1, 2, 4, ... folds the
-// F pieces pairwise (F[t] += F[t+d] for t - (t0+1) divisible by 2d), so a bucket of any
-// population - e.g. "scalar == 1" in a boolean-heavy witness - is stitched in log2(pieces) steps;
-// rounds beyond the largest span exit at once (max_span is written by k_accumulate).
-template <bool QUAD>
-__global__ void __launch_bounds__(256, 2) k_fixup_round(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                         uint32_t nb, uint32_t S, uint32_t T, uint32_t d,
-                                                         const uint32_t* __restrict__ max_span, uint32_t* __restrict__ slots,
-                                                         uint32_t stride, uint32_t* __restrict__ work_cnt, uint2* __restrict__ work_list) {
-  ADD_SCRATCH_DECL(QUAD);
-  if (d >= *max_span) return;
-  uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt, q = gt & 3u;   // one lane or one quad per slice
-  const uint32_t M = offsets[nb - 1] + counts[nb - 1];
-  uint32_t pos0 = t * S;
-  if (t >= T || pos0 >= M) return;
-  uint32_t b = bucket_of(offsets, nb, pos0);
-  if (offsets[b] >= pos0) return;                       // slice does not start inside a bucket
-  uint32_t tF0 = offsets[b] / S + 1, tF1 = (offsets[b] + counts[b] - 1) / S;
-  // a bucket of more than two pieces goes on the list of k_fixup_tree (first round only; at most T / 3 of them)
-  if (work_list && t == tF0 && tF1 - tF0 >= 2 && (!QUAD || q == 0)) work_list[atomicAdd(work_cnt, 1u)] = make_uint2(tF0, tF1);
-  if ((t - tF0) % (2 * d) != 0 || t + d > tF1) return;
-  pt_add<QUAD>(make_ref(slots, stride, nb + t), make_ref(slots, stride, nb + t + d), q, sc);
+// Stitch buckets that were cut by slice boundaries.  A bucket that starts in slice t0 and ends in slice t1 > t0 has pieces L[t0],
+// F[t0+1], ..., F[t1].  First the F pieces are folded into F[t0+1]: buckets of 2 .. 4 F pieces by one lane each, densely over the
+// list k_accumulate made (with uniform scalars a few percent of the buckets have two F pieces, none more: one launch over every
+// slice, as rounds 1-2 had it, kept every wave busy for the sake of one lane in twelve); buckets of more pieces - "scalar == 1"
+// in a boolean-heavy witness holds a third of all entries - by a workgroup each, pairwise, in log2(pieces) rounds.
+__global__ void __launch_bounds__(256, 2) k_fixup_short(const uint32_t* __restrict__ cnt, const uint2* __restrict__ list, uint32_t nb,
+                                                         uint32_t* __restrict__ slots, uint32_t stride) {
+  ADD_SCRATCH_DECL(false);
+  const uint32_t n = *cnt;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint2 w = list[i];                          // first F slot, number of F pieces
+    const XyzzRef dst = make_ref(slots, stride, nb + w.x);
+    for (uint32_t j = 1; j < w.y; j++) add_mem_s(dst, make_ref(slots, stride, nb + w.x + j), sc.zz, sc.zzz);
+  }
 }
 
-// Rounds d = 2, 4, ... of the stitching for the buckets of more than two pieces (the list the first round made), ALL rounds in
-// one launch: a workgroup takes a bucket, its 64 quads fold the pieces pairwise, a barrier between rounds (the pieces live in
-// global memory, coherent inside a CU).  Such buckets are few ("scalar = 1" in a boolean-heavy witness) but long: one launch per
-// round meant sixteen launches per MSM that mostly found nothing to do.
+// Buckets of more than four F pieces (the long list): ALL rounds d = 1, 2, 4, ... in one launch: a workgroup takes a bucket, its 64
+// quads fold the pieces pairwise (F[t] += F[t+d] for t - first divisible by 2d), a barrier between rounds (the pieces live in
+// global memory, coherent inside a CU).  Such buckets are few but long.
 __global__ void __launch_bounds__(256, 2) k_fixup_tree(const uint32_t* __restrict__ work_cnt, const uint2* __restrict__ work_list, uint32_t nb,
                                                         uint32_t* __restrict__ slots, uint32_t stride) {
   ADD_SCRATCH_DECL(true);
@@ -730,7 +745,7 @@ __global__ void __launch_bounds__(256, 2) k_fixup_tree(const uint32_t* __restric
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
     const uint2 w = work_list[i];                     // first and last F piece of the bucket
 #pragma unroll 1
-    for (uint32_t d = 2; d <= w.y - w.x; d <<= 1) {
+    for (uint32_t d = 1; d <= w.y - w.x; d <<= 1) {
       for (uint64_t t = (uint64_t)w.x + (uint64_t)quad * 2 * d; t + d <= w.y; t += (uint64_t)64 * 2 * d)
         pt_add<true>(make_ref(slots, stride, nb + (uint32_t)t), make_ref(slots, stride, nb + (uint32_t)t + d), q, sc);
       __threadfence_block();
@@ -1172,7 +1187,8 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
     if ((size_t)ctx->slot_stride * 108 * 4 >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;
   }
   HIP_TRY(hipMalloc(&ctx->buckets, (size_t)ctx->slot_stride * 108 * 4));
-  HIP_TRY(hipMalloc(&ctx->fix_list, ((size_t)ctx->T / 3 + 2) * sizeof(uint2)));     // buckets cut into more than two pieces: at most T / 3
+  HIP_TRY(hipMalloc(&ctx->fix_list, ((size_t)ctx->T / 5 + 2) * sizeof(uint2)));     // buckets of more than four F pieces: at most T / 5
+  HIP_TRY(hipMalloc(&ctx->fix_short, ((size_t)ctx->T / 2 + 2) * sizeof(uint2)));    // buckets of two to four F pieces: at most T / 2
   // reduction scratch: S ping-pong (<= nb/L each) and R arrays (sum over levels <= nb/L * L/(L-1)), R sums
   HIP_TRY(hipMalloc(&ctx->segS[0], (nb / 2 + 1) * 108 * 4));
   HIP_TRY(hipMalloc(&ctx->segS[1], (nb / 2 + 1) * 108 * 4));
@@ -1193,7 +1209,7 @@ void msm_plan_free(MsmCtx* ctx) {
                   ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi,
                   ctx->colS[0], ctx->colS[1], ctx->hilo, ctx->pbuf[0], ctx->pbuf[1], ctx->aff_scratch,
                   ctx->lcnt[0], ctx->lcnt[1], ctx->lcnt[2], ctx->lcnt[3], ctx->loff[0], ctx->loff[1], ctx->loff[2], ctx->loff[3],
-                  ctx->fix_list};
+                  ctx->fix_list, ctx->fix_short};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->win_host) (void)hipHostFree(ctx->win_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1323,7 +1339,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   }
   const bool dense = ctx->aff_levels > 0;
   if (dense) bp.p[0] = ctx->pbuf[(ctx->aff_levels - 1) & 1];
-  HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 8, st));   // block_tot[0] is reused as the max-span cell, [1] as the length of fix_list (scans are done)
+  HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 8, st));   // block_tot[0], [1] are reused as the lengths of the two stitching lists (scans are done)
   // slice length for THIS n (the plan's slot array is sized for max_n)
   uint32_t S_run, T_run;
   {
@@ -1340,18 +1356,17 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   const uint32_t* acc_entries = dense ? nullptr : ctx->entries;
   if (ctx->K == 1 || dense)
     hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off, cur_cnt,
-                       (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
+                       (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list);
   else
     hipLaunchKernelGGL(k_accumulate<MSM_MAX_JOBS>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off,
-                       cur_cnt, (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0);
+                       cur_cnt, (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
-  // the first round touches up to every slice (throughput-bound: one lane per addition) and lists the buckets of more than two
-  // pieces; their remaining rounds are latency-bound (a quad per addition) and run in one launch
-  if (T_run > 1)
-    hipLaunchKernelGGL(k_fixup_round<false>, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, T_run,
-                       1u, ctx->block_tot + 0, ctx->buckets, ctx->slot_stride, ctx->block_tot + 1, ctx->fix_list);
-  if (T_run > 2)
+  // fold the F pieces of the buckets that have several (lists made by k_accumulate), then L + F for every cut bucket
+  if (T_run > 2) {
+    hipLaunchKernelGGL(k_fixup_short, dim3(nblk(T_run / 2 < 256 * 512 ? T_run / 2 + 1 : 256 * 512, 256)), dim3(256), 0, st, ctx->block_tot + 0, ctx->fix_short,
+                       (uint32_t)nb, ctx->buckets, ctx->slot_stride);
     hipLaunchKernelGGL(k_fixup_tree, dim3(128), dim3(256), 0, st, ctx->block_tot + 1, ctx->fix_list, (uint32_t)nb, ctx->buckets, ctx->slot_stride);
+  }
   hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, T_run,
                      ctx->buckets, ctx->slot_stride);
   HIP_TRY(hipGetLastError());
