@@ -53,10 +53,24 @@ void zkhip_shutdown(void);
 const char* zkhip_strerror(int code);
 const char* zkhip_last_error(void);
 
-/* Window size (bits) of the bucket method; 0 = automatic from len. */
+/* Options of a base set / proving key.  They are resolved ONCE, when the key is uploaded, and travel with the handle: two threads
+ * (or two GPUs) loading keys with different options do not see each other's choice.  A field left at its "default" value takes
+ * the process-wide default, i.e. what the deprecated zkhip_set_* switches below last set. */
+typedef struct {
+  int precompute;   /* -1: default (on);  0: plain base sets;  1: window tables (2^(c w) P_i for every window position) */
+  int table_naf;    /* -1: default (off, or ZKHIP_TABLE_NAF);  0: one table level per window;  1: EVERY bit position + scalars in
+                       non-adjacent form (378 levels: within ZKHIP_NAF_TABLE_GB, default 48 GB per key, else one level per window) */
+  int window;       /*  0: automatic from the length;  else the window c of the table, in [4, 22] */
+  int batch_msms;   /* -1: default (on);  0: one launch sequence per MSM;  1: the five MSMs of a proof in one launch sequence */
+} zkhip_key_opts;
+#define ZKHIP_KEY_OPTS_DEFAULT {-1, -1, 0, -1}
+
+/* DEPRECATED process-wide switches (kept for callers of rounds 1-2): they set the DEFAULTS that zkhip_key_opts falls back to.
+ * Window size (bits) of the bucket method; 0 = automatic from len. */
 int zkhip_set_msm_window(int c);
 /* Bucket accumulation: number of batched-affine levels (pairwise sums inside the buckets, one shared inversion per lane) that
- * run before the XYZZ accumulation; -1 = automatic from the size (0 for small inputs).  Results do not depend on it. */
+ * run before the XYZZ accumulation; -1 = automatic (currently NONE at every size: measured slower on gfx950).  A
+ * measurement / test knob, process-wide, read when an MSM plan is made.  Results do not depend on it. */
 int zkhip_set_affine_levels(int levels);
 
 /* replaces: holding r1cs_gg_ppzksnark_proving_key query vectors in host memory
@@ -72,6 +86,8 @@ void zkhip_bases_free(zkhip_bases* b);
  * unchanged (same group element).  c = 0 chooses the window from the length.  zkhip_crs_upload builds the tables of a
  * key by default; zkhip_set_crs_precompute(0) turns that off. */
 int zkhip_bases_precompute(zkhip_bases* b, int c);
+/* the same with the kind of table as an argument (zkhip_key_opts.table_naf: -1 default, 0 one level per window, 1 every bit position) */
+int zkhip_bases_precompute_ex(zkhip_bases* b, int c, int table_naf);
 int zkhip_bases_table_window(const zkhip_bases* b);      /* 0: no table */
 int zkhip_set_crs_precompute(int on);
 /* on = 1: window tables built from now on hold EVERY bit position (378 levels, sixteen times the memory) and scalars are recoded in
@@ -155,7 +171,13 @@ typedef struct {
 } zkhip_crs_desc;
 typedef struct zkhip_crs zkhip_crs;
 int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out);
+/* the same with the key's options as an argument (opts == NULL: all defaults) */
+int zkhip_crs_upload_ex(const zkhip_crs_desc* d, const zkhip_key_opts* opts, zkhip_crs** out);
 void zkhip_crs_free(zkhip_crs* c);
+int zkhip_crs_table_kind(const zkhip_crs* c);            /* 0: no tables, 1: one level per window, 2: every bit position (NAF scalars) */
+/* bases of the five query vectors (A, B-G2, B-G1, H, L) that are not the point at infinity: the terms an MSM over the key can
+ * actually have (a base at infinity produces no bucket entry) */
+int zkhip_crs_finite_terms(const zkhip_crs* c, size_t out[5]);
 int zkhip_crs_table_window(const zkhip_crs* c);          /* window of the key's tables, 0: none */
 int zkhip_crs_device(const zkhip_crs* c);                /* the GPU that holds the key */
 
@@ -174,6 +196,8 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
  * zkhip_groth16_prove is exactly prove_partial over the whole key followed by finish. */
 int zkhip_crs_upload_slice(const zkhip_crs_desc* full_key, size_t a_lo, size_t a_len, size_t h_lo, size_t h_len, size_t l_lo, size_t l_len,
                            zkhip_crs** out);
+int zkhip_crs_upload_slice_ex(const zkhip_crs_desc* full_key, size_t a_lo, size_t a_len, size_t h_lo, size_t h_len, size_t l_lo, size_t l_len,
+                              const zkhip_key_opts* opts, zkhip_crs** out);
 int zkhip_groth16_prove_partial(const zkhip_crs* crs_slice, zkhip_r1cs* r1cs, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
                                 uint64_t sums_jac[180]);
 int zkhip_groth16_finish(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],

@@ -288,3 +288,63 @@ def test_entry_points_bind_their_device_on_any_thread(zk):
     with pytest.raises(zk.ZkhipError):
         zk.set_device(15)               # never initialised
     crs.free(); r1.free(); kp.free(); agg.free()
+
+
+@pytest.mark.parametrize("naf", [False, True], ids=["window-tables", "naf-tables"])
+@pytest.mark.parametrize("gpu_witness", [False, True], ids=["host-witness", "gpu-witness"])
+def test_wrapping_proof_equals_oracle(zk, oracle_lib, naf, gpu_witness):
+    """The checks of aggregator_dummy_test.cpp:61-96 with the ORACLE as the judge of the proof itself: the assignment of the real
+    batch-2 circuit (reference fixtures) goes through the C restatement of r1cs_to_qap_witness_map + r1cs_gg_ppzksnark_prover and
+    through the GPU prover with the same (r, s) uniform in Fr - the three proof elements must agree limb for limb, for both kinds
+    of window table and for the assignment generated on the host and on the GPU.  (Rounds 1-2 held this comparison in bench.py only.)"""
+    from tests.helpers import random_fr_uniform
+    O = oracle_lib
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    crs = kp.upload_crs(zk.key_opts(table_naf=naf))
+    assert crs.table_kind == (2 if naf else 1)
+    r1 = zk.r1cs_from_desc(desc)
+    (p1, in1), (p2, in2) = proofs[0], proofs[1]
+    npr = np.concatenate([nested_proof_limbs(p1), nested_proof_limbs(p2)])
+    l = agg.num_primary_inputs()
+    pk, m, l_pk, dom = kp.pk_arrays()
+    assert l_pk == l
+    A, B, C = agg.get_constraint_system()
+    rs = random_fr_uniform(1234, 2)                       # canonical limbs below r are valid Montgomery residues: uniform in Fr
+    for bump, bits in ((0, 3), (1, 1)):
+        nin = np.array([fr_limbs(in1[0]), fr_limbs(in2[0] + bump)])
+        z = agg.witness_gpu(nvk_l, npr, nin) if gpu_witness else agg.witness(nvk_l, npr, nin)
+        assert O.r1cs_first_unsatisfied(A, B, C, z) == -1
+        h = O.qap_h(A, B, C, z, agg.num_constraints, l)
+        assert (r1.qap_h(z) == h).all()                   # coefficients_for_H, limb for limb
+        expect = O.groth16_prove(pk, z, l, h, rs[0], rs[1])
+        got = zk.groth16_prove(crs, r1, z, rs[0], rs[1])
+        assert (got == expect).all()
+        assert zk.groth16_verify(kp.vk(), z[1:1 + l], got) and fr_int(z[2]) == bits
+    crs.free(); r1.free(); kp.free(); agg.free()
+
+
+def test_two_threads_load_keys_with_different_options(zk):
+    """zkhip_key_opts travel with the handle: a default key and an every-bit-position key uploaded AT THE SAME TIME from two threads
+    each get the kind of table they asked for (the process-wide switches of rounds 1-2 raced here), and both prove the same proof."""
+    from concurrent.futures import ThreadPoolExecutor
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    r1 = zk.r1cs_from_desc(desc)
+    (p1, in1), (p2, in2) = proofs[2], proofs[3]
+    z = agg.witness(nvk_l, np.concatenate([nested_proof_limbs(p1), nested_proof_limbs(p2)]), np.array([fr_limbs(in1[0]), fr_limbs(in2[0])]))
+    r, s_ = fr_limbs(0x77), fr_limbs(0x99)
+    for rep in range(3):
+        with ThreadPoolExecutor(max_workers=3) as pool:
+            futs = [pool.submit(kp.upload_crs, zk.key_opts(table_naf=False)), pool.submit(kp.upload_crs, zk.key_opts(table_naf=True)),
+                    pool.submit(kp.upload_crs, zk.key_opts(precompute=False))]
+            keys = [f.result() for f in futs]
+        assert [k.table_kind for k in keys] == [1, 2, 0]
+        with ThreadPoolExecutor(max_workers=3) as pool:
+            provers = [zk.Prover(k, desc) for k in keys]
+            got = [f.result() for f in [pool.submit(p.prove, z, r, s_) for p in provers]]
+        assert (got[0] == got[1]).all() and (got[0] == got[2]).all()
+        assert zk.groth16_verify(kp.vk(), z[1:1 + agg.num_primary_inputs()], got[0])
+        for p in provers:
+            p.free()
+        for k in keys:
+            k.free()
+    r1.free(); kp.free(); agg.free()

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import pyref as R
-from tests.helpers import aff_limbs, aff_point, fr_array, golden, h2i, pt_from_json, random_fr_canonical
+from tests.helpers import aff_limbs, aff_point, fr_array, golden, h2i, pt_from_json, random_fr_canonical, random_fr_uniform
 
 pytestmark = pytest.mark.gpu
 
@@ -71,9 +71,13 @@ def test_fixed_base_mul_matches_oracle(zk, oracle_lib):
 @pytest.mark.parametrize("n,window", [(1 << 10, 0), (5000, 11), (1 << 14, 0), (1 << 14, 13)])
 def test_random_vs_oracle_g1(zk, oracle_lib, n, window):
     O = oracle_lib
-    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(100 + n, n), montgomery=False)
-    scal = random_fr_canonical(200 + n, n)
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_uniform(100 + n, n), montgomery=False)
+    scal = random_fr_uniform(200 + n, n)         # uniform in [0, r): every residue the ABI allows, top bit included (bench.py draws the same way)
     assert (_msm_aff(zk, bases, scal, window=window) == O.jac_to_affine(O.msm(bases, scal))).all()
+    # the same limbs as CANONICAL integers (scalars_montgomery = 0): digits up to the top bit of r
+    scal_m = np.array([O.f_op("from_canonical", 1, s_) for s_ in scal[:2000]])
+    got = zk.jac_to_affine(zk.msm_raw(bases[:2000], scal[:2000], montgomery=False))
+    assert (got == O.jac_to_affine(O.msm(bases[:2000], scal_m))).all()
 
 
 def test_random_vs_oracle_g2(zk, oracle_lib):
@@ -81,7 +85,7 @@ def test_random_vs_oracle_g2(zk, oracle_lib):
     n = 3000
     bases = zk.fixed_base_mul(aff_limbs(R.G2_GEN), random_fr_canonical(31, n), montgomery=False)
     assert O.on_curve(bases[5], g2=True)
-    scal = random_fr_canonical(32, n)
+    scal = random_fr_uniform(32, n)
     assert (_msm_aff(zk, bases, scal) == O.jac_to_affine(O.msm(bases, scal))).all()
 
 

@@ -38,6 +38,9 @@ struct MsmCtx {
   uint32_t S, T, slot_stride;   // slice length, slice count, words per row of the slot array
   hipStream_t stream, stream2;
   hipEvent_t ev, ev2, ev_acc0, ev_acc1, ev_done;
+  hipEvent_t acc_gate;  // optional (not owned): the accumulation of this launch sequence starts after this event - the end of the
+                        // accumulation of the MSM submitted before it on another context (zkhip_msm_submit): the sort of MSM i+1 and
+                        // the reduction of MSM i-1 run under the accumulation of MSM i, two accumulations never share the chip
   // bucket sort (k_digit_pass / k_bucket_sort): hist[part][block] (+ 1: the total), (entry, low bucket bits) pairs grouped by part
   uint32_t sort_LB, sort_NP, sort_bins, sort_tile;
   uint32_t* hist;

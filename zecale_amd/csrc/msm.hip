@@ -1352,6 +1352,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     S_run = (uint32_t)S; T_run = (uint32_t)((m + S - 1) / S);
   }
   HIP_TRY(hipMemsetAsync(ctx->buckets, 0, (size_t)ctx->slot_stride * 108 * 4, st));
+  if (ctx->acc_gate) HIP_TRY(hipStreamWaitEvent(st, ctx->acc_gate, 0));
   if (ctx->aff_levels == 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
   const uint32_t* acc_entries = dense ? nullptr : ctx->entries;
   if (ctx->K == 1 || dense)

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 
 #include "ec.cuh"
@@ -38,6 +39,7 @@ struct zkhip_crs {
   zkhip_bases *A, *B2, *B1, *H, *L;
   uint64_t alpha_g1[24], beta_g1[24], beta_g2[24], delta_g1[24], delta_g2[24];
   int device;
+  int batch_msms = 1;     // the five MSMs of a proof in one launch sequence (zkhip_key_opts; the key carries its own choice)
 };
 
 struct zkhip_keypair {
@@ -58,6 +60,7 @@ struct ProveState {
   size_t dz_cap = 0;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float last_accumulate_ms = 0.f;
+  int last_submit_slot = -1;       // zkhip_msm_submit: the slot of the previous submission (its accumulation gates the next one's)
   uint32_t quad_below = 0;         // 0: the engine's default; else the MSM contexts' quad_below (zkhip_prover_set_streaming)
   void release() {
     for (int k = 0; k < 5; k++) if (ready[k]) { msm_plan_free(&ctx[k]); ready[k] = false; }
@@ -80,13 +83,17 @@ struct DevState {
 struct Lib {
   DevState dev[ZK_MAX_DEVICES];
   int default_device = -1;
-  int forced_c = 0;
-  int crs_tables = 1;       // zkhip_crs_upload builds window tables (zkhip_set_crs_precompute)
-  int batch_msms = 1;       // table-backed keys: the five MSMs of a proof in one launch sequence
+  // process-wide DEFAULTS of the key options (deprecated setters zkhip_set_*; a key's own options travel in zkhip_key_opts and
+  // are resolved once at upload): atomics, so that a setter racing an upload is at least a clean read of one value or the other
+  std::atomic<int> forced_c{0};
+  std::atomic<int> crs_tables{1};       // zkhip_crs_upload builds window tables (zkhip_set_crs_precompute)
+  std::atomic<int> batch_msms{1};       // table-backed keys: the five MSMs of a proof in one launch sequence
   std::mutex mu;            // guards inited / default_device
 } g;
 thread_local char t_err[512] = {0};   // zkhip_last_error(): the calling thread's last failure
-thread_local int t_dev = -1;          // this thread's library device (-1: the default device)
+thread_local int t_dev = -1;          // this thread's library device (-1: the default device); changed by zkhip_init / zkhip_set_device ONLY
+thread_local int t_slot_dev[4] = {-1, -1, -1, -1};   // device of this thread's last zkhip_msm_submit per slot (zkhip_msm_collect has no handle)
+thread_local int t_prove_dev = -1;    // device of this thread's last MSM or proof through a handle (zkhip_last_prove_timings / _accumulate_ms)
 
 int fail(int code, const char* msg) {
   snprintf(t_err, sizeof t_err, "%s", msg);
@@ -118,7 +125,7 @@ struct Scratch {
   } while (0)
 
 int auto_window(size_t n) {
-  if (g.forced_c) return g.forced_c;
+  if (g.forced_c.load()) return g.forced_c.load();
   if (n <= (1u << 10)) return 8;
   if (n <= (1u << 13)) return 10;
   if (n <= (1u << 16)) return 12;
@@ -208,7 +215,7 @@ const char* zkhip_last_error(void) { return t_err; }
 
 int zkhip_set_msm_window(int c) {
   if (c != 0 && (c < 4 || c > 18)) return fail(ZKHIP_ERR_ARG, "window must be 0 or in [4, 18]");   // (tables: zkhip_bases_precompute takes up to 22)
-  g.forced_c = c;
+  g.forced_c.store(c);
   return ZKHIP_OK;
 }
 
@@ -278,10 +285,10 @@ int zkhip_set_affine_levels(int levels) {
   msm_force_aff_levels(levels);
   return ZKHIP_OK;
 }
-int zkhip_set_crs_precompute(int on) { g.crs_tables = on ? 1 : 0; return ZKHIP_OK; }
-static int g_table_naf = -1;       // -1: the environment decides (default off); see naf_tables_wanted
-int zkhip_set_table_naf(int on) { g_table_naf = on < 0 ? -1 : (on ? 1 : 0); return ZKHIP_OK; }
-int zkhip_set_batch_msms(int on) { g.batch_msms = on ? 1 : 0; return ZKHIP_OK; }
+int zkhip_set_crs_precompute(int on) { g.crs_tables.store(on ? 1 : 0); return ZKHIP_OK; }
+static std::atomic<int> g_table_naf{-1};       // -1: the environment decides (default off); see naf_tables_wanted
+int zkhip_set_table_naf(int on) { g_table_naf.store(on < 0 ? -1 : (on ? 1 : 0)); return ZKHIP_OK; }
+int zkhip_set_batch_msms(int on) { g.batch_msms.store(on ? 1 : 0); return ZKHIP_OK; }
 
 // Which kind of table: one level per window (default), or every bit position (378 levels) with the scalars recoded in width-(c+1)
 // non-adjacent form - an eighth fewer additions per scalar over the same buckets, sixteen times the table.  MEASURED (DESIGN.md
@@ -290,17 +297,25 @@ int zkhip_set_batch_msms(int on) { g.batch_msms = on ? 1 : 0; return ZKHIP_OK; }
 // a 2^20-point set (76 GB) LOSES 24 %.  So it is an option (zkhip_set_table_naf / ZKHIP_TABLE_NAF=1, within ZKHIP_NAF_TABLE_GB,
 // default 48 GB per base set or proving key), off by default in the library (the streaming bench and the gRPC server
 // switch it on for their key), tested like the default.
+static bool naf_tables_fit(size_t total_points) {
+  static const double cap_gb = [] { const char* e = getenv("ZKHIP_NAF_TABLE_GB"); double v = e ? atof(e) : 48.0; return v > 0 ? v : 48.0; }();
+  return (double)total_points * 378.0 * (double)(sizeof(AffPacked) + 1) <= cap_gb * 1e9 && total_points * 378 < ((size_t)1 << 31);
+}
 static bool naf_tables_wanted(size_t total_points) {
   static const int env_on = [] { const char* e = getenv("ZKHIP_TABLE_NAF"); return e ? atoi(e) : 0; }();
-  static const double cap_gb = [] { const char* e = getenv("ZKHIP_NAF_TABLE_GB"); double v = e ? atof(e) : 48.0; return v > 0 ? v : 48.0; }();
-  const int on = g_table_naf >= 0 ? g_table_naf : env_on;
-  if (!on) return false;
-  return (double)total_points * 378.0 * (double)(sizeof(AffPacked) + 1) <= cap_gb * 1e9 && total_points * 378 < ((size_t)1 << 31);
+  const int cur = g_table_naf.load();
+  const int on = cur >= 0 ? cur : env_on;
+  return on && naf_tables_fit(total_points);
 }
 static int bases_precompute_mode(zkhip_bases* b, int c, int naf);
 int zkhip_bases_precompute(zkhip_bases* b, int c) {
   if (!b) return fail(ZKHIP_ERR_ARG, "null pointer");
   return bases_precompute_mode(b, c, naf_tables_wanted(b->len) ? 1 : 0);
+}
+int zkhip_bases_precompute_ex(zkhip_bases* b, int c, int table_naf) {
+  if (!b) return fail(ZKHIP_ERR_ARG, "null pointer");
+  const int naf = table_naf < 0 ? (naf_tables_wanted(b->len) ? 1 : 0) : ((table_naf && naf_tables_fit(b->len)) ? 1 : 0);
+  return bases_precompute_mode(b, c, naf);
 }
 static int bases_precompute_mode(zkhip_bases* b, int c, int naf) {
   if (!b) return fail(ZKHIP_ERR_ARG, "null pointer");
@@ -348,7 +363,7 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
   rc = msm_run(&ps.ctx[0], bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                scalars_montgomery, bases->len, out_jac);
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", ps.ctx[0].errbuf);
-  else ps.last_accumulate_ms = ps.ctx[0].last_accumulate_ms;
+  else { ps.last_accumulate_ms = ps.ctx[0].last_accumulate_ms; t_prove_dev = bases->device; }
   return rc;
 }
 
@@ -356,32 +371,42 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
 // the latency-bound bucket reduction of one with the accumulation of the other (what the prover does between its own MSMs).
 int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery, int slot) {
   if (!bases || (len && !d_scalars)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (slot < 0 || slot > 3) return fail(ZKHIP_ERR_ARG, "slot must be in [0, 3]");
   BIND(bases);
-  t_dev = bases->device;                     // zkhip_msm_collect(slot) has no handle: it collects on this thread's device
   ProveState& ps = g.dev[bases->device].ps;
   std::lock_guard<std::mutex> lk(g.dev[bases->device].mu);
-  if (slot < 0 || slot > 3) return fail(ZKHIP_ERR_ARG, "slot must be in [0, 3]");
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
   MsmCtx* cx = &ps.ctx[slot];
   if (ps.ready[slot] && cx->pending) return fail(ZKHIP_ERR_STATE, "slot busy: collect its result first");
   int rc = ensure_ctx(cx, &ps.ready[slot], len ? len : 1, bases->table_c, 1, bases->table_naf);
   if (rc != ZKHIP_OK) return rc;
+  // a stream of MSMs, optionally GATED (ZKHIP_MSM_GATE=1): the accumulation of this one waits for the end of the accumulation
+  // submitted before it on another slot, so that two accumulations never share the chip.  Measured (tools/gate_ab.sh, 2^20 terms):
+  // 75.0 Mscalar/s gated against 76.9 free-running - the free overlap fills the tail of one accumulation with the head of the
+  // next - so the default is off; the gate gives event-timed kernel durations that are per-launch costs.
+  static const bool gate = getenv("ZKHIP_MSM_GATE") ? atoi(getenv("ZKHIP_MSM_GATE")) != 0 : false;
+  const int prev = ps.last_submit_slot;
+  cx->acc_gate = (gate && prev >= 0 && prev != slot && ps.ready[prev]) ? ps.ctx[prev].ev_acc1 : nullptr;
   rc = msm_launch(cx, bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                   scalars_montgomery, bases->len);
+  cx->acc_gate = nullptr;                   // (the event belongs to another context: never kept beyond this launch)
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", cx->errbuf);
+  else if (len) ps.last_submit_slot = slot;
+  if (rc == ZKHIP_OK) t_slot_dev[slot] = bases->device;      // zkhip_msm_collect(slot) has no handle: it collects where this thread submitted
   return rc;
 }
 
 int zkhip_msm_collect(int slot, uint64_t out_jac[36]) {
-  BIND_CUR();
-  ProveState& ps = g.dev[cur_dev()].ps;
-  std::lock_guard<std::mutex> lk(g.dev[cur_dev()].mu);
   if (slot < 0 || slot > 3 || !out_jac) return fail(ZKHIP_ERR_ARG, "bad slot or null pointer");
+  const int dev = t_slot_dev[slot] >= 0 ? t_slot_dev[slot] : cur_dev();     // the device this thread submitted the slot on
+  { int rc_ = bind_dev(dev); if (rc_ != ZKHIP_OK) return rc_; }
+  ProveState& ps = g.dev[dev].ps;
+  std::lock_guard<std::mutex> lk(g.dev[dev].mu);
   MsmCtx* cx = &ps.ctx[slot];
   if (!ps.ready[slot] || !cx->pending) return fail(ZKHIP_ERR_STATE, "nothing submitted on this slot");
   int rc = msm_finish(cx, out_jac);
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", cx->errbuf);
-  else ps.last_accumulate_ms = cx->last_accumulate_ms;
+  else { ps.last_accumulate_ms = cx->last_accumulate_ms; t_prove_dev = dev; }
   return rc;
 }
 
@@ -504,15 +529,29 @@ int zkhip_qap_h(zkhip_r1cs* r, const uint64_t* z, uint64_t* h_out) {
   return rc;
 }
 
+// The options of a key, resolved once at upload against the process-wide defaults (zkhip_set_*), then carried by the handle:
+// two threads loading keys with different options never see each other's choice.
+struct ResolvedOpts { int precompute, naf, window, batch; };
+static ResolvedOpts resolve_opts(const zkhip_key_opts* o) {
+  ResolvedOpts r;
+  r.precompute = (o && o->precompute >= 0) ? (o->precompute ? 1 : 0) : g.crs_tables.load();
+  r.naf = (o && o->table_naf >= 0) ? (o->table_naf ? 1 : 0) : -1;                  // -1: naf_tables_wanted() decides
+  r.window = (o && o->window > 0) ? o->window : g.forced_c.load();
+  r.batch = (o && o->batch_msms >= 0) ? (o->batch_msms ? 1 : 0) : g.batch_msms.load();
+  return r;
+}
+
 // one window size for the whole key (the prover's MSM contexts are shared by the five query vectors)
-static int crs_build_tables(zkhip_crs* c) {
-  if (!g.crs_tables) return ZKHIP_OK;
+static int crs_build_tables(zkhip_crs* c, const ResolvedOpts& o) {
+  c->batch_msms = o.batch;
+  if (!o.precompute) return ZKHIP_OK;
   size_t maxlen = c->A->len > c->H->len ? c->A->len : c->H->len;
-  const int tc = g.forced_c ? g.forced_c : auto_table_window(maxlen);
+  const int tc = o.window ? o.window : auto_table_window(maxlen);
   zkhip_bases* all[5] = {c->A, c->B2, c->B1, c->H, c->L};
   size_t total = 0;
   for (zkhip_bases* b : all) total += b->len;
-  const int naf = naf_tables_wanted(total) ? 1 : 0;            // one kind of table for the whole key
+  // one kind of table for the whole key; an explicit request for the larger kind still respects the memory guard
+  const int naf = (o.naf >= 0 ? (o.naf && naf_tables_fit(total)) : naf_tables_wanted(total)) ? 1 : 0;
   for (zkhip_bases* b : all) {
     int rc = bases_precompute_mode(b, tc, naf);
     if (rc != ZKHIP_OK) return rc;
@@ -520,34 +559,10 @@ static int crs_build_tables(zkhip_crs* c) {
   return ZKHIP_OK;
 }
 
-int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) {
-  BIND_CUR();
-  if (!d || !out || !d->alpha_g1 || !d->beta_g1 || !d->beta_g2 || !d->delta_g1 || !d->delta_g2)
-    return fail(ZKHIP_ERR_ARG, "null pointer");
-  if (d->n_vars < d->n_primary + 1 || d->domain_size < 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
-  zkhip_crs* c = new zkhip_crs();
-  c->device = cur_dev();
-  c->n_vars = d->n_vars; c->n_primary = d->n_primary; c->domain_size = d->domain_size;
-  memcpy(c->alpha_g1, d->alpha_g1, 192); memcpy(c->beta_g1, d->beta_g1, 192); memcpy(c->beta_g2, d->beta_g2, 192);
-  memcpy(c->delta_g1, d->delta_g1, 192); memcpy(c->delta_g2, d->delta_g2, 192);
-  int rc;
-  if ((rc = zkhip_bases_upload(d->a_query, d->n_vars, &c->A)) == ZKHIP_OK &&
-      (rc = zkhip_bases_upload(d->b_g2_query, d->n_vars, &c->B2)) == ZKHIP_OK &&
-      (rc = zkhip_bases_upload(d->b_g1_query, d->n_vars, &c->B1)) == ZKHIP_OK &&
-      (rc = zkhip_bases_upload(d->h_query, d->domain_size - 1, &c->H)) == ZKHIP_OK &&
-      (rc = zkhip_bases_upload(d->l_query, d->n_vars - d->n_primary - 1, &c->L)) == ZKHIP_OK)
-    rc = crs_build_tables(c);
-  if (rc != ZKHIP_OK) { zkhip_crs_free(c); return rc; }     // frees what was uploaded so far (null members are skipped)
-  *out = c;
-  return ZKHIP_OK;
-}
-
-int zkhip_crs_upload_slice(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, size_t h_lo, size_t h_len, size_t l_lo, size_t l_len,
-                           zkhip_crs** out) {
-  BIND_CUR();
-  if (!d || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
-  if (a_lo + a_len > d->n_vars || h_lo + h_len > d->domain_size - 1 || l_lo + l_len > d->n_vars - d->n_primary - 1)
-    return fail(ZKHIP_ERR_ARG, "slice out of range");
+static int crs_upload_impl(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, size_t h_lo, size_t h_len, size_t l_lo, size_t l_len,
+                           const zkhip_key_opts* opts, zkhip_crs** out) {
+  if (opts && (opts->window < 0 || (opts->window > 0 && (opts->window < 4 || opts->window > 22))))
+    return fail(ZKHIP_ERR_ARG, "zkhip_key_opts.window must be 0 (automatic) or in [4, 22]");
   zkhip_crs* c = new zkhip_crs();
   c->device = cur_dev();
   c->n_vars = d->n_vars; c->n_primary = d->n_primary; c->domain_size = d->domain_size;
@@ -559,14 +574,44 @@ int zkhip_crs_upload_slice(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, s
       (rc = zkhip_bases_upload(d->b_g1_query + a_lo * 24, a_len, &c->B1)) == ZKHIP_OK &&
       (rc = zkhip_bases_upload(d->h_query + h_lo * 24, h_len, &c->H)) == ZKHIP_OK &&
       (rc = zkhip_bases_upload(d->l_query + l_lo * 24, l_len, &c->L)) == ZKHIP_OK)
-    rc = crs_build_tables(c);
-  if (rc != ZKHIP_OK) { zkhip_crs_free(c); return rc; }
+    rc = crs_build_tables(c, resolve_opts(opts));
+  if (rc != ZKHIP_OK) { zkhip_crs_free(c); return rc; }     // frees what was uploaded so far (null members are skipped)
   *out = c;
   return ZKHIP_OK;
 }
 
+int zkhip_crs_upload_ex(const zkhip_crs_desc* d, const zkhip_key_opts* opts, zkhip_crs** out) {
+  BIND_CUR();
+  if (!d || !out || !d->alpha_g1 || !d->beta_g1 || !d->beta_g2 || !d->delta_g1 || !d->delta_g2)
+    return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (d->n_vars < d->n_primary + 1 || d->domain_size < 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
+  return crs_upload_impl(d, 0, d->n_vars, 0, d->domain_size - 1, 0, d->n_vars - d->n_primary - 1, opts, out);
+}
+int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) { return zkhip_crs_upload_ex(d, nullptr, out); }
+
+int zkhip_crs_upload_slice_ex(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, size_t h_lo, size_t h_len, size_t l_lo, size_t l_len,
+                              const zkhip_key_opts* opts, zkhip_crs** out) {
+  BIND_CUR();
+  if (!d || !out || !d->alpha_g1 || !d->beta_g1 || !d->beta_g2 || !d->delta_g1 || !d->delta_g2) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (d->n_vars < d->n_primary + 1 || d->domain_size < 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
+  if (a_lo + a_len > d->n_vars || h_lo + h_len > d->domain_size - 1 || l_lo + l_len > d->n_vars - d->n_primary - 1)
+    return fail(ZKHIP_ERR_ARG, "slice out of range");
+  return crs_upload_impl(d, a_lo, a_len, h_lo, h_len, l_lo, l_len, opts, out);
+}
+int zkhip_crs_upload_slice(const zkhip_crs_desc* d, size_t a_lo, size_t a_len, size_t h_lo, size_t h_len, size_t l_lo, size_t l_len,
+                           zkhip_crs** out) {
+  return zkhip_crs_upload_slice_ex(d, a_lo, a_len, h_lo, h_len, l_lo, l_len, nullptr, out);
+}
+
 int zkhip_crs_table_window(const zkhip_crs* c) { return (c && c->A) ? c->A->table_c : 0; }
 int zkhip_crs_device(const zkhip_crs* c) { return c ? c->device : -1; }
+int zkhip_crs_table_kind(const zkhip_crs* c) { return (c && c->A && c->A->table_c) ? (c->A->table_naf ? 2 : 1) : 0; }
+int zkhip_crs_finite_terms(const zkhip_crs* c, size_t out[5]) {
+  if (!c || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  const zkhip_bases* all[5] = {c->A, c->B2, c->B1, c->H, c->L};
+  for (int k = 0; k < 5; k++) out[k] = all[k] ? all[k]->n_finite : 0;
+  return ZKHIP_OK;
+}
 
 void zkhip_crs_free(zkhip_crs* c) {
   if (!c) return;
@@ -576,8 +621,9 @@ void zkhip_crs_free(zkhip_crs* c) {
 }
 
 int zkhip_last_prove_timings(double out_ms[8]) {
-  if (!out_ms || cur_dev() < 0) return ZKHIP_ERR_ARG;
-  memcpy(out_ms, g.dev[cur_dev()].ps.ms, sizeof g.dev[0].ps.ms);
+  const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();
+  if (!out_ms || dev < 0) return ZKHIP_ERR_ARG;
+  memcpy(out_ms, g.dev[dev].ps.ms, sizeof g.dev[0].ps.ms);
   return ZKHIP_OK;
 }
 
@@ -627,7 +673,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   struct { const zkhip_bases* b; const uint64_t* sc; size_t len; int mode; uint64_t* out; } jobs[5] = {
       {crs->A, dz + a_lo * 6, a_len, 1, sums}, {crs->B2, dz + a_lo * 6, a_len, 1, sums + 36}, {crs->B1, dz + a_lo * 6, a_len, 1, sums + 72},
       {crs->H, (const uint64_t*)rd->bufA + h_lo * 6, h_len, 2, sums + 108}, {crs->L, dz + (l + 1 + l_lo) * 6, l_len, 1, sums + 144}};
-  bool batched = tc > 0 && g.batch_msms;
+  bool batched = tc > 0 && crs->batch_msms;
   if (batched) {
     // table-backed key: the five MSMs share ONE launch sequence (one sort, one accumulation launch over all five entry
     // lists, one reduction chain with a bucket window per MSM) - a fifth of the launches, five times the lanes in each.
@@ -741,7 +787,7 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
     int rc = prove_partial(g.dev[crs->device].ps, crs, r1cs->dev, z, 0, 0, 0, sums);
     if (rc != ZKHIP_OK) return rc;
   }
-  t_dev = crs->device;      // zkhip_last_prove_timings reads this thread's device
+  t_prove_dev = crs->device;      // zkhip_last_prove_timings reads the device of this thread's last proof
   return zkhip_groth16_finish(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine);
 }
 
@@ -1040,7 +1086,10 @@ int zkhip_keypair_read(const char* path, zkhip_keypair** out) {
 
 void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 
-float zkhip_last_accumulate_ms(void) { return cur_dev() >= 0 ? g.dev[cur_dev()].ps.last_accumulate_ms : 0.f; }
+float zkhip_last_accumulate_ms(void) {
+  const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();       // where this thread's last MSM / proof ran
+  return dev >= 0 ? g.dev[dev].ps.last_accumulate_ms : 0.f;
+}
 
 // ---- witness generation on the GPU (witness.hip) ---------------------------------------------------------------------------
 struct zkhip_gpu_witness {

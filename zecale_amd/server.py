@@ -232,11 +232,9 @@ class GpuProver:
         self.vk = self.kp.vk()
         if self.vk["ABC"].shape[0] != self.agg.num_primary_inputs() + 1:      # the server's "invalid VK" check (:490, :504)
             raise ValueError("invalid VK")
-        zkhip.set_table_naf(1)              # a server proves a stream of batches: the larger kind of window table pays
-        try:
-            self.crs = self.kp.upload_crs()
-        finally:
-            zkhip.set_table_naf(-1)
+        # a server proves a stream of batches: the larger kind of window table pays.  The option travels with
+        # THIS key (zkhip_key_opts), not with the process: another key loaded on another thread keeps its own.
+        self.crs = self.kp.upload_crs(zkhip.key_opts(table_naf=True if os.environ.get("ZKHIP_TABLE_NAF") is None else None))
         self.pipe = zkhip.AggregatorPipeline(self.agg, self.crs, gpu_slots=gpu_slots, witness_workers=witness_workers, gpu_witness=gpu_witness)
 
     def verification_key_json(self):

@@ -28,6 +28,7 @@ EXPORTS = [
     "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_new_ex", "zkhip_crs_device", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
+    "zkhip_crs_upload_ex", "zkhip_crs_upload_slice_ex", "zkhip_bases_precompute_ex", "zkhip_crs_table_kind", "zkhip_crs_finite_terms",
 ]
 
 
@@ -41,6 +42,17 @@ c_u64p_t = ctypes.POINTER(ctypes.c_uint64)
 class R1csDesc(ctypes.Structure):
     _fields_ = [("n_constraints", ctypes.c_size_t), ("n_vars", ctypes.c_size_t), ("n_primary", ctypes.c_size_t)] + [
         (f"{m}_{k}", ctypes.c_void_p) for m in "abc" for k in ("row_ptr", "col", "val")]
+
+
+class KeyOpts(ctypes.Structure):
+    """zkhip_key_opts: the options of a proving key / base set, carried by the handle (include/zkhip.h)."""
+    _fields_ = [("precompute", ctypes.c_int), ("table_naf", ctypes.c_int), ("window", ctypes.c_int), ("batch_msms", ctypes.c_int)]
+
+
+def key_opts(precompute=None, table_naf=None, window=0, batch_msms=None):
+    """None = the process-wide default (the deprecated zkhip_set_* switches), True / False = this key's own choice."""
+    t = lambda v: -1 if v is None else int(bool(v))
+    return KeyOpts(t(precompute), t(table_naf), int(window or 0), t(batch_msms))
 
 
 class CrsDesc(ctypes.Structure):
@@ -99,6 +111,11 @@ def load():
     lib.zkhip_qap_h.argtypes = [ctypes.c_void_p, c_u64p, c_u64p]
     lib.zkhip_crs_upload.argtypes = [ctypes.POINTER(CrsDesc), ctypes.POINTER(ctypes.c_void_p)]
     lib.zkhip_crs_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_crs_upload_ex.argtypes = [ctypes.POINTER(CrsDesc), ctypes.POINTER(KeyOpts), ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_crs_upload_slice_ex.argtypes = [ctypes.POINTER(CrsDesc)] + [ctypes.c_size_t] * 6 + [ctypes.POINTER(KeyOpts), ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_crs_table_kind.argtypes = [ctypes.c_void_p]
+    lib.zkhip_crs_finite_terms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.zkhip_bases_precompute_ex.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.zkhip_groth16_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
     lib.zkhip_last_prove_timings.argtypes = [ctypes.POINTER(ctypes.c_double)]
     lib.zkhip_crs_upload_slice.argtypes = [ctypes.POINTER(CrsDesc)] + [ctypes.c_size_t] * 6 + [ctypes.POINTER(ctypes.c_void_p)]
@@ -205,9 +222,10 @@ class Bases:
     def __len__(self):
         return load().zkhip_bases_len(self.handle)
 
-    def precompute(self, c=0):
-        """Build the window table (2^(c w) P_i for every window position): all later msm calls use it."""
-        _check(load().zkhip_bases_precompute(self.handle, c))
+    def precompute(self, c=0, table_naf=None):
+        """Build the window table (2^(c w) P_i for every window position): all later msm calls use it.
+        table_naf: None = the process default, True = every bit position + NAF scalars, False = one level per window."""
+        _check(load().zkhip_bases_precompute_ex(self.handle, c, -1 if table_naf is None else int(bool(table_naf))))
         return self
 
     @property
@@ -357,7 +375,7 @@ class Crs:
     """The Groth16 proving key resident in HBM.  pk: dict with alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2
     (24 limbs) and the query arrays A, B2, B1, H, L (n x 24 limbs)."""
 
-    def __init__(self, pk, n_vars, n_primary, domain_size):
+    def __init__(self, pk, n_vars, n_primary, domain_size, opts=None):
         d = CrsDesc()
         d.n_vars, d.n_primary, d.domain_size = n_vars, n_primary, domain_size
         keep = []
@@ -370,7 +388,7 @@ class Crs:
             keep.append(a)
             setattr(d, field, a.ctypes.data if a.size else None)
         h = ctypes.c_void_p()
-        _check(load().zkhip_crs_upload(ctypes.byref(d), ctypes.byref(h)))
+        _check(load().zkhip_crs_upload_ex(ctypes.byref(d), ctypes.byref(opts) if opts is not None else None, ctypes.byref(h)))
         self.handle = h
 
     @property
@@ -378,13 +396,24 @@ class Crs:
         """Window size of the key's precomputed tables (0: plain key)."""
         return load().zkhip_crs_table_window(self.handle)
 
+    @property
+    def table_kind(self):
+        """0: plain key, 1: one table level per window, 2: every bit position (scalars in non-adjacent form)."""
+        return load().zkhip_crs_table_kind(self.handle)
+
+    def finite_terms(self):
+        """Bases of A, B-G2, B-G1, H, L that are not the point at infinity (the terms an MSM over the key can have)."""
+        out = (ctypes.c_size_t * 5)()
+        _check(load().zkhip_crs_finite_terms(self.handle, out))
+        return [int(v) for v in out]
+
     def free(self):
         if self.handle:
             load().zkhip_crs_free(self.handle)
             self.handle = None
 
     @classmethod
-    def upload_slice(cls, pk, n_vars, n_primary, domain_size, a_range, h_range, l_range):
+    def upload_slice(cls, pk, n_vars, n_primary, domain_size, a_range, h_range, l_range, opts=None):
         """This rank's slice of the proving key: ranges are (lo, hi) into the A/B queries, the H query and the L query."""
         d = CrsDesc()
         d.n_vars, d.n_primary, d.domain_size = n_vars, n_primary, domain_size
@@ -397,8 +426,9 @@ class Crs:
             setattr(d, field, a.ctypes.data if a.size else None)
         self = cls.__new__(cls)
         h = ctypes.c_void_p()
-        _check(load().zkhip_crs_upload_slice(ctypes.byref(d), a_range[0], a_range[1] - a_range[0], h_range[0], h_range[1] - h_range[0],
-                                             l_range[0], l_range[1] - l_range[0], ctypes.byref(h)))
+        _check(load().zkhip_crs_upload_slice_ex(ctypes.byref(d), a_range[0], a_range[1] - a_range[0], h_range[0], h_range[1] - h_range[0],
+                                                l_range[0], l_range[1] - l_range[0], ctypes.byref(opts) if opts is not None else None,
+                                                ctypes.byref(h)))
         self.handle = h
         self.ranges = (a_range, h_range, l_range)
         return self
@@ -638,12 +668,13 @@ class Keypair:
         kp.handle = h
         return kp
 
-    def upload_crs(self):
+    def upload_crs(self, opts=None):
+        """opts: key_opts(...) - this key's own table / launch options (None: the process defaults)."""
         d = CrsDesc()
         _check(load().zkhip_keypair_crs_desc(self.handle, ctypes.byref(d)))
         crs = Crs.__new__(Crs)
         h = ctypes.c_void_p()
-        _check(load().zkhip_crs_upload(ctypes.byref(d), ctypes.byref(h)))
+        _check(load().zkhip_crs_upload_ex(ctypes.byref(d), ctypes.byref(opts) if opts is not None else None, ctypes.byref(h)))
         crs.handle = h
         return crs
 
