@@ -149,3 +149,47 @@ def test_pool_orders_by_fee_and_only_returns_whole_batches():
         pool.add_tx({"fee_in_wei": fee})
     assert [t["fee_in_wei"] for t in pool.get_next_batch()] == [9, 3]
     assert pool.tx_pool_size() == 1 and pool.get_next_batch() == []
+
+
+def test_malformed_proof_is_refused_at_submission_and_a_failed_batch_goes_back(live):
+    """(1) A nested proof with a point off its curve is refused by SubmitNestedTransaction - queued, it would be batched with another
+    user's transaction and take it down with it.  (2) When the prover fails, the batch that was popped under the lock returns to
+    the pool in its old order instead of being lost."""
+    from zecale_amd import zkhip
+    client, prover, service = live
+    agg = zkhip.AggregatorCircuit(S.BATCH_SIZE, S.NUM_INPUTS_PER_NESTED_PROOF)          # host code: the circuit's own curve checks
+    prover.check_nested_proof = lambda vk_limbs, proof: bool(agg.check_inputs(vk_limbs, np.concatenate([proof] * S.BATCH_SIZE)))
+    client.register_application(golden("dummy_app/vk.json"), "dummy_app")
+    bad = json.loads(json.dumps(golden("dummy_app/extproof1.json")))
+    y = int(bad["extended_proof"]["proof"]["a"][1], 16)
+    bad["extended_proof"]["proof"]["a"][1] = hex(y ^ 2)                                   # A leaves its curve
+    with pytest.raises(grpc.RpcError) as e:
+        client.submit_nested_transaction(bad)
+    assert _details(e) == (grpc.StatusCode.INVALID_ARGUMENT, "nested proof has a point that is not on its curve")
+    assert service.pools["dummy_app"].tx_pool_size() == 0
+    for k in (1, 2, 3):
+        client.submit_nested_transaction(golden("dummy_app/extproof%d.json" % k))
+    good_prove = prover.prove
+
+    def failing(*a):
+        raise RuntimeError("device lost")
+    prover.prove = failing
+    with pytest.raises(grpc.RpcError) as e:
+        client.get_aggregated_transaction("dummy_app")
+    assert e.value.details() == "device lost"
+    assert service.pools["dummy_app"].tx_pool_size() == 3                                 # nothing was dropped
+    prover.prove = good_prove
+    batch = client.get_aggregated_transaction("dummy_app")                               # and the order is the old one: fees 11, 10
+    fees = sorted((golden("dummy_app/extproof%d.json" % k) for k in (1, 2, 3)), key=lambda t: -t["fee_in_wei"])
+    assert [int(x, 16) for x in batch["ext_proof"]["inputs"][2:]] == [int(t["extended_proof"]["inputs"][0], 16) for t in fees[:2]]
+    agg.free()
+
+
+def test_handler_pool_is_as_deep_as_the_prover():
+    class P(StubProver):
+        gpu_slots = 14
+    server, port, _ = S.serve(P(), "127.0.0.1:0")
+    try:
+        assert server._state.thread_pool._max_workers >= 14 + 4
+    finally:
+        server.stop(0)

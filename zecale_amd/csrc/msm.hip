@@ -30,6 +30,11 @@
 #ifndef ZK_ACC_REGY
 #define ZK_ACC_REGY 1
 #endif
+#ifndef ZK_ACC_TOUCH
+#define ZK_ACC_TOUCH 0      // 1: touch the NEXT point's two cache lines one addition ahead.  Measured (round 3): k_accumulate 11.5 -> 12.1 ms at
+                            // 2^20, the wrapping stream 306 -> 278 proofs/s - the three carried registers push the kernel from 12-19 to
+                            // 46-48 spilled dwords, which costs more than the warmed cache returns.  Left in as a measured alternative.
+#endif
 
 namespace zkhip {
 
@@ -392,15 +397,27 @@ template <int NJ> __device__ __forceinline__ const AffPacked* base_of(const Base
   return r;
 }
 
+// Slice length.  The host sizes the slices for the entries that CAN occur (digit positions x finite bases); the list the sort
+// produced may be shorter - zero digits produce no entry (a boolean-heavy witness: most of them), recoded scalars have fewer
+// digits than positions.  A launch that has the chip to itself (tight != 0) then shortens the slices so that all T lanes of the
+// grid get work: S = ceil(M / T), at least 16, never above the host's S (so the slot array still fits).  A prover that shares the
+// chip with others keeps the longer slices (fewer cut buckets to stitch; the chip is full anyway).
+__device__ __forceinline__ uint32_t slice_len(uint32_t M, uint32_t T, uint32_t S_host, int tight) {
+  if (!tight) return S_host;
+  const uint32_t s_ = (M + T - 1) / T;
+  return s_ < 16u ? (S_host < 16u ? S_host : 16u) : s_;
+}
+
 // entries == nullptr: the sorted list IS the dense point array bp.p[0] (the output of the batched-affine levels, k_affine_level):
 // entry k is point k, never negated; a point may be the level encoding of infinity (skipped).
 template <int NJ>
 __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, const uint32_t* __restrict__ entries,
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                        uint32_t nb, uint32_t S, uint32_t T, uint32_t* __restrict__ slots,
+                                                        uint32_t nb, uint32_t S_host, int tight, uint32_t T, uint32_t* __restrict__ slots,
                                                         uint32_t stride, uint32_t* __restrict__ fix_cnt /* [2] */, uint2* __restrict__ fix_short, uint2* __restrict__ fix_long) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
+  const uint32_t S = slice_len(M, T, S_host, tight);
   uint32_t pos0 = t * S;
   if (t >= T || pos0 >= M) return;
   uint32_t pos1 = min(pos0 + S, M);
@@ -448,6 +465,9 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
 #endif
   const bool dense = entries == nullptr;
   uint32_t e_next = dense ? pos0 : entries[pos0];
+#if ZK_ACC_TOUCH
+  uint32_t touch = 0, t0 = 0, t1 = 0;
+#endif
   for (uint32_t k = pos0; k < pos1; k++) {
     if (k == bend) {
       if (!first) {
@@ -470,6 +490,18 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
     uint32_t e = e_next;
     if (k + 1 < pos1) e_next = dense ? k + 1 : entries[k + 1];        // fetched a whole addition ahead of its use
     const AffPacked* p = (dense ? bp.p[0] : base_of<NJ>(bp, b >> bshift)) + (e & 0x7fffffffu);
+#if ZK_ACC_TOUCH
+    // A point is gathered from a table of gigabytes: its page-table walk and the fetch of its two 128-byte lines cost microseconds,
+    // and with two waves per SIMD a stalled wave is half of the SIMD's multiplier idle.  The NEXT entry is known an addition ahead:
+    // one word of each of its lines is loaded now and consumed (folded into `touch`) at the top of the next iteration - by then
+    // it has long arrived, and the real loads of that point hit the cache.  Only inside a bucket (the next bucket may belong to
+    // another job, i.e. another table).
+    touch ^= t0 ^ t1;
+    if (k + 1 < bend && k + 1 < pos1) {
+      const AffPacked* pn = (dense ? bp.p[0] : base_of<NJ>(bp, b >> bshift)) + (e_next & 0x7fffffffu);
+      t0 = pn->x[0]; t1 = pn->y[23];
+    }
+#endif
     bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_digit_pass drops them)
     if (dense && p->x[23] == ZK_AFF_INF_WORD) continue;        // a pair of the levels below cancelled
     if (inf) {
@@ -499,6 +531,9 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   }
   // a run that cancelled to infinity leaves ZZ = 0 in its slot: madd_same_x wrote the zeros, or the slot
   // was never written (zero-filled array)
+#if ZK_ACC_TOUCH
+  if ((touch ^ t0 ^ t1) == 0x9e3779b9u && t == 0xffffffffu) fix_cnt[0] = touch;      // (never true: keeps the touching loads alive)
+#endif
 }
 
 // ---- batched-affine levels ------------------------------------------------------------------------------------------------
@@ -756,10 +791,11 @@ __global__ void __launch_bounds__(256, 2) k_fixup_tree(const uint32_t* __restric
 
 // final stitch: the slice in which a cut bucket STARTS owns it: bucket = L[t0] + F[t0+1] (folded).
 __global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                   uint32_t nb, uint32_t S, uint32_t T, uint32_t* __restrict__ slots, uint32_t stride) {
+                                                   uint32_t nb, uint32_t S_host, int tight, uint32_t T, uint32_t* __restrict__ slots, uint32_t stride) {
   ADD_SCRATCH_DECL(false);
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // throughput-bound (one addition per slice): one lane each
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
+  const uint32_t S = slice_len(M, T, S_host, tight);
   uint32_t pos0 = t * S;
   if (t >= T || pos0 >= M) return;
   uint32_t pos1 = min(pos0 + S, M);
@@ -1351,16 +1387,17 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     while ((m + S - 1) / S > ctx->T) S++;
     S_run = (uint32_t)S; T_run = (uint32_t)((m + S - 1) / S);
   }
+  const int tight = (ctx->one_stream || dense) ? 0 : env_int("ZKHIP_TIGHT_SLICES", 1, 0, 1);      // (a streaming prover shares the chip: see slice_len)
   HIP_TRY(hipMemsetAsync(ctx->buckets, 0, (size_t)ctx->slot_stride * 108 * 4, st));
   if (ctx->acc_gate) HIP_TRY(hipStreamWaitEvent(st, ctx->acc_gate, 0));
   if (ctx->aff_levels == 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
   const uint32_t* acc_entries = dense ? nullptr : ctx->entries;
   if (ctx->K == 1 || dense)
     hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off, cur_cnt,
-                       (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list);
+                       (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list);
   else
     hipLaunchKernelGGL(k_accumulate<MSM_MAX_JOBS>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off,
-                       cur_cnt, (uint32_t)nb, S_run, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list);
+                       cur_cnt, (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
   // fold the F pieces of the buckets that have several (lists made by k_accumulate), then L + F for every cut bucket
   if (T_run > 2) {
@@ -1368,7 +1405,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
                        (uint32_t)nb, ctx->buckets, ctx->slot_stride);
     hipLaunchKernelGGL(k_fixup_tree, dim3(128), dim3(256), 0, st, ctx->block_tot + 1, ctx->fix_list, (uint32_t)nb, ctx->buckets, ctx->slot_stride);
   }
-  hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, T_run,
+  hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, tight, T_run,
                      ctx->buckets, ctx->slot_stride);
   HIP_TRY(hipGetLastError());
 

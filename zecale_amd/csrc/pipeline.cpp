@@ -40,8 +40,10 @@ struct zkhip_pipeline {
   std::vector<zkhip_prover*> provers;
   std::vector<std::thread> threads;
   std::mutex mu;
-  std::condition_variable cv_wit, cv_gpu, cv_done, cv_room;
+  std::condition_variable cv_wit, cv_gpu, cv_done, cv_room, cv_host;
   std::deque<std::shared_ptr<Job>> q_wit, q_gpu;
+  std::deque<std::shared_ptr<Job>> q_host;         // GPU-witness mode: batches the device could not witness (degenerate nested points, a failed
+                                                   // launch) wait here for the host generator thread - the batcher does not stop for them
   std::map<uint64_t, std::shared_ptr<Job>> jobs;   // submitted and not yet collected
   size_t max_unfinished = 0, unfinished = 0;     // back-pressure counts batches not yet proved (finished ones wait for their collector)
   uint64_t next_id = 1;
@@ -137,18 +139,39 @@ void gpu_witness_loop(zkhip_pipeline* p) {
         j->d_z = (char*)p->slabs[slab].base + i * p->n_vars * 48;
         j->slab = slab;
         on_device++;
-      } else {                                        // host generator for this one
-        j->z.resize(p->n_vars * 6);
-        int hrc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
-        if (hrc != ZKHIP_OK) { std::lock_guard<std::mutex> lk(p->mu); finish_failed(p, j, hrc); j.reset(); }
       }
     }
+    // the on-device jobs go to the provers and the slab is accounted for at once; what the device could not witness goes to the
+    // host generator THREAD (crafted inputs - ABC_1 == ABC_0 - must not be able to stall the launches of everybody else's batches)
     std::lock_guard<std::mutex> lk(p->mu);
     p->slabs[slab].outstanding = on_device;
     if (on_device == 0) { p->slab_free.push_back(slab); p->cv_buf.notify_one(); }
-    for (auto& j : good) if (j) { p->q_gpu.push_back(j); p->cv_gpu.notify_one(); }
+    for (auto& j : good) {
+      if (j->d_z) { p->q_gpu.push_back(j); p->cv_gpu.notify_one(); }
+      else { p->q_host.push_back(j); p->cv_host.notify_one(); }
+    }
   }
   zkhip_gpu_witness_free(gw);
+}
+
+// GPU-witness mode: the host generator for the batches the device handed back.
+void host_fallback_loop(zkhip_pipeline* p) {
+  pthread_setname_np(pthread_self(), "zk-wit-host");
+  for (;;) {
+    std::shared_ptr<Job> j;
+    {
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv_host.wait(lk, [&] { return p->stop || !p->q_host.empty(); });
+      if (p->stop) return;
+      j = p->q_host.front();
+      p->q_host.pop_front();
+    }
+    j->z.resize(p->n_vars * 6);
+    const int rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (rc != ZKHIP_OK) finish_failed(p, j, rc);
+    else { p->q_gpu.push_back(j); p->cv_gpu.notify_one(); }
+  }
 }
 
 void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
@@ -229,6 +252,7 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
     p->provers.push_back(pr);
   }
   for (int i = 0; i < witness_workers; i++) p->threads.emplace_back(p->gpu_witness ? gpu_witness_loop : witness_loop, p);
+  if (p->gpu_witness) p->threads.emplace_back(host_fallback_loop, p);
   for (zkhip_prover* pr : p->provers) p->threads.emplace_back(gpu_loop, p, pr);
   *out = p;
   return ZKHIP_OK;
@@ -240,7 +264,7 @@ void zkhip_aggregator_pipeline_free(zkhip_pipeline* p) {
     std::lock_guard<std::mutex> lk(p->mu);
     p->stop = true;
   }
-  p->cv_wit.notify_all(); p->cv_gpu.notify_all(); p->cv_done.notify_all(); p->cv_room.notify_all(); p->cv_buf.notify_all();
+  p->cv_wit.notify_all(); p->cv_gpu.notify_all(); p->cv_done.notify_all(); p->cv_room.notify_all(); p->cv_buf.notify_all(); p->cv_host.notify_all();
   for (auto& t : p->threads) t.join();
   for (zkhip_prover* q : p->provers) zkhip_prover_free(q);
   for (auto& q : p->slabs) zkhip_device_free(q.base);

@@ -11,14 +11,25 @@
 
 namespace zkhip {
 inline hipError_t zk_event_wait(hipEvent_t ev) {
-  static thread_local bool slack_set = false;
-  if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 2000UL); slack_set = true; }     // the default slack of 50 us would triple a 20 us sleep
+  hipError_t e = hipEventQuery(ev);
+  if (e != hipErrorNotReady) return e;
+  // The sleeps below want a timer slack of ~2 us (the default 50 us would triple a 20 us sleep).  The slack is a property of the
+  // calling THREAD, which may be the application's: it is changed for the duration of this wait only and put back afterwards.
+  const int old_slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+  if (old_slack > 2000) (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);
   for (int i = 0;; i++) {
-    hipError_t e = hipEventQuery(ev);
-    if (e != hipErrorNotReady) return e;
-    if (i < 8) { sched_yield(); continue; }
-    timespec ts{0, i < 64 ? 20000 : 100000};      // 20 us, then 100 us (plus the kernel's timer slack)
-    nanosleep(&ts, nullptr);
+    if (i < 8) sched_yield();
+    else {
+      timespec ts{0, i < 64 ? 20000 : 100000};      // 20 us, then 100 us (plus the timer slack)
+      nanosleep(&ts, nullptr);
+    }
+    e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) break;
   }
+  if (old_slack > 2000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old_slack, 0, 0, 0);
+  // hipErrorNotReady is a status, not a failure, but the runtime may have recorded it as this thread's last error: a later
+  // hipGetLastError() check of a kernel launch must not trip over it
+  if (e == hipSuccess) (void)hipGetLastError();
+  return e;
 }
 }  // namespace zkhip

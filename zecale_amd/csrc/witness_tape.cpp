@@ -340,7 +340,13 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
         if (!live[i] || in_chain(i)) continue;
         int32_t d[2];
         deps(i, d);
-        for (int32_t x : d) if (x >= 0) { pending[i]++; succ_off[(size_t)x + 1]++; }
+        for (int32_t x : d) {
+          if (x < 0) continue;
+          // the levelled program and the key-hash chain run CONCURRENTLY on two streams: a levelled instruction that read a chain
+          // value would never become ready here (its operand is never levelled) and would be laid out before it
+          if (in_chain((size_t)x)) throw std::runtime_error("witness tape: a levelled instruction reads a value of the key-hash chain");
+          pending[i]++; succ_off[(size_t)x + 1]++;
+        }
       }
       for (size_t i = 0; i < n_ops; i++) succ_off[i + 1] += succ_off[i];
       succ.resize(succ_off[n_ops]);
@@ -369,6 +375,10 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
           }
         max_level = l++;
       }
+      // every live instruction outside the chain must have fired: one that is left waits for an operand that never will (a dead
+      // or out-of-program reference) and would silently keep level 0
+      for (size_t i = 0; i < n_ops; i++)
+        if (live[i] && !in_chain(i) && pending[i] != 0) throw std::runtime_error("witness tape: an instruction's operand is never computed (levelling left it pending)");
     }
     // layout: by level, inside a level by kind (inversions first, then multiplications, then the cheap ones)
     auto kind_rank = [](uint8_t c) { return (c == WT_INV || c == WT_INV0) ? 0 : c == WT_MUL ? 1 : c == WT_INPUT ? 2 : c == WT_BIT ? 3 : 4; };

@@ -203,11 +203,20 @@ class ApplicationPool:
     def tx_pool_size(self):
         return len(self._heap)
 
-    def get_next_batch(self):
-        """Whole batches only (application_pool.tcc:49-63): [] unless NumProofs transactions are queued."""
+    def pop_batch_entries(self):
+        """Whole batches only (application_pool.tcc:49-63): [] unless NumProofs transactions are queued.  Heap entries
+        (-fee, arrival order, tx), so that a batch whose proof failed can go back in its old place (requeue)."""
         if len(self._heap) < self.num_proofs:
             return []
-        return [heapq.heappop(self._heap)[2] for _ in range(self.num_proofs)]
+        return [heapq.heappop(self._heap) for _ in range(self.num_proofs)]
+
+    def get_next_batch(self):
+        return [e[2] for e in self.pop_batch_entries()]
+
+    def requeue(self, entries):
+        """A batch that was popped but not proved (prover or GPU error): back into the queue with its fee order and arrival order."""
+        for e in entries:
+            heapq.heappush(self._heap, e)
 
 
 # ---------------------------------------------------------------------------------------------- provers
@@ -218,6 +227,7 @@ class GpuProver:
     def __init__(self, keypair_file=None, device=0, gpu_slots=14, witness_workers=8, gpu_witness=False):
         from . import zkhip
         self.zk = zkhip
+        self.gpu_slots = gpu_slots
         zkhip.init(device)
         self.agg = zkhip.AggregatorCircuit(BATCH_SIZE, NUM_INPUTS_PER_NESTED_PROOF)
         desc = zkhip.r1cs_desc_from_aggregator(self.agg)
@@ -242,6 +252,11 @@ class GpuProver:
 
     def nested_vk_hash(self, nested_vk_limbs):
         return self.zk.aggregator_vk_hash(nested_vk_limbs, NUM_INPUTS_PER_NESTED_PROOF)
+
+    def check_nested_proof(self, nested_vk_limbs, proof_limbs):
+        """Well-formedness of ONE nested proof at submission time (libsnark's proof.is_well_formed(): every point on its curve).
+        Host code.  A malformed transaction is refused before it can sit in a batch with somebody else's honest one."""
+        return bool(self.agg.check_inputs(nested_vk_limbs, np.concatenate([proof_limbs] * BATCH_SIZE)))
 
     def prove(self, nested_vk_limbs, proofs, inputs):
         """proofs: BATCH_SIZE x 48 limbs; inputs: BATCH_SIZE x k x 6 limbs -> extended proof JSON of the wrapping proof."""
@@ -308,6 +323,11 @@ class AggregatorService:
                 if len(ep["inputs"]) != NUM_INPUTS_PER_NESTED_PROOF:
                     raise ValueError("invalid number of inputs")                         # aggregator_server.cpp:254-257
                 proof, inputs = E.nested_extended_proof_from_json(ep)
+                # refuse a malformed proof HERE: once queued it would be batched with another user's transaction and take it down
+                # with it when the batch fails (the reference checks well-formedness when it decodes the proof)
+                check = getattr(self.prover, "check_nested_proof", None)
+                if check is not None and not check(pool.vk_limbs, proof):
+                    raise ValueError("nested proof has a point that is not on its curve")
                 pool.add_tx({"proof": proof, "inputs": inputs, "parameters": bytes(request.parameters),
                              "fee_in_wei": int(request.fee_in_wei) & 0xFFFFFFFF})         # uint32_t(fee), proto_utils.tcc:44
             return empty_pb2.Empty()
@@ -318,11 +338,18 @@ class AggregatorService:
             name = request.application_name
             with self.mu:
                 pool = self._pool(name)
-                batch = pool.get_next_batch()
-                if not batch:
+                entries = pool.pop_batch_entries()
+                if not entries:
                     raise RuntimeError("insufficient entries in pool")                   # aggregator_server.cpp:298-300
+                batch = [e[2] for e in entries]
                 vk_limbs = pool.vk_limbs
-            ep = self.prover.prove(vk_limbs, [tx["proof"] for tx in batch], [tx["inputs"] for tx in batch])
+            try:
+                ep = self.prover.prove(vk_limbs, [tx["proof"] for tx in batch], [tx["inputs"] for tx in batch])
+            except Exception:
+                # the batch was taken out of the pool under the lock; a prover / GPU error must not lose the transactions in it
+                with self.mu:
+                    pool.requeue(entries)
+                raise
             resp = message_class("zecale_proto.AggregatedTransaction")()
             resp.application_name = name
             resp.extended_proof.CopyFrom(extended_proof_to_proto(ep))
@@ -355,8 +382,12 @@ class AggregatorService:
         return grpc.method_handlers_generic_handler(SERVICE, handlers)
 
 
-def serve(prover, endpoint=DEFAULT_ENDPOINT, max_workers=8):
-    """RunServer (aggregator_server.cpp:390-416): insecure, listens on `endpoint`; returns (server, bound port)."""
+def serve(prover, endpoint=DEFAULT_ENDPOINT, max_workers=None):
+    """RunServer (aggregator_server.cpp:390-416): insecure, listens on `endpoint`; returns (server, bound port).
+    A GenerateAggregatedTransaction handler blocks for the length of a proof, so the handler pool is at least as deep as the prover
+    has slots (else the slots could never all be busy) plus a few threads for the short RPCs."""
+    if max_workers is None:
+        max_workers = max(8, int(getattr(prover, "gpu_slots", 0)) + 4)
     server = grpc.server(futures.ThreadPoolExecutor(max_workers=max_workers))
     service = AggregatorService(prover)
     server.add_generic_rpc_handlers((service.generic_handler(),))
