@@ -272,6 +272,69 @@ __device__ __forceinline__ bool madd_lds_regy(const XyzzRef& acc, uint32_t* xs, 
   return same_x;
 }
 
+// Full addition into an accumulator that lives ON THE CU for a whole chain of additions: X (packed), ZZ, ZZZ in LDS, Y in registers
+// (the layout of the bucket accumulation); B is an XYZZ point in memory (finite).  A chain acc = B0 + B1 + ... then costs six
+// coordinate loads per addition (of B only: ZZ2 and ZZZ2 twice) and one accumulator store at the very end, where add_mem_s moves
+// ten loads and four stores per addition - the plain sums of the bucket reduction are bound by those round trips, not by the
+// multiplier.  `spill` is where the accumulator goes on the rare same-x path.  Returns true if that path ran.
+__device__ __forceinline__ bool add_lds_regy(const XyzzRef& spill, uint32_t* xs, uint32_t* zz, uint32_t* zzz, Fq& ty, const XyzzRef& B) {
+  Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
+  bool same_x = false;
+#pragma unroll 1
+  for (int step = 0; step < 12; step++) {
+    Fq a, b;
+    switch (step) {
+      case 0: a = lds_ld_packed(xs); b = mem_ld(B, CZZ); break;      // U1 = X1 ZZ2
+      case 1: a = mem_ld(B, CX); b = lds_ld(zz); break;              // U2 = X2 ZZ1
+      case 2: a = T1; b = T1; break;                                 // PP
+      case 3: a = T1; b = T2; break;                                 // PPP
+      case 4: a = T0; b = T2; break;                                 // Q = U1 PP
+      case 5: a = lds_ld(zz); b = T2; break;                         // ZZ1 PP
+      case 6: a = lds_ld(zz); b = mem_ld(B, CZZ); break;             // (ZZ1 PP) ZZ2
+      case 7: a = ty; b = mem_ld(B, CZZZ); break;                    // S1 = Y1 ZZZ2
+      case 8: a = mem_ld(B, CY); b = lds_ld(zzz); break;             // S2 = Y2 ZZZ1
+      case 9: a = lds_ld(zzz); b = T1; break;                        // ZZZ1 PPP
+      case 10: a = lds_ld(zzz); b = mem_ld(B, CZZZ); break;          // (ZZZ1 PPP) ZZZ2
+      default: a = T3; b = T3; break;                                // RR
+    }
+    Fq r = (step == 2 || step == 11) ? fp_sqr(a) : fp_mul(a, b);
+    switch (step) {
+      case 0: T0 = r; break;                                         // U1
+      case 1: T1 = fp_sub<FqParams, 2>(r, T0); break;                // P [4]
+      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
+      case 3: T1 = r; break;                                         // PPP
+      case 4: T0 = r; break;                                         // Q
+      case 5: lds_st(zz, r); break;
+      case 6: lds_st(zz, r); break;                                  // ZZ3
+      case 7: ty = r; break;                                         // S1 (Y1 is dead)
+      case 8: T3 = fp_sub<FqParams, 2>(r, ty); break;                // R [4]
+      case 9: lds_st(zzz, r); break;
+      case 10: lds_st(zzz, r); break;                                // ZZZ3
+      default: {
+        Fq X3 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T1), fp_dbl(T0));   // X3 [10]
+        lds_st_packed(xs, X3);
+        T0 = fp_sub<FqParams, 16>(T0, X3);                           // Q - X3 [18]
+        break;
+      }
+    }
+    if (same_x) break;
+  }
+  if (!same_x) {
+    ty = fp_mul2(T3, T0, fp_sub<FqParams, 2>(fp_zero<FqParams>(), ty), T1);     // Y3 = R (Q - X3) + (2p - S1) PPP  [2]
+  } else {            // PP = 0 at step 2: the accumulator is untouched so far
+    mem_st(spill, CX, lds_ld_packed(xs));
+    mem_st(spill, CY, ty);
+    mem_st(spill, CZZ, lds_ld(zz));
+    mem_st(spill, CZZZ, lds_ld(zzz));
+    add_same_x(spill, B);
+    lds_st_packed(xs, fp_cond_sub_p(fp_mul(mem_ld(spill, CX), fp_one<FqParams>())));   // any bound -> canonical
+    ty = mem_ld(spill, CY);
+    lds_st(zz, mem_ld(spill, CZZ));
+    lds_st(zzz, mem_ld(spill, CZZZ));
+  }
+  return same_x;
+}
+
 // a (memory) += b (memory); both may be infinite.  a is updated in place; b is not written.
 __device__ __forceinline__ void add_mem(const XyzzRef& A, const XyzzRef& B) {
   if (mem_is_inf(B)) return;

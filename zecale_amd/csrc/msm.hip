@@ -845,6 +845,38 @@ __global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_
   for (int u = 1; u < L; u++) pt_add<QUAD>(acc, make_ref(in, in_stride, (uint32_t)(i0 + (size_t)u * row_len)), q, sc);
 }
 
+// k_sum with one lane per output and the running sum held on the CU (add_lds_regy): the throughput-bound plain sums of the bucket
+// reduction.  Same indexing as k_sum.
+__global__ void __launch_bounds__(256, 2) k_sum_lds(uint32_t* __restrict__ in, size_t n_in, uint32_t in_stride, int L, uint32_t row_len,
+                                                     uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds_zz[27 * ZK_LDS_STRIDE], lds_zzz[27 * ZK_LDS_STRIDE], lds_x[24 * ZK_LDS_STRIDE];
+  const size_t n_out = n_in / L;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out) return;
+  uint32_t* zz = lds_zz + threadIdx.x;
+  uint32_t* zzz = lds_zzz + threadIdx.x;
+  uint32_t* xs = lds_x + threadIdx.x;
+  const size_t i0 = (t / row_len) * ((size_t)L * row_len) + (t % row_len);
+  const XyzzRef dst = make_ref(out, (uint32_t)n_out, (uint32_t)t);
+  bool inf = true;
+  Fq ty = fp_zero<FqParams>();
+  for (int u = 0; u < L; u++) {
+    const XyzzRef B = make_ref(in, in_stride, (uint32_t)(i0 + (size_t)u * row_len));
+    if (mem_is_inf(B)) continue;
+    if (inf) {
+      lds_st_packed(xs, mem_ld(B, CX));             // X of a stored point is an X3 [10]: below 2^768, packs into 24 words
+      ty = mem_ld(B, CY);
+      lds_st(zz, mem_ld(B, CZZ));
+      lds_st(zzz, mem_ld(B, CZZZ));
+      inf = false;
+      continue;
+    }
+    if (add_lds_regy(dst, xs, zz, zzz, ty, B)) inf = fp_is_zero_2p(lds_ld(zz));
+  }
+  if (inf) { mem_set_inf(dst); return; }
+  mem_st(dst, CX, lds_ld_packed(xs)); mem_st(dst, CY, ty); mem_st(dst, CZZ, lds_ld(zz)); mem_st(dst, CZZZ, lds_ld(zzz));
+}
+
 // Two-level split of the bucket index j = hi * R + lo (R = 2^lo_bits, H = 2^hi_bits rows):
 //   sum_j (j+1) B_j = R * sum_hi hi * Row[hi] + sum_lo (lo+1) * Col[lo].
 // k_place_hilo lays both small weighted sums out as 2W groups of N = max(R, H) items with weights index+1:
@@ -1425,7 +1457,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   const uint32_t Rr = 1u << lo_bits, Hh = 1u << hi_bits, Nn = Rr > Hh ? Rr : Hh;
   auto launch_sum = [&](hipStream_t s_, uint32_t* in, size_t n_in, uint32_t in_stride, int L, uint32_t row_len, uint32_t* out) {
     size_t n_out = n_in / L;
-    if (n_out >= QUAD_BELOW) hipLaunchKernelGGL(k_sum<false>, dim3(nblk(n_out, 256)), dim3(256), 0, s_, in, n_in, in_stride, L, row_len, out);
+    if (n_out >= QUAD_BELOW) hipLaunchKernelGGL(k_sum_lds, dim3(nblk(n_out, 256)), dim3(256), 0, s_, in, n_in, in_stride, L, row_len, out);
     else hipLaunchKernelGGL(k_sum<true>, dim3(nblk(n_out * 4, 256)), dim3(256), 0, s_, in, n_in, in_stride, L, row_len, out);
   };
   HIP_TRY(hipEventRecord(ctx->ev, st));
