@@ -47,8 +47,8 @@ struct MsmCtx {
   uint2* pairs;
   size_t hist_len;
   uint32_t *counts, *offsets, *block_tot, *entries;
-  uint2* fix_list;      // (first, last) F slot of the buckets cut into more than four F pieces (k_accumulate -> k_fixup_tree)
-  uint2* fix_short;     // (first F slot, number of F pieces) of the buckets with two to four (k_accumulate -> k_fixup_short)
+  uint2* fix_list;      // (first, last) F slot of the buckets cut into more than four F pieces (k_accumulate -> k_fixup_fold)
+  uint2* fix_short;     // (first F slot, number of F pieces) of the buckets with two to four (k_accumulate -> k_fixup_fold)
   uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels, *colS[2], *hilo;
   uint64_t *win_abi, *win_host;
   // batched-affine levels in front of the XYZZ accumulation (k_affine_level): per level the bucket counts / offsets of its output,

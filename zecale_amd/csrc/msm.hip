@@ -9,7 +9,7 @@
 //   k_scan_*            exclusive prefix sum of the (part, block) histogram
 //   k_bucket_sort       a workgroup per part orders its entries by bucket: bucket-ordered list of (point index, sign), offsets, counts
 //   k_accumulate        one lane per fixed-size SLICE of the sorted list: XYZZ mixed additions   <-- dominant
-//   k_fixup_short/_tree/_fixup  stitch the buckets that slice boundaries cut
+//   k_fixup_fold / k_fixup  stitch the buckets that slice boundaries cut
 //   k_sum / k_seg       bucket reduction  sum_j (j+1) B_j : two-level split of the bucket index, then L-ary running sums
 //   k_window_combine / k_hilo_combine   per bucket window: Horner over the levels, R * hi + lo
 // Plain base sets: one bucket window per digit position, and the last step, sum_w 2^(off_w) W_w (about 380 serial
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   {
     // A bucket cut by slice boundaries leaves an L piece (slice t0, where it starts) and F pieces in the slices t0+1 .. t1.  The
     // slice that holds the FIRST F piece of a bucket with several of them puts the bucket on a list: (first F slot, number of F
-    // pieces) - a short list (2 .. 4 pieces: one lane folds them, k_fixup_short) and a long one (k_fixup_tree).  One atomic per
+    // pieces) - a short list (2 .. 4 pieces: one lane or quad folds them) and a long one (a workgroup each): k_fixup_fold.  One atomic per
     // wave and list.
     uint32_t span = 0, tF0 = 0;
     if (offsets[b] < pos0) {
@@ -754,35 +754,36 @@ template <bool QUAD> __device__ __forceinline__ void pt_set_inf(const XyzzRef& d
 }
 
 // Stitch buckets that were cut by slice boundaries.  A bucket that starts in slice t0 and ends in slice t1 > t0 has pieces L[t0],
-// F[t0+1], ..., F[t1].  First the F pieces are folded into F[t0+1]: buckets of 2 .. 4 F pieces by one lane each, densely over the
-// list k_accumulate made (with uniform scalars a few percent of the buckets have two F pieces, none more: one launch over every
-// slice, as rounds 1-2 had it, kept every wave busy for the sake of one lane in twelve); buckets of more pieces - "scalar == 1"
-// in a boolean-heavy witness holds a third of all entries - by a workgroup each, pairwise, in log2(pieces) rounds.
-__global__ void __launch_bounds__(256, 2) k_fixup_short(const uint32_t* __restrict__ cnt, const uint2* __restrict__ list, uint32_t nb,
-                                                         uint32_t* __restrict__ slots, uint32_t stride) {
-  ADD_SCRATCH_DECL(false);
-  const uint32_t n = *cnt;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint2 w = list[i];                          // first F slot, number of F pieces
-    const XyzzRef dst = make_ref(slots, stride, nb + w.x);
-    for (uint32_t j = 1; j < w.y; j++) add_mem_s(dst, make_ref(slots, stride, nb + w.x + j), sc.zz, sc.zzz);
-  }
-}
-
-// Buckets of more than four F pieces (the long list): ALL rounds d = 1, 2, 4, ... in one launch: a workgroup takes a bucket, its 64
-// quads fold the pieces pairwise (F[t] += F[t+d] for t - first divisible by 2d), a barrier between rounds (the pieces live in
-// global memory, coherent inside a CU).  Such buckets are few but long.
-__global__ void __launch_bounds__(256, 2) k_fixup_tree(const uint32_t* __restrict__ work_cnt, const uint2* __restrict__ work_list, uint32_t nb,
+// F[t0+1], ..., F[t1].  First the F pieces are folded into F[t0+1] (k_fixup_fold, ONE launch, two kinds of workgroup):
+//   * buckets of 2 .. 4 F pieces (the short list k_accumulate made): one lane - or one quad, in a latency-bound launch - folds them,
+//     densely over the list.  With uniform scalars a few percent of the buckets have two F pieces, none more: one launch over
+//     every slice, as rounds 1-2 had it, kept every wave busy for the sake of one lane in twelve.
+//   * buckets of more pieces (the long list: "scalar == 1" in a boolean-heavy witness holds a third of all entries): a workgroup
+//     each, its 64 quads fold the pieces pairwise (F[t] += F[t+d] for t - first divisible by 2d) in log2(pieces) rounds d = 1, 2,
+//     4, ..., a barrier between rounds (the pieces live in global memory, coherent inside a CU).
+// Both kinds touch different buckets, so they run side by side: a proof on its own waits for the longer of the two, not their sum.
+template <bool QUAD>
+__global__ void __launch_bounds__(256, 2) k_fixup_fold(const uint32_t* __restrict__ cnt /* [2]: short, long */, const uint2* __restrict__ list_short,
+                                                        const uint2* __restrict__ list_long, uint32_t short_blocks, uint32_t nb,
                                                         uint32_t* __restrict__ slots, uint32_t stride) {
-  ADD_SCRATCH_DECL(true);
-  const uint32_t n = *work_cnt;
-  const uint32_t quad = threadIdx.x >> 2, q = threadIdx.x & 3u;
-  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint2 w = work_list[i];                     // first and last F piece of the bucket
+  ADD_SCRATCH_DECL(QUAD);
+  const uint32_t q = threadIdx.x & 3u;
+  if (blockIdx.x < short_blocks) {
+    const uint32_t n = cnt[0], per = QUAD ? 64u : 256u;
+    for (uint32_t i = blockIdx.x * per + (QUAD ? threadIdx.x >> 2 : threadIdx.x); i < n; i += short_blocks * per) {
+      const uint2 w = list_short[i];                    // first F slot, number of F pieces
+      const XyzzRef dst = make_ref(slots, stride, nb + w.x);
+      for (uint32_t j = 1; j < w.y; j++) pt_add<QUAD>(dst, make_ref(slots, stride, nb + w.x + j), q, sc);
+    }
+    return;
+  }
+  const uint32_t n = cnt[1], quad = threadIdx.x >> 2;
+  for (uint32_t i = blockIdx.x - short_blocks; i < n; i += gridDim.x - short_blocks) {
+    const uint2 w = list_long[i];                       // first and last F piece of the bucket
 #pragma unroll 1
     for (uint32_t d = 1; d <= w.y - w.x; d <<= 1) {
       for (uint64_t t = (uint64_t)w.x + (uint64_t)quad * 2 * d; t + d <= w.y; t += (uint64_t)64 * 2 * d)
-        pt_add<true>(make_ref(slots, stride, nb + (uint32_t)t), make_ref(slots, stride, nb + (uint32_t)t + d), q, sc);
+        add_mem_quad(make_ref(slots, stride, nb + (uint32_t)t), make_ref(slots, stride, nb + (uint32_t)t + d), q);
       __threadfence_block();
       __syncthreads();
     }
@@ -1433,9 +1434,14 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
   // fold the F pieces of the buckets that have several (lists made by k_accumulate), then L + F for every cut bucket
   if (T_run > 2) {
-    hipLaunchKernelGGL(k_fixup_short, dim3(nblk(T_run / 2 < 256 * 512 ? T_run / 2 + 1 : 256 * 512, 256)), dim3(256), 0, st, ctx->block_tot + 0, ctx->fix_short,
-                       (uint32_t)nb, ctx->buckets, ctx->slot_stride);
-    hipLaunchKernelGGL(k_fixup_tree, dim3(128), dim3(256), 0, st, ctx->block_tot + 1, ctx->fix_list, (uint32_t)nb, ctx->buckets, ctx->slot_stride);
+    const bool fold_quads = T_run < (1u << 18) && ctx->quad_below > 1024;     // a small launch that has the chip to itself is latency-bound
+    const uint32_t per = fold_quads ? 64u : 256u;
+    uint32_t sblocks = nblk((size_t)T_run / 2 + 1, per);
+    if (sblocks > 1024) sblocks = 1024;                                        // (the list is walked with a grid stride)
+    if (fold_quads) hipLaunchKernelGGL(k_fixup_fold<true>, dim3(sblocks + 128), dim3(256), 0, st, ctx->block_tot, ctx->fix_short, ctx->fix_list, sblocks,
+                                       (uint32_t)nb, ctx->buckets, ctx->slot_stride);
+    else hipLaunchKernelGGL(k_fixup_fold<false>, dim3(sblocks + 128), dim3(256), 0, st, ctx->block_tot, ctx->fix_short, ctx->fix_list, sblocks,
+                            (uint32_t)nb, ctx->buckets, ctx->slot_stride);
   }
   hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, tight, T_run,
                      ctx->buckets, ctx->slot_stride);
