@@ -1417,6 +1417,14 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     if (fills < 1) fills = 1;
     size_t S = (m + lanes * fills - 1) / (lanes * fills);
     if (S < 16) S = 16;
+    // a bucket should not span more than ~3 slices (the stitching folds 2 .. 4 pieces by one lane; longer chains go through a
+    // workgroup each, which is for the few heavy buckets of a witness, not for every bucket of a small MSM with a narrow window)
+    {
+      size_t n_jobs = 0;
+      for (int k = 0; k < K; k++) n_jobs += jobs[k].n ? 1 : 0;
+      const size_t live_buckets = merged ? B * (n_jobs ? n_jobs : 1) : nb, avg = m / (live_buckets ? live_buckets : 1);
+      if (S < (avg + 1) / 2) S = (avg + 1) / 2;
+    }
     while ((m + S - 1) / S > ctx->T) S++;
     S_run = (uint32_t)S; T_run = (uint32_t)((m + S - 1) / S);
   }
