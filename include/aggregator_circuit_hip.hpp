@@ -74,10 +74,11 @@ struct extended_proof {
 
 class keypair {                            // wsnarkT::keypair: pk (HBM-resident) + vk
  public:
-  explicit keypair(zkhip_keypair* kp) : kp_(kp) {
+  // opts: the key's own table / launch options (a server that proves a stream asks for table_naf = 1); nullptr = the defaults
+  explicit keypair(zkhip_keypair* kp, const zkhip_key_opts* opts = nullptr) : kp_(kp) {
     zkhip_crs_desc d;
     zk_check(zkhip_keypair_crs_desc(kp_, &d), "zkhip_keypair_crs_desc");
-    zk_check(zkhip_crs_upload(&d, &crs_), "zkhip_crs_upload");
+    zk_check(zkhip_crs_upload_ex(&d, opts, &crs_), "zkhip_crs_upload_ex");
   }
   keypair(const keypair&) = delete;
   keypair& operator=(const keypair&) = delete;

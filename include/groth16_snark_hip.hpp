@@ -45,10 +45,11 @@ struct csr_matrix {
 // (libzecale/circuits/aggregator_circuit.hpp:95-97).
 class hip_proving_key {
  public:
-  hip_proving_key(const zkhip_crs_desc& crs, const zkhip_r1cs_desc& cs) {
+  // opts: this key's own table / launch options (zkhip_key_opts travel with the handle; nullptr = the defaults)
+  hip_proving_key(const zkhip_crs_desc& crs, const zkhip_r1cs_desc& cs, const zkhip_key_opts* opts = nullptr) {
     zk_check(zkhip_r1cs_upload(&cs, &r1cs_), "zkhip_r1cs_upload");
-    int rc = zkhip_crs_upload(&crs, &crs_);
-    if (rc != ZKHIP_OK) { zkhip_r1cs_free(r1cs_); zk_check(rc, "zkhip_crs_upload"); }
+    int rc = zkhip_crs_upload_ex(&crs, opts, &crs_);
+    if (rc != ZKHIP_OK) { zkhip_r1cs_free(r1cs_); zk_check(rc, "zkhip_crs_upload_ex"); }
     n_vars_ = cs.n_vars;
   }
   hip_proving_key(const hip_proving_key&) = delete;

@@ -310,7 +310,8 @@ def test_wrapping_proof_equals_oracle(zk, oracle_lib, naf, gpu_witness):
     assert l_pk == l
     A, B, C = agg.get_constraint_system()
     rs = random_fr_uniform(1234, 2)                       # canonical limbs below r are valid Montgomery residues: uniform in Fr
-    for bump, bits in ((0, 3), (1, 1)):
+    # (the invalid-nested-proof batch for the default combination only: the CPU oracle needs ~4 s per proof)
+    for bump, bits in (((0, 3), (1, 1)) if not (naf or gpu_witness) else ((0, 3),)):
         nin = np.array([fr_limbs(in1[0]), fr_limbs(in2[0] + bump)])
         z = agg.witness_gpu(nvk_l, npr, nin) if gpu_witness else agg.witness(nvk_l, npr, nin)
         assert O.r1cs_first_unsatisfied(A, B, C, z) == -1
@@ -332,7 +333,7 @@ def test_two_threads_load_keys_with_different_options(zk):
     (p1, in1), (p2, in2) = proofs[2], proofs[3]
     z = agg.witness(nvk_l, np.concatenate([nested_proof_limbs(p1), nested_proof_limbs(p2)]), np.array([fr_limbs(in1[0]), fr_limbs(in2[0])]))
     r, s_ = fr_limbs(0x77), fr_limbs(0x99)
-    for rep in range(3):
+    for rep in range(2):
         with ThreadPoolExecutor(max_workers=3) as pool:
             futs = [pool.submit(kp.upload_crs, zk.key_opts(table_naf=False)), pool.submit(kp.upload_crs, zk.key_opts(table_naf=True)),
                     pool.submit(kp.upload_crs, zk.key_opts(precompute=False))]

@@ -11,9 +11,30 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
-for d, pre, wl in (("msm_trace", "msm", "msm"), ("prover_trace", "prover", "prover"), ("agg_trace", "agg", "aggregator"),
-                   ("agg_serial_trace", "agg_serial", "aggregator_serial")):
-    shutil.copy(os.path.join(SRC, d, pre + "_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_{wl}_kernel_stats.csv"))
+for d, pre, wl in (("msm_trace", "msm", "msm"), ("msm_only_trace", "msm", "msm_stream_only"), ("msm_serial_trace", "msm", "msm_serial"),
+                   ("prover_trace", "prover", "prover"), ("agg_trace", "agg", "aggregator"), ("agg_serial_trace", "agg_serial", "aggregator_serial")):
+    src = os.path.join(SRC, d, pre + "_kernel_stats.csv")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(DST, f"{tag}_bench_{wl}_kernel_stats.csv"))
+
+# the solo / overlapped split of the MSM stream: per kernel, its average when one MSM runs at a time (nothing else on the chip)
+# beside its average inside the stream of the driver's command (two MSMs in flight)
+def _stats(path):
+    out = {}
+    if os.path.exists(path):
+        for r in csv.DictReader(open(path)):
+            out[r["Name"].split("(")[0].replace("void ", "")] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3)
+    return out
+solo, over = _stats(os.path.join(SRC, "msm_serial_trace", "msm_kernel_stats.csv")), _stats(os.path.join(SRC, "msm_only_trace", "msm_kernel_stats.csv"))
+if solo and over:
+    with open(os.path.join(DST, f"{tag}_msm_solo_vs_stream.csv"), "w") as f:
+        f.write("# per kernel of one 2^20-term G1 MSM: average duration (us) with ONE MSM at a time (bench.py --serial) and inside the stream of the\n")
+        f.write("# driver's command (bench.py --gpus 1 --steps 20 --warmup 5, two MSMs in flight: launches of different MSMs overlap in time)\n")
+        f.write("kernel,calls_per_msm,solo_avg_us,solo_min_us,stream_avg_us,stream_min_us\n")
+        n_solo = max(1, solo.get("zkhip::k_accumulate<1>", (1, 0, 0))[0])
+        for k, (c, a, m) in sorted(solo.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            if k in over and not k.startswith("zkhip::k_table") and not k.startswith("zkhip::k_fixed") and not k.startswith("zkhip::k_bases"):
+                f.write("%s,%.1f,%.1f,%.1f,%.1f,%.1f\n" % (k, c / n_solo, a, m, over[k][1], over[k][2]))
 
 
 def pmc(path):
@@ -32,7 +53,7 @@ for d, pre in (("msm_fetch", "msm"), ("msm_write", "msm"), ("calib_fetch", "cali
         rows.append((k, c, len(v), sum(v) / len(v)))
         tot[(k, c)] = sum(v) / len(v)
 with open(os.path.join(DST, f"{tag}_pmc_fetch_write.csv"), "w") as f:
-    f.write("# rocprofv3 --pmc passes (separate runs: FETCH_SIZE, WRITE_SIZE) of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`\n")
+    f.write("# rocprofv3 --pmc passes (separate runs: FETCH_SIZE, WRITE_SIZE) of `python bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-secondary` (one MSM at a time)\n")
     f.write("# and of tools/ubench/fetch_calib.hip (known byte counts: k_row4 reads 1 GiB, k_gather16 reads 768 MiB, k_store4 writes 1 GiB).\n")
     f.write("# Values in KiB as rocprofv3 reports them.\n# kernel, counter, dispatches, avg_per_dispatch_KiB\n")
     for r in rows:
@@ -54,7 +75,7 @@ out = {
     "calibration": {"row4_true_over_reported": round(f_row, 4), "gather16_true_over_reported": round(f_gather, 4),
                     "store4_true_over_reported": round(f_store, 4), "applied_fetch_factor": round(f_fetch, 4),
                     "applied_write_factor": round(f_store, 4)},
-    "workload": "python bench.py (default: 2^20-term G1 MSM on a table-backed base set)",
+    "workload": "python bench.py --serial (2^20-term G1 MSM on a table-backed base set, one MSM at a time: per-launch counters of a kernel that has the chip to itself)",
     "note": "FETCH_SIZE / WRITE_SIZE of rocprofv3 (KiB x 1024), separate --pmc passes; corrected with factors measured on this "
             "library's own access patterns (tools/ubench/fetch_calib.hip: 4 B/lane limb-major rows through a buffer descriptor, "
             "16 B/lane gathers of 192-byte points) as the guide prescribes for widths it does not calibrate; Infinity-Cache hits "
