@@ -1481,8 +1481,17 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     // row tree: [W][H][R] -> [W][H]  (sum over lo, contiguous)
     uint32_t* in = ctx->buckets; uint32_t in_stride = ctx->slot_stride; size_t n_in = nb; uint32_t left = Rr; int pp = 0;
     if (left == 1) rows = in;   // (c <= 2 never happens: c >= 4)
+    // fan-in of a tree level: 4 while the level is throughput-bound (one lane per output, three additions each, fewer passes over
+    // the data); 2 once it is latency-bound (a quad per output): ONE addition deep instead of three - the chain of dependent
+    // additions of a row / column tree shrinks from 3 log4 to log2 of its length
+    auto tree_fan_in = [&](size_t n_in_, uint32_t left_) {
+      int L = ctx->L;
+      if (n_in_ / (size_t)L < QUAD_BELOW) L = 2;
+      while ((uint32_t)L > left_) L >>= 1;
+      return L;
+    };
     while (left > 1) {
-      int L = ctx->L; while ((uint32_t)L > left) L >>= 1;
+      const int L = tree_fan_in(n_in, left);
       uint32_t* out = ctx->segS[pp];
       // halving-style grouping inside each row of `left` items (item lo' + u * left/L): lanes of a wave read adjacent
       // slots (summing L CONSECUTIVE items instead makes every lane stride L slots: a quarter of each sector used)
@@ -1493,7 +1502,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     in = ctx->buckets; in_stride = ctx->slot_stride; n_in = nb; left = Hh; pp = 0;
     if (left == 1) { cols = ctx->colS[0]; launch_sum(st2, in, n_in, in_stride, 1, Rr, cols); }
     while (left > 1) {
-      int L = ctx->L; while ((uint32_t)L > left) L >>= 1;
+      const int L = tree_fan_in(n_in, left);
       uint32_t* out = ctx->colS[pp];
       launch_sum(st2, in, n_in, in_stride, L, Rr, out);
       n_in /= L; left /= L; in = out; in_stride = (uint32_t)n_in; pp ^= 1; cols = out;
