@@ -161,11 +161,18 @@ struct HJac {
     return q;
   }
   HJac neg() const { HJac r = *this; r.Y = Y.neg(); return r; }
+  // k * P for a canonical little-endian scalar: 4-bit fixed windows from the top (14 additions for the table, then four doublings
+  // and at most one addition per window: ~100 additions instead of the ~190 of double-and-add on a 377-bit scalar)
   HJac mul_canonical(const uint64_t* k, int nlimbs) const {
+    HJac tab[16];
+    tab[0] = infinity(); tab[1] = *this;
+    for (int d = 2; d < 16; d++) tab[d] = (d & 1) ? tab[d - 1].add(*this) : tab[d / 2].dbl();
     HJac acc = infinity();
-    for (int i = nlimbs * 64 - 1; i >= 0; i--) {
-      acc = acc.dbl();
-      if ((k[i / 64] >> (i % 64)) & 1) acc = acc.add(*this);
+    bool any = false;
+    for (int w = nlimbs * 16 - 1; w >= 0; w--) {
+      if (any) { acc = acc.dbl(); acc = acc.dbl(); acc = acc.dbl(); acc = acc.dbl(); }
+      const unsigned d = (unsigned)(k[w / 16] >> ((w % 16) * 4)) & 15u;
+      if (d) { acc = any ? acc.add(tab[d]) : tab[d]; any = true; }
     }
     return acc;
   }

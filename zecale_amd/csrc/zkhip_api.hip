@@ -737,9 +737,31 @@ int zkhip_groth16_prove_partial(const zkhip_crs* crs_slice, zkhip_r1cs* r1cs, co
 }
 
 // tail: A = alpha + evA + r delta1;  B = beta + evB + s delta;  C = evH + evL + s A + r B1 - rs delta1
+// The part of the prover's tail that depends on the key and on (r, s) only - r delta1, s delta2, s delta1, rs delta1: four 377-bit
+// scalar multiplications of single points - is started BEFORE the device work of a proof and collected after it (one host thread
+// each, asleep on the GPU otherwise): a proof on its own then waits for ONE scalar multiplication after its MSMs (s A, r B1 side
+// by side) instead of two in a row.
+struct TailPre {
+  bool started = false;
+  uint64_t rc_[6], sc_[6], rsc_[6];
+  std::future<host::HJac> rd1, sd2, sd1, rsd1;
+};
+static std::future<host::HJac> tail_smul(host::HJac p, const uint64_t* k) {
+  return std::async(std::launch::async, [p, k]() { return p.mul_canonical(k, 6); });
+}
+static void tail_begin(TailPre& tp, const uint64_t delta_g1[24], const uint64_t delta_g2[24], const uint64_t r_m[6], const uint64_t s_m[6]) {
+  using namespace host;
+  HFr r = HFr::from_limbs(r_m), s = HFr::from_limbs(s_m), rs = r * s;
+  r.to_canonical(tp.rc_); s.to_canonical(tp.sc_); rs.to_canonical(tp.rsc_);
+  auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
+  const HJac d1 = aff(delta_g1), d2 = aff(delta_g2);
+  tp.rd1 = tail_smul(d1, tp.rc_); tp.sd2 = tail_smul(d2, tp.sc_); tp.sd1 = tail_smul(d1, tp.sc_); tp.rsd1 = tail_smul(d1, tp.rsc_);
+  tp.started = true;
+}
+
 static int finish_impl(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
                        const uint64_t delta_g2[24], const uint64_t sums_jac[180], const uint64_t r_m[6], const uint64_t s_m[6],
-                       uint64_t proof_affine[72], double* tail_ms) {
+                       uint64_t proof_affine[72], double* tail_ms, TailPre* pre = nullptr) {
   using namespace host;
   using clk = std::chrono::steady_clock;
   if (!alpha_g1 || !beta_g1 || !beta_g2 || !delta_g1 || !delta_g2 || !sums_jac || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
@@ -747,19 +769,15 @@ static int finish_impl(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], 
   const uint64_t *evA = sums_jac, *evB2 = sums_jac + 36, *evB1 = sums_jac + 72, *evH = sums_jac + 108, *evL = sums_jac + 144;
   auto jac = [](const uint64_t* p) { HJac q; q.X = HFq::from_limbs(p); q.Y = HFq::from_limbs(p + 12); q.Z = HFq::from_limbs(p + 24); return q; };
   auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
-  HFr r = HFr::from_limbs(r_m), s = HFr::from_limbs(s_m), rs = r * s;
-  uint64_t rc_[6], sc_[6], rsc_[6];
-  r.to_canonical(rc_); s.to_canonical(sc_); rs.to_canonical(rsc_);
-  HJac d1 = aff(delta_g1), d2 = aff(delta_g2);
-  // six independent 377-bit scalar multiplications of single points: serial chains, one host thread each
-  auto smul = [](HJac p, const uint64_t* k) { return std::async(std::launch::async, [p, k]() { return p.mul_canonical(k, 6); }); };
-  auto f_rd1 = smul(d1, rc_), f_sd2 = smul(d2, sc_), f_sd1 = smul(d1, sc_), f_rsd1 = smul(d1, rsc_);
-  HJac gA = jac(evA).add(aff(alpha_g1)).add(f_rd1.get());
-  auto f_sA = smul(gA, sc_);
-  HJac gB1 = jac(evB1).add(aff(beta_g1)).add(f_sd1.get());
-  auto f_rB1 = smul(gB1, rc_);
-  HJac gB2 = jac(evB2).add(aff(beta_g2)).add(f_sd2.get());
-  HJac gC = jac(evH).add(jac(evL)).add(f_sA.get()).add(f_rB1.get()).add(f_rsd1.get().neg());
+  TailPre local;
+  TailPre& tp = (pre && pre->started) ? *pre : local;
+  if (!tp.started) tail_begin(tp, delta_g1, delta_g2, r_m, s_m);       // (the plain zkhip_groth16_finish: nothing was started ahead)
+  HJac gA = jac(evA).add(aff(alpha_g1)).add(tp.rd1.get());
+  auto f_sA = tail_smul(gA, tp.sc_);
+  HJac gB1 = jac(evB1).add(aff(beta_g1)).add(tp.sd1.get());
+  auto f_rB1 = tail_smul(gB1, tp.rc_);
+  HJac gB2 = jac(evB2).add(aff(beta_g2)).add(tp.sd2.get());
+  HJac gC = jac(evH).add(jac(evL)).add(f_sA.get()).add(f_rB1.get()).add(tp.rsd1.get().neg());
   HFq x, y;
   gA.to_affine(x, y); x.to_limbs(proof_affine); y.to_limbs(proof_affine + 12);
   gB2.to_affine(x, y); x.to_limbs(proof_affine + 24); y.to_limbs(proof_affine + 36);
@@ -780,15 +798,18 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
   if (!crs || !r1cs || !z || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (crs->device != r1cs->device) return fail(ZKHIP_ERR_ARG, "proving key and constraint system live on different devices");
   BIND(crs);
+  TailPre pre;
   {
     std::lock_guard<std::mutex> lk(g.dev[crs->device].mu);
     const size_t m = r1cs->dev->n_vars, l = r1cs->dev->n_primary, d = (size_t)1 << r1cs->dev->log_d;
     if (crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+    tail_begin(pre, crs->delta_g1, crs->delta_g2, r_m, s_m);       // the key-only part of the tail runs under the device work
     int rc = prove_partial(g.dev[crs->device].ps, crs, r1cs->dev, z, 0, 0, 0, sums);
     if (rc != ZKHIP_OK) return rc;
   }
   t_prove_dev = crs->device;      // zkhip_last_prove_timings reads the device of this thread's last proof
-  return zkhip_groth16_finish(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine);
+  return finish_impl(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine,
+                     &g.dev[crs->device].ps.ms[7], &pre);
 }
 
 // ---- prover instances: one proof in flight each, several instances per GPU -------------------------------------------
@@ -843,10 +864,12 @@ static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t*
   BIND(p);                                    // called from pipeline / application threads that never ran zkhip_init
   std::lock_guard<std::mutex> lk(p->mu);
   uint64_t sums[180];
+  const zkhip_crs* c = p->crs;
+  TailPre pre;
+  tail_begin(pre, c->delta_g1, c->delta_g2, r_m, s_m);             // the key-only part of the tail runs under the device work
   int rc = prove_partial(p->ps, p->crs, p->rd, z, 0, 0, 0, sums, d_z);
   if (rc != ZKHIP_OK) return rc;
-  const zkhip_crs* c = p->crs;
-  return finish_impl(c->alpha_g1, c->beta_g1, c->beta_g2, c->delta_g1, c->delta_g2, sums, r_m, s_m, proof_affine, &p->ps.ms[7]);
+  return finish_impl(c->alpha_g1, c->beta_g1, c->beta_g2, c->delta_g1, c->delta_g2, sums, r_m, s_m, proof_affine, &p->ps.ms[7], &pre);
 }
 
 int zkhip_prover_set_streaming(zkhip_prover* p, int on) {
