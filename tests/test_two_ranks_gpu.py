@@ -32,3 +32,4 @@ def test_point_partitioned_msm_across_two_processes():
     line = _bench("--gpus", "2", "--log-n", "16", "--steps", "4", "--warmup", "1", "--no-cpu-baseline")
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["terms_per_gpu"] == 1 << 16
+    assert line["combined_result_matches_closed_form"] is True        # sum over BOTH ranks' slices = (sum s_i k_i) G
