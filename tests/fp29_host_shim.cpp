@@ -23,6 +23,8 @@ extern "C" {
     for (int i = 0; i < PR::NL; i++) { x.l[i] = a[i]; y.l[i] = b[i]; z.l[i] = c[i]; w.l[i] = d[i]; } \
     Fp<PR> o = fp_mul2(x, y, z, w);                                                            \
     for (int i = 0; i < PR::NL; i++) r[i] = o.l[i]; }                                          \
+  void F##_sub_sub2(const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* r) {     \
+    fp_to_abi<PR>(fp_sub_sub2<PR, 8>(fp_from_abi<PR>(a), fp_from_abi<PR>(b), fp_from_abi<PR>(c)), r); } \
   void F##_sqr(const uint64_t* a, uint64_t* r) { fp_to_abi<PR>(fp_sqr(fp_from_abi<PR>(a)), r); } \
   void F##_add(const uint64_t* a, const uint64_t* b, uint64_t* r) {                            \
     fp_to_abi<PR>(fp_add(fp_from_abi<PR>(a), fp_from_abi<PR>(b)), r); }                        \

@@ -45,6 +45,8 @@ def test_fp29_against_golden_and_random(shim, name, p, n):
         assert fm(R.limbs_to_int(out)) == a * a % p
         getattr(shim, name + "_add")(_arr(tm(a), n), _arr(tm(b), n), out)
         assert fm(R.limbs_to_int(out)) == (a + b) % p
+        getattr(shim, name + "_sub_sub2")(_arr(tm(a), n), _arr(tm(b), n), _arr(tm((a ^ b) % p), n), out)
+        assert fm(R.limbs_to_int(out)) == (a - b - 2 * ((a ^ b) % p)) % p          # one carry pass for a - b - 2c + 8p
         # the dual product (one reduction for a b + c d): plain operands, then lazily bounded ones with every limb near its maximum
         c, d = (a * 3 + 1) % p, (b * b + 7) % p
         getattr(shim, name + "_mul2")(_arr(tm(a), n), _arr(tm(b), n), _arr(tm(c), n), _arr(tm(d), n), out)

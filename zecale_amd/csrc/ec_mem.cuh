@@ -251,7 +251,7 @@ __device__ __forceinline__ bool madd_lds_regy(const XyzzRef& acc, uint32_t* xs, 
       case 4: lds_st(zz, r); break;
       case 5: lds_st(zzz, r); break;
       case 6: T0 = r; break;                                         // Q
-      default: T2 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T3), fp_dbl(T0)); lds_st_packed(xs, T2); break;   // X3 [10]
+      default: T2 = fp_sub_sub2<FqParams, 8>(r, T3, T0); lds_st_packed(xs, T2); break;   // X3 = RR - PPP - 2Q [10], one carry pass
     }
     if (same_x) break;
   }
@@ -311,7 +311,7 @@ __device__ __forceinline__ bool add_lds_regy(const XyzzRef& spill, uint32_t* xs,
       case 9: lds_st(zzz, r); break;
       case 10: lds_st(zzz, r); break;                                // ZZZ3
       default: {
-        Fq X3 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T1), fp_dbl(T0));   // X3 [10]
+        Fq X3 = fp_sub_sub2<FqParams, 8>(r, T1, T0);                 // X3 = RR - PPP - 2Q [10], one carry pass
         lds_st_packed(xs, X3);
         T0 = fp_sub<FqParams, 16>(T0, X3);                           // Q - X3 [18]
         break;
@@ -428,7 +428,7 @@ __device__ __forceinline__ void add_mem_s(const XyzzRef& A, const XyzzRef& B, ui
       case 9: lds_st(zzz, r); break;
       case 10: mem_st(A, CZZZ, r); break;                            // ZZZ3
       default: {
-        Fq X3 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T1), fp_dbl(T0));   // X3 [10]
+        Fq X3 = fp_sub_sub2<FqParams, 8>(r, T1, T0);                 // X3 = RR - PPP - 2Q [10], one carry pass
         mem_st(A, CX, X3);
         T0 = fp_sub<FqParams, 16>(T0, X3);                           // Q - X3 [18]
         break;

@@ -230,6 +230,35 @@ ZK_HD ZK_INL Fp<PR> fp_sub_k(const Fp<PR>& a, const Fp<PR>& b) {
   return r;
 }
 
+// K * p with every limb but the top raised by 4 * 2^29 at its upper neighbour's expense (same number): a_i + d_i - b_i - 2 c_i never
+// goes below zero for normalised a_i, b_i, c_i.
+template <class PR, int K>
+struct SubSafe3KP {
+  uint32_t l[PR::NL];
+  constexpr SubSafe3KP() : l{} {
+    uint64_t c = 0;
+    for (int i = 0; i < PR::NL; i++) {
+      c += (uint64_t)PR::P[i] * K;
+      l[i] = (i + 1 < PR::NL) ? (uint32_t)(c & M29) : (uint32_t)c;
+      c >>= 29;
+    }
+    for (int i = 0; i + 1 < PR::NL; i++) { l[i] += 4u << 29; l[i + 1] -= 4u; }
+  }
+};
+// r = a - b - 2c + K*p with ONE carry pass (X3 = RR - PPP - 2Q of every addition formula: two subtractions and a doubling, each
+// with its own carry normalisation, cost three passes).  Requires b + 2c <= K*p and K*p's top limb >= 4; limbs of a, b, c normalised.
+// bound(r) = bound(a) + K.
+template <class PR, int K>
+ZK_HD ZK_INL Fp<PR> fp_sub_sub2(const Fp<PR>& a, const Fp<PR>& b, const Fp<PR>& c) {
+  constexpr SubSafe3KP<PR, K> kp{};
+  static_assert(PR::NL >= 2, "");
+  Fp<PR> r;
+#pragma unroll
+  for (int i = 0; i < PR::NL; i++) r.l[i] = a.l[i] + kp.l[i] - b.l[i] - (c.l[i] << 1);
+  fp_normalise(r);
+  return r;
+}
+
 template <class PR>
 ZK_HD ZK_INL Fp<PR> fp_const(const uint32_t (&c)[PR::NL]) {
   Fp<PR> r;
