@@ -227,7 +227,8 @@ __device__ __forceinline__ bool madd_mem_lds(const XyzzRef& acc, uint32_t* xs, u
 // Y3 = R (Q - X3) + (-Y1) PPP as ONE dual product with one Montgomery reduction (fp_mul2): 13,149 v_mad_u64_u32 per addition
 // (6 x 1,458 + 2 x 1,107 + 2,187) instead of 13,878, and one lazy subtraction less.  Five field elements live at most.
 __device__ __forceinline__ bool madd_lds_regy(const XyzzRef& acc, uint32_t* xs, uint32_t* zz, uint32_t* zzz, Fq& ty, const AffPacked* p, bool neg) {
-  Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
+  Fq T0, T1, T2, T3;      // (deliberately not initialised: every one is written by the step before the first that reads it, and zeroing
+                          //  them costs 108 moves per addition)
   bool same_x = false;
 #pragma unroll 1
   for (int step = 0; step < 8; step++) {
