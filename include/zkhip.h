@@ -338,6 +338,9 @@ void zkhip_keypair_free(zkhip_keypair* kp);
 
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
+/* begin and end of that launch (ms, HIP events) on a per-device time base: a caller that keeps several MSMs in flight
+ * (zkhip_msm_submit / collect) can see how their accumulations overlap and take the union of the intervals */
+int zkhip_last_accumulate_interval(float out_ms[2]);
 
 /* replaces: libff::Fr<wppT>::random_element() as r1cs_gg_ppzksnark_prover draws the proof's randomisers r, s (reached from
  * aggregator_circuit.tcc:168) and the generator its toxic waste: one field element uniform in Fr, 6 Montgomery limbs, from the

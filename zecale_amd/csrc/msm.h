@@ -61,6 +61,8 @@ struct MsmCtx {
   uint32_t* aff_scratch;
   size_t m_acc_max;                  // upper bound on the entries that reach k_accumulate (sizes S, T and the slot array)
   float last_accumulate_ms;
+  float last_acc_begin_ms, last_acc_end_ms;   // the same launch on the device's time base (msm_time_base): lets a caller that keeps
+                                              // several MSMs in flight see how their accumulations overlap
   bool pending;       // an MSM has been enqueued by msm_launch and not yet collected by msm_finish
   size_t pending_n;
   char errbuf[256];
@@ -70,6 +72,8 @@ struct MsmCtx {
 void msm_force_aff_levels(int levels);
 int msm_forced_aff_levels();
 int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K);
+// a per-device event recorded once: the origin of last_acc_begin_ms / last_acc_end_ms
+hipEvent_t msm_time_base();
 void msm_plan_free(MsmCtx* ctx);
 int msm_bases_convert(const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags, char* errbuf, size_t errlen);
 // table_stride: distance (in points) between the levels of a precomputed table (merged plans only)

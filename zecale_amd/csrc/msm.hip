@@ -1159,8 +1159,33 @@ static int choose_aff_levels(size_t m_entries, size_t nb) {
   return forced >= 0 ? forced : 0;
 }
 
+// One event per device, recorded the first time a plan is made there: the origin of the absolute launch times of k_accumulate.
+hipEvent_t msm_time_base() {
+  static hipEvent_t base[64];
+  static bool made[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!made[dev]) {
+    if (hipEventCreate(&base[dev]) == hipSuccess && hipEventRecord(base[dev], 0) == hipSuccess && hipEventSynchronize(base[dev]) == hipSuccess) made[dev] = true;
+    else return nullptr;
+  }
+  return base[dev];
+}
+
+static void read_accumulate_times(MsmCtx* ctx) {
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
+  ctx->last_accumulate_ms = ms;
+  hipEvent_t base = msm_time_base();
+  float t0 = 0, t1 = 0;
+  if (base && hipEventElapsedTime(&t0, base, ctx->ev_acc0) == hipSuccess && hipEventElapsedTime(&t1, base, ctx->ev_acc1) == hipSuccess) {
+    ctx->last_acc_begin_ms = t0; ctx->last_acc_end_ms = t1;
+  }
+}
+
 int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   memset(ctx, 0, sizeof *ctx);
+  (void)msm_time_base();
   if (K < 1 || K > MSM_MAX_JOBS || (!merged && K != 1)) return ZKHIP_ERR_ARG;
   ctx->K = K;
   ctx->quad_below = (uint32_t)env_int("ZKHIP_QUAD_BELOW", 65536, 1, 1 << 30);
@@ -1582,9 +1607,7 @@ int msm_finish_multi(MsmCtx* ctx, int K, uint64_t* out_jac) {
   ctx->pending = false;
   if (ctx->pending_n) {
     HIP_TRY(zk_event_wait(ctx->ev_done));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
-    ctx->last_accumulate_ms = ms;
+    read_accumulate_times(ctx);
   }
   for (int k = 0; k < K; k++) {
     HJac q = HJac::infinity();
@@ -1612,9 +1635,7 @@ int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]) {
     return ZKHIP_OK;
   }
   HIP_TRY(zk_event_wait(ctx->ev_done));
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
-  ctx->last_accumulate_ms = ms;
+  read_accumulate_times(ctx);
 
   // host: sum_w 2^(c w) W_w  (Horner from the top window)
   HJac acc = HJac::infinity();

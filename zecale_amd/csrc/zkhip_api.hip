@@ -60,6 +60,7 @@ struct ProveState {
   size_t dz_cap = 0;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float last_accumulate_ms = 0.f;
+  float last_acc_interval[2] = {0.f, 0.f};   // begin / end of that launch on the device's time base
   int last_submit_slot = -1;       // zkhip_msm_submit: the slot of the previous submission (its accumulation gates the next one's)
   uint32_t quad_below = 0;         // 0: the engine's default; else the MSM contexts' quad_below (zkhip_prover_set_streaming)
   void release() {
@@ -363,7 +364,7 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
   rc = msm_run(&ps.ctx[0], bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                scalars_montgomery, bases->len, out_jac);
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", ps.ctx[0].errbuf);
-  else { ps.last_accumulate_ms = ps.ctx[0].last_accumulate_ms; t_prove_dev = bases->device; }
+  else { ps.last_accumulate_ms = ps.ctx[0].last_accumulate_ms; ps.last_acc_interval[0] = ps.ctx[0].last_acc_begin_ms; ps.last_acc_interval[1] = ps.ctx[0].last_acc_end_ms; t_prove_dev = bases->device; }
   return rc;
 }
 
@@ -406,7 +407,7 @@ int zkhip_msm_collect(int slot, uint64_t out_jac[36]) {
   if (!ps.ready[slot] || !cx->pending) return fail(ZKHIP_ERR_STATE, "nothing submitted on this slot");
   int rc = msm_finish(cx, out_jac);
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", cx->errbuf);
-  else { ps.last_accumulate_ms = cx->last_accumulate_ms; t_prove_dev = dev; }
+  else { ps.last_accumulate_ms = cx->last_accumulate_ms; ps.last_acc_interval[0] = cx->last_acc_begin_ms; ps.last_acc_interval[1] = cx->last_acc_end_ms; t_prove_dev = dev; }
   return rc;
 }
 
@@ -1109,6 +1110,12 @@ int zkhip_keypair_read(const char* path, zkhip_keypair** out) {
 
 void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 
+int zkhip_last_accumulate_interval(float out_ms[2]) {
+  const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();
+  if (!out_ms || dev < 0) return ZKHIP_ERR_ARG;
+  out_ms[0] = g.dev[dev].ps.last_acc_interval[0]; out_ms[1] = g.dev[dev].ps.last_acc_interval[1];
+  return ZKHIP_OK;
+}
 float zkhip_last_accumulate_ms(void) {
   const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();       // where this thread's last MSM / proof ran
   return dev >= 0 ? g.dev[dev].ps.last_accumulate_ms : 0.f;

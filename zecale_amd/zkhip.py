@@ -28,7 +28,7 @@ EXPORTS = [
     "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_new_ex", "zkhip_crs_device", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
-    "zkhip_crs_upload_ex", "zkhip_crs_upload_slice_ex", "zkhip_bases_precompute_ex", "zkhip_crs_table_kind", "zkhip_crs_finite_terms",
+    "zkhip_last_accumulate_interval", "zkhip_crs_upload_ex", "zkhip_crs_upload_slice_ex", "zkhip_bases_precompute_ex", "zkhip_crs_table_kind", "zkhip_crs_finite_terms",
 ]
 
 
@@ -752,3 +752,10 @@ def jac_add(a, b):
 
 def last_accumulate_ms():
     return float(load().zkhip_last_accumulate_ms())
+
+
+def last_accumulate_interval():
+    """(begin, end) of the last collected MSM's accumulation launch, ms on the device's time base."""
+    t = (ctypes.c_float * 2)()
+    _check(load().zkhip_last_accumulate_interval(t))
+    return float(t[0]), float(t[1])
