@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 #include "ec_affine.cuh"
@@ -1163,8 +1164,10 @@ static int choose_aff_levels(size_t m_entries, size_t nb) {
 hipEvent_t msm_time_base() {
   static hipEvent_t base[64];
   static bool made[64];
+  static std::mutex mu;                     // plans are made under per-device or per-prover locks: several threads may arrive here
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lk(mu);
   if (!made[dev]) {
     if (hipEventCreate(&base[dev]) == hipSuccess && hipEventRecord(base[dev], 0) == hipSuccess && hipEventSynchronize(base[dev]) == hipSuccess) made[dev] = true;
     else return nullptr;
