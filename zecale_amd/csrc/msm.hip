@@ -1227,7 +1227,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
     ctx->sort_NP = (uint32_t)(ctx->B >> LB);
     ctx->sort_bins = merged ? ctx->sort_NP : ctx->sort_NP * (uint32_t)ctx->Wd;
     if ((size_t)ctx->sort_bins * 8 > 60 * 1024) return ZKHIP_ERR_ARG;             // LDS of k_digit_pass<1>: counters + bases
-    uint32_t tile = 1024;
+    uint32_t tile = (uint32_t)env_int("ZKHIP_SORT_TILE", 1024, 256, 16384) & ~255u;      // scalars per block of k_digit_pass (tuning knob)
     while ((max_n + tile - 1) / tile > 1024) tile *= 2;
     ctx->sort_tile = tile;
     const size_t nbx = (max_n + tile - 1) / tile;
