@@ -143,11 +143,9 @@ __device__ __forceinline__ bool madd_mem(const XyzzRef& acc, const AffPacked* p,
   return same_x;
 }
 
-// ---- LDS-staged variant for the bucket accumulation --------------------------------------------
-// ZZ and ZZZ of the lane's current accumulator live in LDS for the whole run of additions into one
-// bucket ([27][256] images, word k of lane t at base[k*256 + t]: conflict-free); X and Y stay in the
-// memory slot.  That halves the accumulator traffic per addition (4 of the 8 coordinate loads and 2 of the
-// 4 stores never leave the CU) and removes four global-memory round trips from the critical path.
+// ---- LDS-staged accumulators -------------------------------------------------------------------
+// X (packed), ZZ and ZZZ of a lane's running accumulator live in LDS for a whole run of additions ([k][256] images, word k of lane
+// t at base[k*256 + t]: conflict-free), Y in registers (madd_lds_regy, add_lds_regy below).
 #define ZK_LDS_STRIDE 256
 __device__ __forceinline__ Fq lds_ld(const uint32_t* base) {
   Fq v;
@@ -174,55 +172,8 @@ __device__ __forceinline__ void lds_st_packed(uint32_t* base, const Fq& v) {   /
   for (int i = 0; i < 24; i++) base[i * ZK_LDS_STRIDE] = w[i];
 }
 
-// acc (Y in memory; X (packed), ZZ, ZZZ in LDS; finite) += p.  Returns true if the rare same-x path ran
-// (the accumulator was then completed through memory and ZZ/ZZZ reloaded).
-__device__ __forceinline__ bool madd_mem_lds(const XyzzRef& acc, uint32_t* xs, uint32_t* zz, uint32_t* zzz, const AffPacked* p, bool neg) {
-  Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
-  bool same_x = false;
-#pragma unroll 1
-  for (int step = 0; step < 10; step++) {
-    Fq a, b;
-    switch (step) {
-      case 0: a = aff_ld_x(p); b = lds_ld(zz); break;                // U2 = x2 ZZ1
-      case 1: a = aff_ld_y(p, neg); b = lds_ld(zzz); break;          // S2 = y2 ZZZ1
-      case 2: a = T0; b = T0; break;                                 // PP = P^2
-      case 3: a = T0; b = T2; break;                                 // PPP = P PP
-      case 4: a = lds_ld(zz); b = T2; break;                         // ZZ3 = ZZ1 PP
-      case 5: a = lds_ld(zzz); b = T3; break;                        // ZZZ3 = ZZZ1 PPP
-      case 6: a = lds_ld_packed(xs); b = T2; break;                  // Q = X1 PP
-      case 7: a = T1; b = T1; break;                                 // RR = R^2
-      case 8: a = T1; b = fp_sub<FqParams, 16>(T0, T2); break;       // Y3a = R (Q - X3)
-      default: a = mem_ld(acc, CY); b = T3; break;                   // Y3b = Y1 PPP
-    }
-    Fq r = (step == 2 || step == 7) ? fp_sqr(a) : fp_mul(a, b);   // PP and RR are squarings (378 + 729 products instead of 1458)
-    switch (step) {
-      case 0: T0 = fp_sub<FqParams, 16>(r, lds_ld_packed(xs)); break; // P  [18]
-      case 1: T1 = fp_sub<FqParams, 4>(r, mem_ld(acc, CY)); break;   // R  [6]
-      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
-      case 3: T3 = r; break;                                         // PPP
-      case 4: lds_st(zz, r); break;
-      case 5: lds_st(zzz, r); break;
-      case 6: T0 = r; break;                                         // Q
-      case 7: T2 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T3), fp_dbl(T0)); lds_st_packed(xs, T2); break;   // X3 [10]
-      case 8: T0 = r; break;                                         // Y3a
-      default: mem_st(acc, CY, fp_sub<FqParams, 2>(T0, r)); break;   // Y3 [4]
-    }
-    if (same_x) break;
-  }
-  if (same_x) {
-    mem_st(acc, CX, lds_ld_packed(xs));
-    mem_st(acc, CZZ, lds_ld(zz));
-    mem_st(acc, CZZZ, lds_ld(zzz));
-    madd_same_x(acc, p, neg);
-    lds_st_packed(xs, fp_cond_sub_p(fp_mul(mem_ld(acc, CX), fp_one<FqParams>())));   // any bound -> canonical
-    lds_st(zz, mem_ld(acc, CZZ));
-    lds_st(zzz, mem_ld(acc, CZZZ));
-  }
-  return same_x;
-}
-
-// Variant with the accumulator's Y carried in REGISTERS across the additions of a run (ty, bound [4]) instead of the memory
-// slot: X (packed), ZZ, ZZZ in LDS as above.  No global accumulator traffic in the steady state; `acc` is only touched on the
+// acc += p (packed affine, finite; y negated when neg), the accumulator's Y carried in REGISTERS across the additions of a run
+// (ty, bound [4]), X (packed), ZZ, ZZZ in LDS.  No global accumulator traffic in the steady state; `acc` is only touched on the
 // rare same-x path.  Eight single products in the rolled loop (one multiplier body, one squarer body), then
 // Y3 = R (Q - X3) + (-Y1) PPP as ONE dual product with one Montgomery reduction (fp_mul2): 13,149 v_mad_u64_u32 per addition
 // (6 x 1,458 + 2 x 1,107 + 2,187) instead of 13,878, and one lazy subtraction less.  Five field elements live at most.
@@ -336,55 +287,8 @@ __device__ __forceinline__ bool add_lds_regy(const XyzzRef& spill, uint32_t* xs,
   return same_x;
 }
 
-// a (memory) += b (memory); both may be infinite.  a is updated in place; b is not written.
-__device__ __forceinline__ void add_mem(const XyzzRef& A, const XyzzRef& B) {
-  if (mem_is_inf(B)) return;
-  if (mem_is_inf(A)) { mem_copy(A, B); return; }
-  Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
-  bool same_x = false;
-#pragma unroll 1
-  for (int step = 0; step < 14; step++) {
-    Fq a, b;
-    switch (step) {
-      case 0: a = mem_ld(A, CX); b = mem_ld(B, CZZ); break;          // U1
-      case 1: a = mem_ld(B, CX); b = mem_ld(A, CZZ); break;          // U2
-      case 2: a = T1; b = T1; break;                                 // PP
-      case 3: a = T1; b = T2; break;                                 // PPP
-      case 4: a = T0; b = T2; break;                                 // Q = U1 PP
-      case 5: a = mem_ld(A, CZZ); b = T2; break;                     // ZZ1 PP
-      case 6: a = mem_ld(A, CZZ); b = mem_ld(B, CZZ); break;         // (ZZ1 PP) ZZ2
-      case 7: a = mem_ld(A, CY); b = mem_ld(B, CZZZ); break;         // S1
-      case 8: a = mem_ld(B, CY); b = mem_ld(A, CZZZ); break;         // S2
-      case 9: a = mem_ld(A, CZZZ); b = T1; break;                    // ZZZ1 PPP
-      case 10: a = mem_ld(A, CZZZ); b = mem_ld(B, CZZZ); break;      // (ZZZ1 PPP) ZZZ2
-      case 11: a = T2; b = T1; break;                                // Y3b = S1 PPP
-      case 12: a = T3; b = T3; break;                                // RR
-      default: a = T3; b = fp_sub<FqParams, 16>(T0, T1); break;      // Y3a = R (Q - X3)
-    }
-    Fq r = fp_mul(a, b);
-    switch (step) {
-      case 0: T0 = r; break;                                         // U1
-      case 1: T1 = fp_sub<FqParams, 2>(r, T0); break;                // P [4]
-      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
-      case 3: T1 = r; break;                                         // PPP
-      case 4: T0 = r; break;                                         // Q
-      case 5: mem_st(A, CZZ, r); break;
-      case 6: mem_st(A, CZZ, r); break;                              // ZZ3
-      case 7: T2 = r; break;                                         // S1
-      case 8: T3 = fp_sub<FqParams, 2>(r, T2); break;                // R [4]
-      case 9: mem_st(A, CZZZ, r); break;
-      case 10: mem_st(A, CZZZ, r); break;                            // ZZZ3
-      case 11: T2 = r; break;                                        // Y3b
-      case 12: T1 = fp_sub<FqParams, 4>(fp_sub<FqParams, 4>(r, T1), fp_dbl(T0)); mem_st(A, CX, T1); break;   // X3 [10]
-      default: mem_st(A, CY, fp_sub<FqParams, 2>(r, T2)); break;     // Y3 [4]
-    }
-    if (same_x) break;
-  }
-  if (same_x) add_same_x(A, B);
-}
-
-// add_mem with a per-lane LDS scratch of 2 x 27 words (limb-major images, ZK_LDS_STRIDE lanes per block): A's ZZ and ZZZ are
-// fetched once instead of three times each, and the two-step products ZZ1 PP ZZ2 / ZZZ1 PPP ZZZ2 keep their intermediate in
+// a (memory) += b (memory); both may be infinite; a is updated in place, b is not written.  Per-lane LDS scratch of 2 x 27 words
+// (limb-major images, ZK_LDS_STRIDE lanes per block): A's ZZ and ZZZ are fetched once instead of three times each, and the two-step products ZZ1 PP ZZ2 / ZZZ1 PPP ZZZ2 keep their intermediate in
 // LDS instead of a global round trip: 15 coordinate transfers per addition instead of 22 (the throughput-bound reduction
 // launches run at the L2's bandwidth, not at the multiplier's).
 __device__ __forceinline__ void add_mem_s(const XyzzRef& A, const XyzzRef& B, uint32_t* zz, uint32_t* zzz) {

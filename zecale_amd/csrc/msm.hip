@@ -28,14 +28,6 @@
 #include "msm.h"
 #include "wait.h"
 
-#ifndef ZK_ACC_REGY
-#define ZK_ACC_REGY 1
-#endif
-#ifndef ZK_ACC_TOUCH
-#define ZK_ACC_TOUCH 0      // 1: touch the NEXT point's two cache lines one addition ahead.  Measured (round 3): k_accumulate 11.5 -> 12.1 ms at
-                            // 2^20, the wrapping stream 306 -> 278 proofs/s - the three carried registers push the kernel from 12-19 to
-                            // 46-48 spilled dwords, which costs more than the warmed cache returns.  Left in as a measured alternative.
-#endif
 
 namespace zkhip {
 
@@ -461,22 +453,15 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   uint32_t* xs = lds_x + threadIdx.x;
   XyzzRef acc = make_ref(slots, stride, 0);
   bool inf = true;
-#if ZK_ACC_REGY
   Fq ty = fp_zero<FqParams>();     // Y of the running accumulator, carried in registers across the additions of a run
-#endif
   const bool dense = entries == nullptr;
   uint32_t e_next = dense ? pos0 : entries[pos0];
-#if ZK_ACC_TOUCH
-  uint32_t touch = 0, t0 = 0, t1 = 0;
-#endif
   for (uint32_t k = pos0; k < pos1; k++) {
     if (k == bend) {
       if (!first) {
         if (!inf) {   // close the finished run
           mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));
-#if ZK_ACC_REGY
           mem_st(acc, CY, ty);
-#endif
         }
         b++;
         while (offsets[b] + counts[b] <= k) b++;     // next non-empty bucket
@@ -491,50 +476,25 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
     uint32_t e = e_next;
     if (k + 1 < pos1) e_next = dense ? k + 1 : entries[k + 1];        // fetched a whole addition ahead of its use
     const AffPacked* p = (dense ? bp.p[0] : base_of<NJ>(bp, b >> bshift)) + (e & 0x7fffffffu);
-#if ZK_ACC_TOUCH
-    // A point is gathered from a table of gigabytes: its page-table walk and the fetch of its two 128-byte lines cost microseconds,
-    // and with two waves per SIMD a stalled wave is half of the SIMD's multiplier idle.  The NEXT entry is known an addition ahead:
-    // one word of each of its lines is loaded now and consumed (folded into `touch`) at the top of the next iteration - by then
-    // it has long arrived, and the real loads of that point hit the cache.  Only inside a bucket (the next bucket may belong to
-    // another job, i.e. another table).
-    touch ^= t0 ^ t1;
-    if (k + 1 < bend && k + 1 < pos1) {
-      const AffPacked* pn = (dense ? bp.p[0] : base_of<NJ>(bp, b >> bshift)) + (e_next & 0x7fffffffu);
-      t0 = pn->x[0]; t1 = pn->y[23];
-    }
-#endif
     bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_digit_pass drops them)
     if (dense && p->x[23] == ZK_AFF_INF_WORD) continue;        // a pair of the levels below cancelled
     if (inf) {
 #pragma unroll
       for (int i = 0; i < 24; i++) xs[i * ZK_LDS_STRIDE] = p->x[i];       // packed words straight into LDS
-#if ZK_ACC_REGY
       ty = aff_ld_y(p, neg);
-#else
-      mem_st(acc, CY, aff_ld_y(p, neg));
-#endif
       lds_st(zz, fp_one<FqParams>());
       lds_st(zzz, fp_one<FqParams>());
       inf = false;
       continue;
     }
-#if ZK_ACC_REGY
     if (madd_lds_regy(acc, xs, zz, zzz, ty, p, neg)) inf = fp_is_zero_2p(lds_ld(zz));   // same-x path may have cancelled to infinity
-#else
-    if (madd_mem_lds(acc, xs, zz, zzz, p, neg)) inf = fp_is_zero_2p(lds_ld(zz));   // same-x path may have cancelled to infinity
-#endif
   }
   if (!inf) {
     mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));
-#if ZK_ACC_REGY
     mem_st(acc, CY, ty);
-#endif
   }
   // a run that cancelled to infinity leaves ZZ = 0 in its slot: madd_same_x wrote the zeros, or the slot
   // was never written (zero-filled array)
-#if ZK_ACC_TOUCH
-  if ((touch ^ t0 ^ t1) == 0x9e3779b9u && t == 0xffffffffu) fix_cnt[0] = touch;      // (never true: keeps the touching loads alive)
-#endif
 }
 
 // ---- batched-affine levels ------------------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 #include <pthread.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/zkhip.h"
@@ -221,6 +222,10 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
   p->vk_words = 60 + 12 * (k + 1); p->proofs_words = 48 * np; p->inputs_words = 6 * k * np;
   p->max_unfinished = (size_t)4 * (size_t)(gpu_slots + witness_workers);
   p->gpu_witness = (flags & ZKHIP_PIPELINE_GPU_WITNESS) != 0;
+  if (const char* e = getenv("ZKHIP_WIT_BATCH")) {            // witnesses per launch of the GPU generator (tuning knob)
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) p->wit_batch = (size_t)v;
+  }
   p->device = zkhip_crs_device(crs);
   if (p->gpu_witness) {
     if (witness_workers > 4) witness_workers = 4;     // batcher threads: each keeps one launch of wit_batch witnesses in flight
