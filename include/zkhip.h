@@ -113,9 +113,10 @@ int zkhip_device_alloc(size_t bytes, void** out);
 int zkhip_device_free(void* p);
 int zkhip_device_copy_in(void* dst, const void* src, size_t bytes);
 
-/* Asynchronous form of zkhip_msm_dev for a stream of MSMs on resident bases: submit enqueues the MSM on one of four
- * slots and returns, collect waits for it.  d_scalars must stay valid until collect.  With two slots in flight the
- * latency-bound bucket reduction of one MSM overlaps the accumulation of the next. */
+/* Asynchronous form of zkhip_msm_dev for a stream of MSMs on resident bases: submit enqueues the MSM on one of EIGHT
+ * slots (0 .. 7) and returns, collect waits for it.  d_scalars must stay valid until collect.  With several slots in flight the
+ * sort, the stitching and the latency-bound bucket reduction of one MSM run under the accumulation of another (measured at
+ * 2^20 terms: 75 / 77 / 80 Mscalar/s with 2 / 3 / 4 in flight); each slot holds its own work space (1.3 GB at 2^20 terms). */
 int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery, int slot);
 int zkhip_msm_collect(int slot, uint64_t out_jac[36]);
 /* one-shot form (BASELINE config 2): host bases + host scalars */

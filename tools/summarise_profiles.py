@@ -29,7 +29,7 @@ solo, over = _stats(os.path.join(SRC, "msm_serial_trace", "msm_kernel_stats.csv"
 if solo and over:
     with open(os.path.join(DST, f"{tag}_msm_solo_vs_stream.csv"), "w") as f:
         f.write("# per kernel of one 2^20-term G1 MSM: average duration (us) with ONE MSM at a time (bench.py --serial) and inside the stream of the\n")
-        f.write("# driver's command (bench.py --gpus 1 --steps 20 --warmup 5, two MSMs in flight: launches of different MSMs overlap in time)\n")
+        f.write("# driver's command (bench.py --gpus 1 --steps 20 --warmup 5, eight MSMs in flight: launches of different MSMs overlap in time)\n")
         f.write("kernel,calls_per_msm,solo_avg_us,solo_min_us,stream_avg_us,stream_min_us\n")
         n_solo = max(1, solo.get("zkhip::k_accumulate<1>", (1, 0, 0))[0])
         for k, (c, a, m) in sorted(solo.items(), key=lambda kv: -kv[1][0] * kv[1][1]):

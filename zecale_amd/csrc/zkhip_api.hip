@@ -51,9 +51,12 @@ namespace {
 // Everything one proof in flight needs on the device: a stream for the QAP map, the witness buffer, five MSM contexts
 // (the prover keeps 2 (large) or 5 (small circuits) MSMs in flight).  The library owns one (the plain entry points,
 // serialised by g.mu); every zkhip_prover owns another, so several host threads can keep several proofs in flight.
+constexpr int ZK_MSM_SLOTS = 8;
 struct ProveState {
-  MsmCtx ctx[5];
-  bool ready[5] = {false, false, false, false, false};
+  // MSM contexts: [0, ZK_MSM_SLOTS) the slots of zkhip_msm_submit / collect (the first five also serve a proof whose five MSMs run as
+  // separate launch sequences), [ZK_MSM_SLOTS] the context of a proof's five MSMs in ONE launch sequence
+  MsmCtx ctx[ZK_MSM_SLOTS + 1];
+  bool ready[ZK_MSM_SLOTS + 1] = {};
   hipStream_t st = nullptr;
   hipEvent_t ev_st = nullptr;      // blocking-sync event for waits on st (the waiting host thread sleeps)
   uint64_t* dz = nullptr;
@@ -64,7 +67,7 @@ struct ProveState {
   int last_submit_slot = -1;       // zkhip_msm_submit: the slot of the previous submission (its accumulation gates the next one's)
   uint32_t quad_below = 0;         // 0: the engine's default; else the MSM contexts' quad_below (zkhip_prover_set_streaming)
   void release() {
-    for (int k = 0; k < 5; k++) if (ready[k]) { msm_plan_free(&ctx[k]); ready[k] = false; }
+    for (int k = 0; k <= ZK_MSM_SLOTS; k++) if (ready[k]) { msm_plan_free(&ctx[k]); ready[k] = false; }
     if (st) { (void)hipStreamDestroy(st); st = nullptr; }
     if (ev_st) { (void)hipEventDestroy(ev_st); ev_st = nullptr; }
     if (dz) { (void)hipFree(dz); dz = nullptr; dz_cap = 0; }
@@ -93,7 +96,7 @@ struct Lib {
 } g;
 thread_local char t_err[512] = {0};   // zkhip_last_error(): the calling thread's last failure
 thread_local int t_dev = -1;          // this thread's library device (-1: the default device); changed by zkhip_init / zkhip_set_device ONLY
-thread_local int t_slot_dev[4] = {-1, -1, -1, -1};   // device of this thread's last zkhip_msm_submit per slot (zkhip_msm_collect has no handle)
+thread_local int t_slot_dev[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // device of this thread's last zkhip_msm_submit per slot (zkhip_msm_collect has no handle)
 thread_local int t_prove_dev = -1;    // device of this thread's last MSM or proof through a handle (zkhip_last_prove_timings / _accumulate_ms)
 
 int fail(int code, const char* msg) {
@@ -372,7 +375,7 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
 // the latency-bound bucket reduction of one with the accumulation of the other (what the prover does between its own MSMs).
 int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery, int slot) {
   if (!bases || (len && !d_scalars)) return fail(ZKHIP_ERR_ARG, "null pointer");
-  if (slot < 0 || slot > 3) return fail(ZKHIP_ERR_ARG, "slot must be in [0, 3]");
+  if (slot < 0 || slot >= ZK_MSM_SLOTS) return fail(ZKHIP_ERR_ARG, "slot must be in [0, 7]");
   BIND(bases);
   ProveState& ps = g.dev[bases->device].ps;
   std::lock_guard<std::mutex> lk(g.dev[bases->device].mu);
@@ -398,7 +401,7 @@ int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scal
 }
 
 int zkhip_msm_collect(int slot, uint64_t out_jac[36]) {
-  if (slot < 0 || slot > 3 || !out_jac) return fail(ZKHIP_ERR_ARG, "bad slot or null pointer");
+  if (slot < 0 || slot >= ZK_MSM_SLOTS || !out_jac) return fail(ZKHIP_ERR_ARG, "bad slot or null pointer");
   const int dev = t_slot_dev[slot] >= 0 ? t_slot_dev[slot] : cur_dev();     // the device this thread submitted the slot on
   { int rc_ = bind_dev(dev); if (rc_ != ZKHIP_OK) return rc_; }
   ProveState& ps = g.dev[dev].ps;
@@ -679,13 +682,13 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     // table-backed key: the five MSMs share ONE launch sequence (one sort, one accumulation launch over all five entry
     // lists, one reduction chain with a bucket window per MSM) - a fifth of the launches, five times the lanes in each.
     // (A plan that does not fit the engine's 32-bit entry positions is refused with ZKHIP_ERR_ARG: one sequence per MSM then.)
-    rc = ensure_ctx(&ps.ctx[4], &ps.ready[4], maxlen, tc, 5, crs->A->table_naf);
-    if (rc == ZKHIP_OK && ps.quad_below) { ps.ctx[4].quad_below = ps.quad_below; ps.ctx[4].one_stream = 1; }
+    rc = ensure_ctx(&ps.ctx[ZK_MSM_SLOTS], &ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf);
+    if (rc == ZKHIP_OK && ps.quad_below) { ps.ctx[ZK_MSM_SLOTS].quad_below = ps.quad_below; ps.ctx[ZK_MSM_SLOTS].one_stream = 1; }
     if (rc == ZKHIP_ERR_ARG) batched = false;
     else if (rc != ZKHIP_OK) return rc;
   }
   if (batched) {
-    MsmCtx* cx = &ps.ctx[4];
+    MsmCtx* cx = &ps.ctx[ZK_MSM_SLOTS];
     MsmJob mj[5];
     for (int j = 0; j < 5; j++)
       mj[j] = MsmJob{jobs[j].b->d_pts, jobs[j].b->d_inf, jobs[j].sc, jobs[j].len, jobs[j].mode, jobs[j].b->len,
@@ -879,7 +882,7 @@ int zkhip_prover_set_streaming(zkhip_prover* p, int on) {
   // measured on the wrapping circuit: 212 -> 228 proofs/s with six provers in flight, 107 -> 98 one at a time
   p->ps.quad_below = on ? 1024u : 0u;
   p->rd->spmv_log_lanes = on ? 2 : 4;
-  for (int k = 0; k < 5; k++) if (p->ps.ready[k]) { p->ps.ctx[k].quad_below = on ? 1024u : 65536u; p->ps.ctx[k].one_stream = on ? 1 : 0; }
+  for (int k = 0; k <= ZK_MSM_SLOTS; k++) if (p->ps.ready[k]) { p->ps.ctx[k].quad_below = on ? 1024u : 65536u; p->ps.ctx[k].one_stream = on ? 1 : 0; }
   return ZKHIP_OK;
 }
 

@@ -244,7 +244,7 @@ class Bases:
         return out
 
     def msm_submit(self, dev_ptr, n, slot, offset=0, montgomery=True):
-        """Enqueue an MSM on `slot` (0..3) and return; msm_collect(slot) waits for the result."""
+        """Enqueue an MSM on `slot` (0..7) and return; msm_collect(slot) waits for the result."""
         _check(load().zkhip_msm_submit(self.handle, offset, ctypes.c_void_p(dev_ptr), n, int(montgomery), slot))
 
     def msm_dev(self, dev_ptr, n, offset=0, montgomery=True):
