@@ -19,7 +19,7 @@ rep = {
     "NUM_MSM_STREAM": "%.1f" % d["value"], "NUM_MSM_STEP": "%.2f" % d["ms_per_step"],
     "NUM_MSM_SERIAL_MS": "%.1f" % serial_line["ms_per_step"], "NUM_MSM_SERIAL": "%.1f" % serial_line["value"],
     "NUM_ACC_ALONE": "%.2f" % rf["kernel_ms_alone"], "NUM_ACC_STREAM": "%.2f" % rf["kernel_ms"],
-    "NUM_FRAC_ALONE": "%.2f" % rf["fq_mul_frac_alone"], "NUM_FRAC_STREAM": "%.2f" % rf["fq_mul_frac"],
+    "NUM_FRAC_ALONE": "%.2f" % rf["fq_mul_frac_alone"], "NUM_FRAC_STREAM": "%.2f" % rf["fq_mul_frac"], "NUM_FRAC_STEP": "%.2f" % rf["fq_mul_frac_whole_step"],
     "NUM_HBM_FRAC": "%.2f %%" % (100 * rf["frac"]), "NUM_HBM_GBS": "%.1f" % rf["achieved"],
     "NUM_TRAFFIC_X": "%.0f" % (traffic / 251658240.0), "NUM_TRAFFIC": "%.1f" % (traffic / 1e9),
     "NUM_PLAIN": "%.1f" % d["plain_path"]["value"],
