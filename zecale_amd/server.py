@@ -224,7 +224,7 @@ class GpuProver:
     """The wrapping prover behind the service: circuit, keypair (file or fresh setup), HBM-resident key, streaming pipeline."""
     snark_name = "GROTH16"
 
-    def __init__(self, keypair_file=None, device=0, gpu_slots=14, witness_workers=8, gpu_witness=False):
+    def __init__(self, keypair_file=None, device=0, gpu_slots=24, witness_workers=10, gpu_witness=False):
         from . import zkhip
         self.zk = zkhip
         self.gpu_slots = gpu_slots
