@@ -251,7 +251,7 @@ def test_table_full_size_2_20_matches_plain_path(zk):
 
 
 @pytest.mark.usefixtures("table_kind")
-def test_submit_collect_two_in_flight(zk, oracle_lib):
+def test_submit_collect_slots_in_flight(zk, oracle_lib):
     """zkhip_msm_submit / zkhip_msm_collect: two MSMs in flight on two slots return what the blocking call returns;
     a busy slot refuses a second submit, an idle slot has nothing to collect."""
     O = oracle_lib
@@ -271,6 +271,16 @@ def test_submit_collect_two_in_flight(zk, oracle_lib):
     assert (zk.jac_to_affine(zk.msm_collect(0)) == exp[2]).all()
     with pytest.raises(zk.ZkhipError):
         zk.msm_collect(0)
+    # all eight slots in flight at once (the depth bench.py streams with), collected in submission order; the accumulation
+    # launches' intervals on the device's time base are well-formed and as long as the reported duration
+    for k in range(8):
+        b.msm_submit(dev[k % 3].ptr, n, slot=k)
+    with pytest.raises(zk.ZkhipError):
+        b.msm_submit(dev[0].ptr, n, slot=8)
+    for k in range(8):
+        assert (zk.jac_to_affine(zk.msm_collect(k)) == exp[k % 3]).all()
+        t0, t1 = zk.last_accumulate_interval()
+        assert t1 > t0 > 0 and abs((t1 - t0) - zk.last_accumulate_ms()) < 0.05
     for d in dev:
         d.free()
     b.free()
