@@ -1182,7 +1182,8 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   // windows get smaller parts so that k_bucket_sort still has about a thousand workgroups to spread over the chip
   {
     uint32_t LB = (uint32_t)(c - 1 < 10 ? c - 1 : 10);
-    while (LB > 6 && (nb >> LB) < 1024 && (ctx->B >> (LB - 1)) * (merged ? 1 : (size_t)ctx->Wd) <= 4096) LB--;
+    const size_t want_parts = (size_t)env_int("ZKHIP_SORT_PARTS", 1024, 64, 8192);      // (tuning knob)
+    while (LB > 6 && (nb >> LB) < want_parts && (ctx->B >> (LB - 1)) * (merged ? 1 : (size_t)ctx->Wd) <= 4096) LB--;
     ctx->sort_LB = LB;
     ctx->sort_NP = (uint32_t)(ctx->B >> LB);
     ctx->sort_bins = merged ? ctx->sort_NP : ctx->sort_NP * (uint32_t)ctx->Wd;
