@@ -119,7 +119,7 @@ __device__ __forceinline__ void scalar_words(const uint64_t* __restrict__ scalar
 // PASS 0: count.  PASS 1: place.  NAF: scalars recoded in width-(c+1) non-adjacent form (merged == 2 plans).
 // Dynamic LDS: cnt[bins] (+ base[bins] in pass 1).
 template <int PASS, bool NAF>
-__global__ void __launch_bounds__(256) k_digit_pass(DigitJobs jobs, int c, int W, WindowPlan plan, int merged, uint32_t B_per_job, SortGeom ge,
+__global__ void __launch_bounds__(256) k_digit_pass(DigitJobs jobs, int c, int W, WindowPlan plan, int merged, SortGeom ge,
                                                      uint32_t* __restrict__ hist, uint2* __restrict__ pairs) {
   extern __shared__ uint32_t sh_dyn[];
   __shared__ uint32_t s_w[NAF ? 13 : 1][256];
@@ -131,7 +131,6 @@ __global__ void __launch_bounds__(256) k_digit_pass(DigitJobs jobs, int c, int W
   const uint8_t* __restrict__ inf_flags = jobs.inf_flags[job];
   const int mode = jobs.mode[job];
   const size_t tab_stride = jobs.tab_stride[job];
-  const uint32_t B = 1u << (c - 1);
   const uint32_t g0 = merged ? job * ge.NP : 0u;                 // first part this block can hit
   const uint32_t lb_mask = (1u << ge.LB) - 1u;
   for (uint32_t j = tid; j < ge.bins; j += 256) {
@@ -239,7 +238,6 @@ __global__ void __launch_bounds__(256) k_digit_pass(DigitJobs jobs, int c, int W
       }
     }
   }
-  (void)B; (void)B_per_job;
   if (PASS == 0) {
     __syncthreads();
     for (uint32_t j = tid; j < ge.bins; j += 256) hist[(size_t)(g0 + j) * ge.nbx + bx] = s_cnt[j];
@@ -1344,14 +1342,14 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   for (int k = K; k < KK; k++) dj.n[k] = 0;
   const dim3 dgrid(ge.nbx, KK);
   const size_t lds0 = (size_t)ge.bins * 4, lds1 = (size_t)ge.bins * 8;
-  if (merged == 2) hipLaunchKernelGGL((k_digit_pass<0, true>), dgrid, dim3(256), lds0, st, dj, c, Wd, plan, merged, (uint32_t)B, ge, ctx->hist, ctx->pairs);
-  else hipLaunchKernelGGL((k_digit_pass<0, false>), dgrid, dim3(256), lds0, st, dj, c, Wd, plan, merged, (uint32_t)B, ge, ctx->hist, ctx->pairs);
+  if (merged == 2) hipLaunchKernelGGL((k_digit_pass<0, true>), dgrid, dim3(256), lds0, st, dj, c, Wd, plan, merged, ge, ctx->hist, ctx->pairs);
+  else hipLaunchKernelGGL((k_digit_pass<0, false>), dgrid, dim3(256), lds0, st, dj, c, Wd, plan, merged, ge, ctx->hist, ctx->pairs);
   unsigned sb = nblk(hist_m, 1024);
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(256), 0, st, ctx->hist, ctx->hist, ctx->block_tot, hist_m);
   hipLaunchKernelGGL(k_scan_tot, dim3(1), dim3(1024), 0, st, ctx->block_tot, (size_t)sb);
   hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, ctx->hist, ctx->block_tot, hist_m);
-  if (merged == 2) hipLaunchKernelGGL((k_digit_pass<1, true>), dgrid, dim3(256), lds1, st, dj, c, Wd, plan, merged, (uint32_t)B, ge, ctx->hist, ctx->pairs);
-  else hipLaunchKernelGGL((k_digit_pass<1, false>), dgrid, dim3(256), lds1, st, dj, c, Wd, plan, merged, (uint32_t)B, ge, ctx->hist, ctx->pairs);
+  if (merged == 2) hipLaunchKernelGGL((k_digit_pass<1, true>), dgrid, dim3(256), lds1, st, dj, c, Wd, plan, merged, ge, ctx->hist, ctx->pairs);
+  else hipLaunchKernelGGL((k_digit_pass<1, false>), dgrid, dim3(256), lds1, st, dj, c, Wd, plan, merged, ge, ctx->hist, ctx->pairs);
   hipLaunchKernelGGL(k_bucket_sort, dim3(ge.nparts), dim3(512), 0, st, ctx->hist, ge, ctx->pairs, ctx->entries, ctx->offsets, ctx->counts);
   sb = nblk(nb, 1024);                                            // (the batched-affine levels below scan arrays of nb counters)
   BasePtrs bp;
