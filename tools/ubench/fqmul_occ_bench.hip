@@ -3,7 +3,7 @@
 // block = two waves per SIMD).  Reported: wave-mads per second chip-wide.  Result (profiles/r03_ubench_multiplier.txt): the fp_mul / fp_sqr
 // chains reach 473-485 G wave-mads/s from two waves per SIMD on (370-390 with one) - MORE than tools/ubench/valu_rates.hip saw with eight
 // independent mads per wave (415 / 448 G/s at 2 / 4 waves), so this, not that, is the pipe's peak: 476 G wave-mads/s = 20.9 G Fq-mul/s;
-// the dual product fp_mul2 runs at 390-400 (its split of the column sum costs feeding).
+// the dual product fp_mul2 runs at 427-431 (the split of its long columns costs feeding).
 #include "../../zecale_amd/csrc/fp29.cuh"
 #include <cstdio>
 #include <cstdlib>

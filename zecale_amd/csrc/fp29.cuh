@@ -117,7 +117,8 @@ ZK_HD ZK_MULATTR Fp<PR> fp_sqr(Fp<PR> a) {
 // (The y coordinate of every addition formula has this shape: Y3 = R (Q - X3) - Y1 PPP.)  A column now holds up to 2 * NL products
 // of < 2^58 plus NL reduction terms: 3 * 27 * 2^58 > 2^64.  So the products of a column are summed on their own (< 2^64: at most 26 pairs
 // of full 29-bit limbs per product - a pair that involves a top limb is small), their upper part goes straight to the next
-// column's carry, and only their low 29 bits meet the reduction terms: three more shift / add operations per column.
+// column's carry, and only their low 29 bits meet the reduction terms: three more shift / add operations per column - in the 11 long
+// columns of the middle only; the 42 columns of at most 21 terms per operand pair fit one accumulator as in fp_mul.
 // Requires normalised limbs and a*b + c*d < 2^10 R p; result < (a*b + c*d)/R + p.
 template <class PR>
 ZK_HD ZK_MULATTR Fp<PR> fp_mul2(Fp<PR> a, Fp<PR> b, Fp<PR> c, Fp<PR> d) {
@@ -127,30 +128,60 @@ ZK_HD ZK_MULATTR Fp<PR> fp_mul2(Fp<PR> a, Fp<PR> b, Fp<PR> c, Fp<PR> d) {
   uint64_t carry = 0;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    uint64_t t = 0;
+    if (3 * (k + 1) <= 63) {
+      // a short column: 3 (k + 1) terms of < 2^58 and the carry fit one accumulator, as in fp_mul
+      uint64_t acc = carry;
 #pragma unroll
-    for (int i = 0; i <= k; i++) t += (uint64_t)a.l[i] * b.l[k - i];
+      for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = 0; i <= k; i++) t += (uint64_t)c.l[i] * d.l[k - i];
-    uint64_t acc = ((uint32_t)t & M29) + carry;
+      for (int i = 0; i <= k; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
 #pragma unroll
-    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * PR::P[k - i];
-    m[k] = ((uint32_t)acc * PR::PINV) & M29;
-    acc += (uint64_t)m[k] * PR::P[0];
-    carry = (acc >> 29) + (t >> 29);
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * PR::P[k - i];
+      m[k] = ((uint32_t)acc * PR::PINV) & M29;
+      acc += (uint64_t)m[k] * PR::P[0];
+      carry = acc >> 29;
+    } else {
+      uint64_t t = 0;
+#pragma unroll
+      for (int i = 0; i <= k; i++) t += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+      for (int i = 0; i <= k; i++) t += (uint64_t)c.l[i] * d.l[k - i];
+      // (the reduction terms do not depend on this column's products: their chain starts from the carry and runs beside the chain
+      //  of the products - two independent accumulators for the scheduler to interleave)
+      uint64_t acc = carry;
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * PR::P[k - i];
+      acc += (uint32_t)t & M29;
+      m[k] = ((uint32_t)acc * PR::PINV) & M29;
+      acc += (uint64_t)m[k] * PR::P[0];
+      carry = (acc >> 29) + (t >> 29);
+    }
   }
 #pragma unroll
   for (int k = N; k < 2 * N - 1; k++) {
-    uint64_t t = 0;
+    if (3 * (2 * N - 1 - k) <= 63) {
+      uint64_t acc = carry;
 #pragma unroll
-    for (int i = k - N + 1; i < N; i++) t += (uint64_t)a.l[i] * b.l[k - i];
+      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = k - N + 1; i < N; i++) t += (uint64_t)c.l[i] * d.l[k - i];
-    uint64_t acc = ((uint32_t)t & M29) + carry;
+      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
 #pragma unroll
-    for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * PR::P[k - i];
-    r.l[k - N] = (uint32_t)acc & M29;
-    carry = (acc >> 29) + (t >> 29);
+      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * PR::P[k - i];
+      r.l[k - N] = (uint32_t)acc & M29;
+      carry = acc >> 29;
+    } else {
+      uint64_t t = 0;
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) t += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) t += (uint64_t)c.l[i] * d.l[k - i];
+      uint64_t acc = carry;
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * PR::P[k - i];
+      acc += (uint32_t)t & M29;
+      r.l[k - N] = (uint32_t)acc & M29;
+      carry = (acc >> 29) + (t >> 29);
+    }
   }
   r.l[N - 1] = (uint32_t)carry;
   return r;
