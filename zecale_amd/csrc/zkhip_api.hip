@@ -385,9 +385,9 @@ int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scal
   int rc = ensure_ctx(cx, &ps.ready[slot], len ? len : 1, bases->table_c, 1, bases->table_naf);
   if (rc != ZKHIP_OK) return rc;
   // a stream of MSMs, optionally GATED (ZKHIP_MSM_GATE=1): the accumulation of this one waits for the end of the accumulation
-  // submitted before it on another slot, so that two accumulations never share the chip.  Measured (tools/gate_ab.sh, 2^20 terms):
-  // 75.0 Mscalar/s gated against 76.9 free-running - the free overlap fills the tail of one accumulation with the head of the
-  // next - so the default is off; the gate gives event-timed kernel durations that are per-launch costs.
+  // submitted before it on another slot, so that two accumulations never share the chip.  Measured (tools/gate_ab.sh, 2^20 terms,
+  // eight in flight): 79.6 Mscalar/s gated against 83.7 free-running - the free overlap fills the tail of one accumulation with the
+  // head of the next - so the default is off; the gate gives event-timed kernel durations that are per-launch costs.
   static const bool gate = getenv("ZKHIP_MSM_GATE") ? atoi(getenv("ZKHIP_MSM_GATE")) != 0 : false;
   const int prev = ps.last_submit_slot;
   cx->acc_gate = (gate && prev >= 0 && prev != slot && ps.ready[prev]) ? ps.ctx[prev].ev_acc1 : nullptr;
