@@ -1433,9 +1433,11 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     const uint32_t per = fold_quads ? 64u : 256u;
     uint32_t sblocks = nblk((size_t)T_run / 2 + 1, per);
     if (sblocks > 1024) sblocks = 1024;                                        // (the list is walked with a grid stride)
-    if (fold_quads) hipLaunchKernelGGL(k_fixup_fold<true>, dim3(sblocks + 128), dim3(256), 0, st, ctx->block_tot, ctx->fix_short, ctx->fix_list, sblocks,
+    // + 512 workgroups for the long list: a wrapping proof has ~290 buckets of 7-8 pieces (values that occur a couple of hundred
+    // times in the assignment, in every window): with 128 workgroups they took three sweeps of three rounds each
+    if (fold_quads) hipLaunchKernelGGL(k_fixup_fold<true>, dim3(sblocks + 512), dim3(256), 0, st, ctx->block_tot, ctx->fix_short, ctx->fix_list, sblocks,
                                        (uint32_t)nb, ctx->buckets, ctx->slot_stride);
-    else hipLaunchKernelGGL(k_fixup_fold<false>, dim3(sblocks + 128), dim3(256), 0, st, ctx->block_tot, ctx->fix_short, ctx->fix_list, sblocks,
+    else hipLaunchKernelGGL(k_fixup_fold<false>, dim3(sblocks + 512), dim3(256), 0, st, ctx->block_tot, ctx->fix_short, ctx->fix_list, sblocks,
                             (uint32_t)nb, ctx->buckets, ctx->slot_stride);
   }
   hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, tight, T_run,
@@ -1506,6 +1508,8 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   LevelShifts ls;
   memset(&ls, 0, sizeof ls);
   size_t r_off = 0;                  // this level's R array starts here inside segR (in points)
+  // (fan-in 2 in this recursion was measured and lost: 8 levels instead of 4 halve the chain of dependent point operations on paper,
+  //  but every level brings its own k_seg launch, R-sum tree and cross-stream hand-over: one wrapping proof's MSM phase 5.7 -> 6.6 ms)
   while (n_cur > (size_t)G) {
     int L = ctx->L;
     while ((size_t)L > n_cur / G) L >>= 1;      // last level: fewer items per group than L
