@@ -84,6 +84,7 @@ class keypair {                            // wsnarkT::keypair: pk (HBM-resident
   keypair& operator=(const keypair&) = delete;
   ~keypair() { zkhip_crs_free(crs_); zkhip_keypair_free(kp_); }
   const zkhip_crs* pk() const { return crs_; }
+  const zkhip_keypair* host() const { return kp_; }      // the key in host memory (what a multi-GPU stream uploads to every GPU)
   // vk: alpha (G1), beta, delta (G2), ABC; `vk_abc_size() == num_primary_inputs() + 1` is the server's sanity check (aggregator_server.cpp:490)
   size_t vk_abc_size() const { uint64_t a[24], b[24], d[24]; const uint64_t* abc; return zkhip_keypair_vk(kp_, a, b, d, &abc); }
   // wsnarkT::verification_key_write_json (aggregator_server.cpp:185,223): the shape of testdata/dummy_app/aggregator_vk.json
@@ -180,6 +181,57 @@ class aggregator_circuit {
   // witness_on_gpu: the assignments are generated by a device kernel (zkhip_gpu_witness_*): fewer host cores, a deeper stream
   std::unique_ptr<stream> open_stream(const keypair& kp, int gpu_slots = 14, int witness_workers = 8, bool witness_on_gpu = false) {
     return std::unique_ptr<stream>(new stream(*this, kp, gpu_slots, witness_workers, witness_on_gpu));
+  }
+
+  // The same stream over EVERY GPU of a node (zkhip_dispatcher_*): a resident copy of the key and a pipeline per entry of `devices`
+  // (an index may repeat), each batch goes to the entry with the fewest batches outstanding.  One process, as the reference server
+  // is (aggregator_server.cpp:106-118, 390-416); whole proofs are independent, so there is no exchange between the GPUs.
+  class node_stream {
+   public:
+    node_stream(aggregator_circuit& c, const keypair& kp, const std::vector<int>& devices, int gpu_slots, int witness_workers,
+                bool witness_on_gpu = false, const zkhip_key_opts* opts = nullptr) : c_(c) {
+      zkhip_crs_desc d;
+      zk_check(zkhip_keypair_crs_desc(kp.host(), &d), "zkhip_keypair_crs_desc");
+      zk_check(zkhip_dispatcher_new(c.agg_, &d, opts, devices.data(), (int)devices.size(), gpu_slots, witness_workers,
+                                    witness_on_gpu ? ZKHIP_PIPELINE_GPU_WITNESS : 0u, &d_), "zkhip_dispatcher_new");
+    }
+    node_stream(const node_stream&) = delete;
+    node_stream& operator=(const node_stream&) = delete;
+    ~node_stream() { zkhip_dispatcher_free(d_); }
+    uint64_t submit(const nested_verification_key& nested_vk, const std::array<const nested_extended_proof*, NumProofs>& nested_proofs) {
+      std::vector<uint64_t> vk, proofs, inputs;
+      c_.flatten(nested_vk, nested_proofs, vk, proofs, inputs);
+      uint64_t r[6], s[6], ticket = 0;
+      random_scalars(r, s);
+      zk_check(zkhip_dispatcher_submit(d_, vk.data(), proofs.data(), inputs.data(), r, s, &ticket), "zkhip_dispatcher_submit");
+      return ticket;
+    }
+    extended_proof wait(uint64_t ticket) {
+      const size_t np = c_.num_primary_inputs();
+      std::vector<uint64_t> prim(np * 6);
+      uint64_t out[72];
+      zk_check(zkhip_dispatcher_wait(d_, ticket, prim.data(), out), "zkhip_dispatcher_wait");
+      extended_proof ep;
+      std::memcpy(ep.proof.a.data(), out, 192); std::memcpy(ep.proof.b.data(), out + 24, 192); std::memcpy(ep.proof.c.data(), out + 48, 192);
+      for (size_t i = 0; i < np; i++) {
+        std::array<uint64_t, 6> x;
+        std::memcpy(x.data(), &prim[i * 6], 48);
+        ep.primary_inputs.push_back(x);
+      }
+      return ep;
+    }
+    std::vector<size_t> batches_per_device() const {          // how many batches each entry of the device list has been given
+      std::vector<size_t> v((size_t)zkhip_dispatcher_size(d_));
+      zk_check(zkhip_dispatcher_stats(d_, v.data()), "zkhip_dispatcher_stats");
+      return v;
+    }
+   private:
+    aggregator_circuit& c_;
+    zkhip_dispatcher* d_ = nullptr;
+  };
+  std::unique_ptr<node_stream> open_node_stream(const keypair& kp, const std::vector<int>& devices, int gpu_slots = 14, int witness_workers = 8,
+                                           bool witness_on_gpu = false, const zkhip_key_opts* opts = nullptr) {
+    return std::unique_ptr<node_stream>(new node_stream(*this, kp, devices, gpu_slots, witness_workers, witness_on_gpu, opts));
   }
 
   // Non-const like the reference (it fills its protoboard); not re-entrant.

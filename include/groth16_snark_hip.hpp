@@ -52,9 +52,21 @@ class hip_proving_key {
     if (rc != ZKHIP_OK) { zkhip_r1cs_free(r1cs_); zk_check(rc, "zkhip_crs_upload_ex"); }
     n_vars_ = cs.n_vars;
   }
+  // The key PARTITIONED over the GPUs of a node (zkhip_multi_prover: a contiguous slice of every query vector and a prover instance
+  // per entry of `devices`, partial sums added on the host, one tail; BASELINE configs[3]).  An index may repeat: {0, 0} is two
+  // contexts on GPU 0.  The reference is one process that owns its prover (aggregator_server.cpp:106-118, 390-416): so is this.
+  hip_proving_key(const zkhip_crs_desc& crs, const zkhip_r1cs_desc& cs, const std::vector<int>& devices, const zkhip_key_opts* opts = nullptr) {
+    if (devices.empty()) throw std::runtime_error("hip_proving_key: empty device list");
+    zk_check(zkhip_multi_prover_new(&crs, &cs, opts, devices.data(), (int)devices.size(), &multi_), "zkhip_multi_prover_new");
+    int rc = zkhip_set_device(devices[0]);                       // (is_satisfied runs on the first GPU of the list)
+    if (rc == ZKHIP_OK) rc = zkhip_r1cs_upload(&cs, &r1cs_);
+    if (rc != ZKHIP_OK) { zkhip_multi_prover_free(multi_); zk_check(rc, "zkhip_r1cs_upload"); }
+    n_vars_ = cs.n_vars;
+  }
   hip_proving_key(const hip_proving_key&) = delete;
   hip_proving_key& operator=(const hip_proving_key&) = delete;
-  ~hip_proving_key() { zkhip_crs_free(crs_); zkhip_r1cs_free(r1cs_); }
+  ~hip_proving_key() { zkhip_multi_prover_free(multi_); zkhip_crs_free(crs_); zkhip_r1cs_free(r1cs_); }
+  size_t num_devices() const { return multi_ ? (size_t)zkhip_multi_prover_size(multi_) : 1; }
 
   size_t num_variables() const { return n_vars_; }
   unsigned log_domain_size() const { return zkhip_r1cs_log_domain(r1cs_); }
@@ -68,7 +80,8 @@ class hip_proving_key {
   // r, s: the prover's randomisers (6 limbs each); libsnark draws them with Fr::random_element().
   groth16_proof generate_proof(const uint64_t* z, const uint64_t r[6], const uint64_t s[6]) const {
     uint64_t out[72];
-    zk_check(zkhip_groth16_prove(crs_, r1cs_, z, r, s, out), "zkhip_groth16_prove");
+    if (multi_) zk_check(zkhip_multi_prover_prove(multi_, z, r, s, out), "zkhip_multi_prover_prove");
+    else zk_check(zkhip_groth16_prove(crs_, r1cs_, z, r, s, out), "zkhip_groth16_prove");
     groth16_proof p;
     std::memcpy(p.a.data(), out, 192);
     std::memcpy(p.b.data(), out + 24, 192);
@@ -79,6 +92,7 @@ class hip_proving_key {
  private:
   zkhip_crs* crs_ = nullptr;
   zkhip_r1cs* r1cs_ = nullptr;
+  zkhip_multi_prover* multi_ = nullptr;     // set: the key lives in slices on several GPUs / contexts, crs_ stays null
   size_t n_vars_ = 0;
 };
 

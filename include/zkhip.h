@@ -119,6 +119,25 @@ int zkhip_device_copy_in(void* dst, const void* src, size_t bytes);
  * 2^20 terms: 75 / 77 / 80 Mscalar/s with 2 / 3 / 4 in flight); each slot holds its own work space (1.3 GB at 2^20 terms). */
 int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery, int slot);
 int zkhip_msm_collect(int slot, uint64_t out_jac[36]);
+/* The same stream of MSMs behind a HANDLE (the slot numbers above are process-wide: two threads streaming on one GPU collide).
+ * A zkhip_msm_stream owns `depth` (1 .. 16) MSM contexts - streams and work space, like a zkhip_prover - on the GPU of its base
+ * set; any number of streams run side by side.  submit enqueues on a free context and returns a ticket (ZKHIP_ERR_STATE when all
+ * `depth` are in flight); collect waits for that ticket (0 = the oldest in flight).  replaces: one libff::multi_exp call
+ * (reached from aggregator_circuit.tcc:168) per ticket.  d_scalars must stay valid until its ticket is collected.
+ * submit_host takes HOST scalars (as libff holds them): one asynchronous copy in front of the MSM's kernels on the context's own
+ * stream - truly asynchronous from pinned memory (zkhip_host_alloc), staged by the runtime from pageable memory - so the 48 MB
+ * uploads of the MSMs in flight travel under their kernels. */
+typedef struct zkhip_msm_stream zkhip_msm_stream;
+int zkhip_msm_stream_new(const zkhip_bases* bases, int depth, zkhip_msm_stream** out);     /* bases must outlive the stream */
+int zkhip_msm_stream_submit(zkhip_msm_stream* st, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery, uint64_t* ticket);
+int zkhip_msm_stream_submit_host(zkhip_msm_stream* st, size_t offset, const uint64_t* scalars, size_t len, int scalars_montgomery, uint64_t* ticket);
+int zkhip_msm_stream_collect(zkhip_msm_stream* st, uint64_t ticket, uint64_t out_jac[36]);
+float zkhip_msm_stream_last_accumulate_ms(zkhip_msm_stream* st);               /* of the MSM collected last */
+int zkhip_msm_stream_last_accumulate_interval(zkhip_msm_stream* st, float out_ms[2]);
+void zkhip_msm_stream_free(zkhip_msm_stream* st);                              /* waits for what is still in flight */
+/* pinned host memory for callers without a HIP runtime of their own (the source of submit_host's asynchronous copies) */
+int zkhip_host_alloc(size_t bytes, void** out);
+int zkhip_host_free(void* p);
 /* one-shot form (BASELINE config 2): host bases + host scalars */
 int zkhip_msm_raw(const uint64_t* bases_affine, const uint64_t* scalars, size_t len, int scalars_montgomery,
                   uint64_t out_jac[36]);
@@ -224,6 +243,11 @@ int zkhip_prover_prove_dev(zkhip_prover* p, const void* d_z, const uint64_t r[6]
 int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]);   /* as zkhip_last_prove_timings, for p's last proof */
 float zkhip_prover_last_accumulate_ms(zkhip_prover* p);          /* as zkhip_last_accumulate_ms, for p's last proof */
 void zkhip_prover_free(zkhip_prover* p);
+/* A prover instance over a SLICE of the key (zkhip_crs_upload_slice[_ex] with the same three offsets): own streams and work space
+ * like any zkhip_prover, so several slices - on several GPUs, or several contexts of one - run side by side.  It only produces
+ * partial sums: zkhip_prover_prove_partial = zkhip_groth16_prove_partial on this instance (QAP map + five MSMs over the slice). */
+int zkhip_prover_new_slice(const zkhip_crs* crs_slice, const zkhip_r1cs_desc* cs, size_t a_lo, size_t h_lo, size_t l_lo, zkhip_prover** out);
+int zkhip_prover_prove_partial(zkhip_prover* p, const uint64_t* z, uint64_t sums_jac[180]);
 
 /* replaces: wsnarkT::verify(primary_inputs, proof, vk) (libzecale/tests/aggregator/aggregator_dummy_test.cpp:61-62)
  * = libsnark r1cs_gg_ppzksnark_verifier_strong_IC for the Clearmatics Groth16 (no gamma in the key:
@@ -342,6 +366,10 @@ float zkhip_last_accumulate_ms(void);
 /* begin and end of that launch (ms, HIP events) on a per-device time base: a caller that keeps several MSMs in flight
  * (zkhip_msm_submit / collect) can see how their accumulations overlap and take the union of the intervals */
 int zkhip_last_accumulate_interval(float out_ms[2]);
+/* The time base above is recorded when the library first plans an MSM on a GPU; the values are FLOAT milliseconds since then (1 us
+ * of resolution for ~8 s, 0.06 ms after an hour).  A caller that compares intervals records the origin again at the start of its
+ * timed region (calling thread's library device). */
+int zkhip_reset_time_base(void);
 
 /* replaces: libff::Fr<wppT>::random_element() as r1cs_gg_ppzksnark_prover draws the proof's randomisers r, s (reached from
  * aggregator_circuit.tcc:168) and the generator its toxic waste: one field element uniform in Fr, 6 Montgomery limbs, from the
@@ -351,6 +379,38 @@ int zkhip_fr_random(uint64_t out[6]);
 /* Montgomery limbs -> canonical integer limbs (little-endian), for the JSON / EVM encodings of the reference
  * (SURVEY App. A.2, A.3): which = 0 for Fq (12 limbs), 1 for Fr (6 limbs).  Host code. */
 int zkhip_to_canonical(int which, const uint64_t* in, uint64_t* out);
+
+/* ---- the GPUs of one node behind one process (multi_device.cpp: host code on the entry points above, no collective) ----------
+ * The reference server is ONE process that owns the prover (aggregator_server.cpp:106-118, 279-348, 390-416; OpenMP is its only
+ * parallelism, CMakeLists.txt:80-84); a drop-in on an 8-GPU node must drive all eight from that process.  `devices` lists GPU
+ * indices; an index may repeat ("0,0": two contexts on GPU 0 - how a one-GPU box rehearses N > 1).  Both constructors call
+ * zkhip_init for the GPUs they use and leave the calling thread's library device as they found it.
+ *
+ * Replicas (BASELINE configs[4], SURVEY 8e "whole proofs"): one resident copy of the key and one streaming pipeline
+ * (zkhip_aggregator_pipeline_*) per list entry; submit hands a batch to the entry with the fewest batches outstanding.
+ * replaces: aggregator_circuit::prove as GenerateAggregatedTransaction calls it (aggregator_server.cpp:318-319), on every GPU. */
+typedef struct zkhip_dispatcher zkhip_dispatcher;
+int zkhip_dispatcher_new(zkhip_aggregator* a, const zkhip_crs_desc* key, const zkhip_key_opts* opts, const int* devices, int n_devices,
+                         int gpu_slots, int witness_workers, unsigned flags /* ZKHIP_PIPELINE_* */, zkhip_dispatcher** out);
+int zkhip_dispatcher_size(const zkhip_dispatcher* d);                          /* entries of the device list */
+int zkhip_dispatcher_submit(zkhip_dispatcher* d, const uint64_t* nested_vk, const uint64_t* nested_proofs, const uint64_t* nested_inputs,
+                            const uint64_t r[6], const uint64_t s[6], uint64_t* ticket);
+int zkhip_dispatcher_wait(zkhip_dispatcher* d, uint64_t ticket, uint64_t* primary_inputs, uint64_t proof_affine[72]);
+int zkhip_dispatcher_stats(const zkhip_dispatcher* d, size_t* submitted_per_entry);   /* batches given to each entry so far */
+void zkhip_dispatcher_free(zkhip_dispatcher* d);
+/* One proof over a key PARTITIONED across the list (BASELINE configs[3]): entry k holds the k-th contiguous slice of
+ * the A / B, H and L queries (sizes differ by at most one, the partition of zecale_amd/dist.py) and a prover instance on it; prove
+ * runs the slices on a host thread each, adds the 5 x 288-byte partial sums in list order on the host (zkhip_jac_add) and finishes
+ * once (zkhip_groth16_finish).  Same proof as zkhip_groth16_prove over the whole key.
+ * replaces: wsnarkT::generate_proof (aggregator_circuit.tcc:168) for a key that one GPU should not hold or prove alone. */
+typedef struct zkhip_multi_prover zkhip_multi_prover;
+int zkhip_multi_prover_new(const zkhip_crs_desc* key, const zkhip_r1cs_desc* cs, const zkhip_key_opts* opts, const int* devices, int n_devices,
+                           zkhip_multi_prover** out);
+int zkhip_multi_prover_size(const zkhip_multi_prover* mp);
+int zkhip_multi_prover_prove(zkhip_multi_prover* mp, const uint64_t* z, const uint64_t r[6], const uint64_t s[6], uint64_t proof_affine[72]);
+/* ms of the last proof: [0] the slowest slice (upload z + QAP map + five MSMs), [1] the host additions, [2] the host tail */
+int zkhip_multi_prover_timings(zkhip_multi_prover* mp, double out_ms[3]);
+void zkhip_multi_prover_free(zkhip_multi_prover* mp);
 
 /* host helpers on results (tiny, serial): Jacobian -> affine (infinity -> all zero), a + b */
 int zkhip_jac_to_affine(const uint64_t jac[36], uint64_t aff[24]);

@@ -1,14 +1,16 @@
-// One process, several prover contexts (SURVEY 8e from the C ABI; the reference server is one process: aggregator_server.cpp:390-416):
-// the proving key of the wrapping circuit is cut into two slices, each uploaded to its own device handle (two GPUs when the box
-// has them, else both on device 0), two host threads run zkhip_groth16_prove_partial side by side, the 5 x 288-byte partial sums
-// are added on the host, zkhip_groth16_finish completes the proof: it must equal the whole-key proof limb for limb.
+// One process, several GPUs (or several contexts of one) THROUGH THE C++ ADAPTER (the reference server is one process that owns
+// its prover: aggregator_server.cpp:106-118, 390-416):
+//   (1) hip_proving_key over a device list = the wrapping key partitioned into slices (zkhip_multi_prover: a prover instance and a
+//       host thread per slice, partial sums added on the host, one tail): its proof must equal the whole-key proof limb for limb;
+//   (2) aggregator_circuit::open_node_stream over a device list = replicas behind a dispatcher (zkhip_dispatcher): every batch is proved,
+//       every proof verifies, and both entries of the list get work.
+// The list is {0, 1} when the box has two GPUs, else {0, 0}: two contexts on device 0.
 // Input: the same binary file as boundary_gpu.cpp.  Test infrastructure only.
 #include <cstdio>
 #include <cstring>
-#include <thread>
 #include <vector>
 
-#include "groth16_snark_hip.hpp"
+#include "aggregator_circuit_hip.hpp"
 
 using namespace zecale_amd;
 
@@ -19,60 +21,78 @@ int main(int argc, char** argv) {
   if (!f || std::fread(in.data(), 8, in.size(), f) != in.size()) return 2;
   std::fclose(f);
   try {
-    const int ndev = zkhip_device_count() >= 2 ? 2 : 1;
-    for (int d = ndev - 1; d >= 0; d--) zk_check(zkhip_init(d), "zkhip_init");          // device 0 last: the thread's library device
-    zkhip_aggregator* agg = nullptr;
-    zk_check(zkhip_aggregator_new(2, 1, &agg), "zkhip_aggregator_new");
-    zkhip_r1cs_desc cs;
-    zk_check(zkhip_aggregator_get_r1cs(agg, &cs), "get_r1cs");
-    uint64_t t[4][6];
-    for (auto& s : t) zk_check(zkhip_fr_random(s), "zkhip_fr_random");
-    zkhip_keypair* kp = nullptr;
-    zk_check(zkhip_groth16_setup(&cs, t[0], t[1], t[2], t[3], &kp), "zkhip_groth16_setup");
+    const std::vector<int> devices = zkhip_device_count() >= 2 ? std::vector<int>{0, 1} : std::vector<int>{0, 0};
+    zk_check(zkhip_init(0), "zkhip_init");
+    aggregator_circuit<2> circuit(1);
+    const zkhip_r1cs_desc& cs = circuit.get_constraint_system();
+    std::unique_ptr<keypair> kp = circuit.generate_trusted_setup();          // whole key on device 0
     zkhip_crs_desc kd;
-    zk_check(zkhip_keypair_crs_desc(kp, &kd), "crs_desc");
+    zk_check(zkhip_keypair_crs_desc(kp->host(), &kd), "crs_desc");
+
+    // nested objects from the flat file
+    nested_verification_key nvk;
+    std::memcpy(nvk.alpha_g1.data(), &in[0], 96); std::memcpy(nvk.beta_g2.data(), &in[12], 192); std::memcpy(nvk.delta_g2.data(), &in[36], 192);
+    nvk.abc_g1.resize(2);
+    std::memcpy(nvk.abc_g1[0].data(), &in[60], 96); std::memcpy(nvk.abc_g1[1].data(), &in[72], 96);
+    nested_extended_proof np[2];
+    for (int i = 0; i < 2; i++) {
+      const uint64_t* p = &in[84 + 48 * i];
+      std::memcpy(np[i].proof.a.data(), p, 96); std::memcpy(np[i].proof.b.data(), p + 12, 192); std::memcpy(np[i].proof.c.data(), p + 36, 96);
+      std::array<uint64_t, 6> x;
+      std::memcpy(x.data(), &in[84 + 96 + 6 * i], 48);
+      np[i].primary_inputs.push_back(x);
+    }
+
+    // (1) the partitioned key against the whole key, same assignment, same (r, s)
     std::vector<uint64_t> z(cs.n_vars * 6);
-    zk_check(zkhip_aggregator_witness(agg, &in[0], &in[84], &in[84 + 96], z.data()), "witness");
+    {
+      std::vector<uint64_t> proofs;
+      for (int i = 0; i < 2; i++) { proofs.insert(proofs.end(), &in[84 + 48 * i], &in[84 + 48 * (i + 1)]); }
+      zkhip_aggregator* agg = nullptr;
+      zk_check(zkhip_aggregator_new(2, 1, &agg), "zkhip_aggregator_new");
+      zk_check(zkhip_aggregator_witness(agg, &in[0], proofs.data(), &in[84 + 96], z.data()), "witness");
+      zkhip_aggregator_free(agg);
+    }
     uint64_t r[6], s[6];
     zk_check(zkhip_fr_random(r), "r"); zk_check(zkhip_fr_random(s), "s");
-    // whole key on device 0
-    zkhip_crs* whole = nullptr; zkhip_r1cs* r0 = nullptr;
-    zk_check(zkhip_crs_upload(&kd, &whole), "crs_upload");
-    zk_check(zkhip_r1cs_upload(&cs, &r0), "r1cs_upload");
-    uint64_t expect[72];
-    zk_check(zkhip_groth16_prove(whole, r0, z.data(), r, s, expect), "prove");
-    // two slices, one context each
-    const size_t m = kd.n_vars, l = kd.n_primary, d = kd.domain_size;
-    const size_t a_cut = m / 3, h_cut = (d - 1) / 2 + 5, l_cut = (m - l - 1) * 2 / 3;     // uneven on purpose
-    struct Ctx { int dev; size_t a0, a1, h0, h1, l0, l1; zkhip_crs* crs = nullptr; zkhip_r1cs* rc = nullptr; uint64_t sums[180]; int rc_code = 0; std::string err; };
-    Ctx cx[2] = {{0, 0, a_cut, 0, h_cut, 0, l_cut}, {ndev - 1, a_cut, m, h_cut, d - 1, l_cut, m - l - 1}};
-    for (auto& c : cx) {
-      zk_check(zkhip_set_device(c.dev), "set_device");
-      zk_check(zkhip_crs_upload_slice(&kd, c.a0, c.a1 - c.a0, c.h0, c.h1 - c.h0, c.l0, c.l1 - c.l0, &c.crs), "upload_slice");
-      zk_check(zkhip_r1cs_upload(&cs, &c.rc), "r1cs_upload");
+    groth16_proof whole, split;
+    {
+      hip_proving_key one(kd, cs);
+      if (!one.is_satisfied(z.data())) throw std::runtime_error("assignment does not satisfy the circuit");
+      whole = one.generate_proof(z.data(), r, s);
     }
-    zk_check(zkhip_set_device(0), "set_device");
-    std::thread th[2];
-    for (int i = 0; i < 2; i++)
-      th[i] = std::thread([&, i] {            // these threads never called zkhip_init / zkhip_set_device: the handles carry their device
-        Ctx& c = cx[i];
-        c.rc_code = zkhip_groth16_prove_partial(c.crs, c.rc, z.data(), c.a0, c.h0, c.l0, c.sums);
-        if (c.rc_code != ZKHIP_OK) c.err = zkhip_last_error();
-      });
-    for (auto& x : th) x.join();
-    for (auto& c : cx) if (c.rc_code != ZKHIP_OK) throw std::runtime_error("prove_partial: " + c.err);
-    uint64_t total[180];
-    for (int k = 0; k < 5; k++) zk_check(zkhip_jac_add(cx[0].sums + 36 * k, cx[1].sums + 36 * k, total + 36 * k), "jac_add");
-    uint64_t got[72];
-    zk_check(zkhip_groth16_finish(kd.alpha_g1, kd.beta_g1, kd.beta_g2, kd.delta_g1, kd.delta_g2, total, r, s, got), "finish");
-    uint64_t a[24], b[24], dl[24]; const uint64_t* abc;
-    const size_t nabc = zkhip_keypair_vk(kp, a, b, dl, &abc);
-    int ok = 0;
-    zk_check(zkhip_groth16_verify(a, b, dl, abc, &z[6], nabc - 1, got, &ok), "verify");
-    std::printf("MULTI devices=%d same_as_whole_key=%d verifies=%d\n", ndev, std::memcmp(got, expect, sizeof got) == 0, ok);
-    for (auto& c : cx) { zkhip_crs_free(c.crs); zkhip_r1cs_free(c.rc); }
-    zkhip_crs_free(whole); zkhip_r1cs_free(r0); zkhip_keypair_free(kp); zkhip_aggregator_free(agg);
+    {
+      hip_proving_key many(kd, cs, devices);
+      split = many.generate_proof(z.data(), r, s);
+      split = many.generate_proof(z.data(), r, s);                           // (a second proof on warm contexts)
+      std::printf("PARTITIONED devices=%zu list=%d,%d same_as_whole_key=%d\n", many.num_devices(), devices[0], devices[1],
+                  whole.a == split.a && whole.b == split.b && whole.c == split.c);
+    }
+    extended_proof ep;
+    ep.proof = split;
+    for (size_t i = 0; i < circuit.num_primary_inputs(); i++) {
+      std::array<uint64_t, 6> x;
+      std::memcpy(x.data(), &z[(i + 1) * 6], 48);
+      ep.primary_inputs.push_back(x);
+    }
+    std::printf("PARTITIONED verifies=%d\n", (int)kp->verify(ep));
+
+    // (2) replicas behind the dispatcher: eight batches over the list
+    {
+      auto stream = circuit.open_node_stream(*kp, devices, /*gpu_slots=*/3, /*witness_workers=*/2);
+      std::vector<uint64_t> tickets;
+      for (int b = 0; b < 8; b++) {
+        const int flip = b & 1;                                              // the two nested proofs in either order
+        tickets.push_back(stream->submit(nvk, {&np[flip], &np[1 - flip]}));
+      }
+      int verified = 0;
+      for (uint64_t t : tickets) verified += kp->verify(stream->wait(t)) ? 1 : 0;
+      const std::vector<size_t> per = stream->batches_per_device();
+      std::printf("REPLICAS entries=%zu verified=%d of 8 batches_per_entry=%zu,%zu\n", per.size(), verified, per[0], per[1]);
+    }
+    kp.reset();
     zkhip_shutdown();
+    std::printf("DONE\n");
   } catch (const std::exception& e) {
     std::printf("EXCEPTION %s\n", e.what());
     return 1;

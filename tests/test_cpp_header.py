@@ -62,6 +62,11 @@ def test_aggregator_circuit_mirror_compiles_and_runs_host_part(tmp_path):
           // the streaming form needs a device: instantiate it only
           auto f_open = &aggregator_circuit<2>::open_stream; auto f_sub = &aggregator_circuit<2>::stream::submit;
           auto f_wait = &aggregator_circuit<2>::stream::wait; (void)f_open; (void)f_sub; (void)f_wait;
+              // ... and the form over the GPUs of a node (zkhip_dispatcher), and the proving key partitioned over a device list
+              auto n_open = &aggregator_circuit<2>::open_node_stream; auto n_sub = &aggregator_circuit<2>::node_stream::submit;
+              auto n_wait = &aggregator_circuit<2>::node_stream::wait; (void)n_open; (void)n_sub; (void)n_wait;
+              try { zkhip_crs_desc kd{}; hip_proving_key pk(kd, agg.get_constraint_system(), std::vector<int>{0, 0}); }
+              catch (const std::runtime_error& e) { std::printf("multi: %s\n", e.what()); }
           extended_proof ep{};
           ep.primary_inputs.resize(1);
           std::printf("%s\n", ep.to_json().substr(0, 40).c_str());
@@ -75,3 +80,4 @@ def test_aggregator_circuit_mirror_compiles_and_runs_host_part(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "primary=4" in out.stdout and "caught: attempt to aggregate proof with invalid number of inputs" in out.stdout
     assert '{"proof": {"a": ["0x' in out.stdout
+    assert "multi: zkhip_multi_prover_new" in out.stdout          # no device here (or a null key): refused, as a std::runtime_error

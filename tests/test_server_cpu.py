@@ -153,8 +153,8 @@ def test_pool_orders_by_fee_and_only_returns_whole_batches():
 
 def test_malformed_proof_is_refused_at_submission_and_a_failed_batch_goes_back(live):
     """(1) A nested proof with a point off its curve is refused by SubmitNestedTransaction - queued, it would be batched with another
-    user's transaction and take it down with it.  (2) When the prover fails, the batch that was popped under the lock returns to
-    the pool in its old order instead of being lost."""
+    user's transaction and take it down with it.  (2) When the prover fails for a TRANSIENT reason, the batch that was popped under
+    the lock returns to the pool in its old order instead of being lost."""
     from zecale_amd import zkhip
     client, prover, service = live
     agg = zkhip.AggregatorCircuit(S.BATCH_SIZE, S.NUM_INPUTS_PER_NESTED_PROOF)          # host code: the circuit's own curve checks
@@ -172,7 +172,7 @@ def test_malformed_proof_is_refused_at_submission_and_a_failed_batch_goes_back(l
     good_prove = prover.prove
 
     def failing(*a):
-        raise RuntimeError("device lost")
+        raise S.TransientProverError("device lost")
     prover.prove = failing
     with pytest.raises(grpc.RpcError) as e:
         client.get_aggregated_transaction("dummy_app")
@@ -183,6 +183,63 @@ def test_malformed_proof_is_refused_at_submission_and_a_failed_batch_goes_back(l
     fees = sorted((golden("dummy_app/extproof%d.json" % k) for k in (1, 2, 3)), key=lambda t: -t["fee_in_wei"])
     assert [int(x, 16) for x in batch["ext_proof"]["inputs"][2:]] == [int(t["extended_proof"]["inputs"][0], 16) for t in fees[:2]]
     agg.free()
+
+
+def test_a_batch_that_fails_for_good_does_not_block_the_pool(live):
+    """a batch whose proof fails DETERMINISTICALLY (a degenerate nested proof makes witness generation return
+    ZKHIP_ERR_ARG; prove()'s own input check raises ValueError) must not go back to the head of the fee-ordered queue, where every
+    later call would pop it and fail again: the reference drops it (aggregator_server.cpp:283-340).  A transient failure is retried a
+    bounded number of times, then set aside too.  Either way the pool makes progress."""
+    from zecale_amd import zkhip
+    client, prover, service = live
+    client.register_application(golden("dummy_app/vk.json"), "dummy_app")
+    for k in (1, 2, 3, 4):
+        client.submit_nested_transaction(golden("dummy_app/extproof%d.json" % k))
+    pool = service.pools["dummy_app"]
+    good_prove, calls = prover.prove, []
+
+    def poisoned(vk, proofs, inputs):                     # the two highest fees form a batch that can never be proved
+        calls.append(1)
+        if len(calls) == 1:
+            raise zkhip.ZkhipError("zkhip error -1 (bad argument): degenerate nested proof", -1)
+        return good_prove(vk, proofs, inputs)
+    prover.prove = poisoned
+    with pytest.raises(grpc.RpcError) as e:
+        client.get_aggregated_transaction("dummy_app")
+    assert "degenerate nested proof" in e.value.details()
+    assert pool.tx_pool_size() == 2 and len(pool.quarantined) == 2                        # dropped, not requeued
+    batch = client.get_aggregated_transaction("dummy_app")                               # the next call proves the NEXT batch
+    assert len(batch["nested_parameters"]) == 2 and pool.tx_pool_size() == 0
+    # a ValueError from the prover's input check is a property of the batch as well
+    for k in (1, 2):
+        client.submit_nested_transaction(golden("dummy_app/extproof%d.json" % k))
+
+    def refuses(*a):
+        raise ValueError("nested proof or verification key has a point that is not on its curve")
+    prover.prove = refuses
+    with pytest.raises(grpc.RpcError):
+        client.get_aggregated_transaction("dummy_app")
+    assert pool.tx_pool_size() == 0 and len(pool.quarantined) == 4
+    # a transient failure that never goes away: three attempts, then the batch is set aside and the pool moves on
+    for k in (1, 2, 3, 4):
+        client.submit_nested_transaction(golden("dummy_app/extproof%d.json" % k))
+    attempts = []
+
+    def flaky(vk, proofs, inputs):
+        fee_batch = len(attempts) < 3                     # fails while the head batch is the one being proved
+        attempts.append(1)
+        if fee_batch:
+            raise S.TransientProverError("device lost")
+        return good_prove(vk, proofs, inputs)
+    prover.prove = flaky
+    for _ in range(3):
+        with pytest.raises(grpc.RpcError):
+            client.get_aggregated_transaction("dummy_app")
+    assert pool.tx_pool_size() == 2 and len(pool.quarantined) == 6                        # the head batch is out after its third failure
+    assert len(client.get_aggregated_transaction("dummy_app")["nested_parameters"]) == 2
+    assert S.is_transient_failure(zkhip.ZkhipError("x", -3)) and S.is_transient_failure(zkhip.ZkhipError("x", -4))
+    assert not S.is_transient_failure(zkhip.ZkhipError("x", -1)) and not S.is_transient_failure(RuntimeError("x"))
+    prover.prove = good_prove
 
 
 def test_handler_pool_is_as_deep_as_the_prover():

@@ -13,11 +13,15 @@ from tests.helpers import fr_int, golden
 pytestmark = pytest.mark.gpu
 
 
-def test_client_script_flow_on_the_gpu(zk, tmp_path):
+@pytest.mark.parametrize("devices", [None, [0, 0]], ids=["one_gpu", "devices_0_0"])
+def test_client_script_flow_on_the_gpu(zk, tmp_path, devices):
+    """devices_0_0: the same flow with the server started as `--devices 0,0` - one process, a dispatcher over two contexts of GPU 0
+    (how a one-GPU box rehearses the 8-GPU server)."""
     from zecale_amd import encoding as E
     from zecale_amd import server as S
     kpf = str(tmp_path / "zeth_setup" / "zecale_keypair.bin")
-    prover = S.GpuProver(kpf, device=0, gpu_slots=2, witness_workers=2)
+    prover = S.GpuProver(kpf, device=0, gpu_slots=2, witness_workers=2, devices=devices)
+    assert prover.gpu_slots == (4 if devices else 2)
     server, port, service = S.serve(prover, "127.0.0.1:0", max_workers=4)
     try:
         client = S.AggregatorClient("127.0.0.1:%d" % port)
@@ -59,6 +63,8 @@ def test_client_script_flow_on_the_gpu(zk, tmp_path):
             assert zk.groth16_verify(vk, inputs, proof) and fr_int(inputs[1]) == 3
             seen.add(tuple(fr_int(x) for x in inputs[2:]))
         assert seen == {(7, 8), (11, 12)}                             # fees 12, 11 (proofs 1, 2) and 8, 7 (proofs 5, 6)
+        if devices:
+            assert sum(prover.pipe.stats()) == 4 and min(prover.pipe.stats()) >= 1      # both entries of the list proved batches
     finally:
         server.stop(0)
         prover.close()

@@ -33,6 +33,7 @@ struct MsmCtx {
   uint16_t win_off[96];
   uint8_t win_bits[96];
   size_t B, max_n;
+  size_t total_terms;   // bound on the terms of one launch sequence (all jobs): sizes the entry list, the slices and the slot array
   int one_stream;       // 1: the whole launch sequence on `stream` (a prover that shares the chip); 0: row / column trees side by side
   uint32_t quad_below;  // reduction launches with fewer outputs than this spread an addition over four lanes (latency) instead of one (total work)
   uint32_t S, T, slot_stride;   // slice length, slice count, words per row of the slot array
@@ -63,6 +64,11 @@ struct MsmCtx {
   float last_accumulate_ms;
   float last_acc_begin_ms, last_acc_end_ms;   // the same launch on the device's time base (msm_time_base): lets a caller that keeps
                                               // several MSMs in flight see how their accumulations overlap
+  // measurement aid (ZKHIP_DEBUG_DUMP=<dir>, tools/acc_probe.py): per-wave begin / end clocks of k_accumulate and, at collection, a dump
+  // of the bucket populations; null / unused otherwise
+  uint64_t* dbg_times;
+  uint32_t last_S, last_T;           // slice length / slices of the last launch (before the kernel's own shortening, see slice_len)
+  int last_tight;
   bool pending;       // an MSM has been enqueued by msm_launch and not yet collected by msm_finish
   size_t pending_n;
   char errbuf[256];
@@ -71,9 +77,12 @@ struct MsmCtx {
 // tuning / test knob: number of batched-affine levels of the plans made from now on (-1: automatic)
 void msm_force_aff_levels(int levels);
 int msm_forced_aff_levels();
-int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K);
+// total_terms: upper bound on the terms (finite bases) of all K jobs of one launch together; 0 = K * max_n
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t total_terms = 0);
 // a per-device event recorded once: the origin of last_acc_begin_ms / last_acc_end_ms
 hipEvent_t msm_time_base();
+// record the origin again (now): intervals read afterwards are relative to this moment
+int msm_time_base_reset();
 void msm_plan_free(MsmCtx* ctx);
 int msm_bases_convert(const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, uint8_t* d_inf_flags, char* errbuf, size_t errlen);
 // table_stride: distance (in points) between the levels of a precomputed table (merged plans only)

@@ -305,8 +305,8 @@ __global__ void __launch_bounds__(512) k_bucket_sort(const uint32_t* __restrict_
 }
 
 // ---- exclusive scan over `m` u32 counters, 1024 per block ----
-__global__ void __launch_bounds__(256) k_scan_local(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                     uint32_t* __restrict__ block_tot, size_t m) {
+// (in and out may be the same array - the histogram is scanned in place -: no __restrict__ on them)
+__global__ void __launch_bounds__(256) k_scan_local(const uint32_t* in, uint32_t* out, uint32_t* __restrict__ block_tot, size_t m) {
   __shared__ uint32_t sh[256];
   size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
   uint32_t v[4], sum = 0;
@@ -405,8 +405,10 @@ template <int NJ>
 __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, const uint32_t* __restrict__ entries,
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                         uint32_t nb, uint32_t S_host, int tight, uint32_t T, uint32_t* __restrict__ slots,
-                                                        uint32_t stride, uint32_t* __restrict__ fix_cnt /* [2] */, uint2* __restrict__ fix_short, uint2* __restrict__ fix_long) {
+                                                        uint32_t stride, uint32_t* __restrict__ fix_cnt /* [2] */, uint2* __restrict__ fix_short, uint2* __restrict__ fix_long,
+                                                        uint64_t* __restrict__ dbg_times /* null, or [waves][4]: tools/acc_probe.py */, int prio_mode) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t dbg_t0 = dbg_times ? wall_clock64() : 0;
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
   const uint32_t S = slice_len(M, T, S_host, tight);
   uint32_t pos0 = t * S;
@@ -455,6 +457,17 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   const bool dense = entries == nullptr;
   uint32_t e_next = dense ? pos0 : entries[pos0];
   for (uint32_t k = pos0; k < pos1; k++) {
+    if (prio_mode) {
+      // The SIMD's arbiter serves its OLDEST wave first: of the two waves that share a SIMD one runs at full speed and the other on
+      // what is left, so a launch of a single machine fill ends with a third of its time at one wave per SIMD (78 % of the
+      // multiplier's rate; measured: waves 0 .. 1023 of 2,000 end at 1.6 ms, the others at 2.55 ms).  The wave that is behind asks
+      // for the higher priority, by quarters of its slice: both advance together and end together.
+      const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((k - pos0) << 2) / S));
+      if (q == 0) __builtin_amdgcn_s_setprio(3);
+      else if (q == 1) __builtin_amdgcn_s_setprio(2);
+      else if (q == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     if (k == bend) {
       if (!first) {
         if (!inf) {   // close the finished run
@@ -493,6 +506,12 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   }
   // a run that cancelled to infinity leaves ZZ = 0 in its slot: madd_same_x wrote the zeros, or the slot
   // was never written (zero-filled array)
+  if (dbg_times && (threadIdx.x & 63u) == 0) {          // (wave-uniform: lane 0 of a wave that had work)
+    const uint32_t wave = t >> 6;
+    dbg_times[4 * wave] = dbg_t0; dbg_times[4 * wave + 1] = wall_clock64();
+    dbg_times[4 * wave + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID: wave, SIMD, CU, SH, SE
+    dbg_times[4 * wave + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+  }
 }
 
 // ---- batched-affine levels ------------------------------------------------------------------------------------------------
@@ -1118,22 +1137,59 @@ static int choose_aff_levels(size_t m_entries, size_t nb) {
   return forced >= 0 ? forced : 0;
 }
 
-// One event per device, recorded the first time a plan is made there: the origin of the absolute launch times of k_accumulate.
+// One event per device, recorded the first time a plan is made there - and again whenever the caller asks (msm_time_base_reset):
+// the origin of the absolute launch times of k_accumulate.  hipEventElapsedTime returns FLOAT milliseconds: 1 us of resolution
+// lasts ~8 s from the origin, 0.06 ms an hour - a caller that compares intervals re-bases at the start of its timed region.
+static hipEvent_t g_time_base[64];
+static bool g_time_base_made[64];
+static std::mutex g_time_base_mu;           // plans are made under per-device or per-prover locks: several threads may arrive here
+static hipEvent_t time_base_locked(int dev, bool renew) {
+  if (!g_time_base_made[dev] && hipEventCreate(&g_time_base[dev]) != hipSuccess) return nullptr;
+  if (!g_time_base_made[dev] || renew) {
+    if (hipEventRecord(g_time_base[dev], 0) != hipSuccess || hipEventSynchronize(g_time_base[dev]) != hipSuccess) {
+      if (!g_time_base_made[dev]) (void)hipEventDestroy(g_time_base[dev]);
+      return nullptr;
+    }
+    g_time_base_made[dev] = true;
+  }
+  return g_time_base[dev];
+}
 hipEvent_t msm_time_base() {
-  static hipEvent_t base[64];
-  static bool made[64];
-  static std::mutex mu;                     // plans are made under per-device or per-prover locks: several threads may arrive here
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  std::lock_guard<std::mutex> lk(mu);
-  if (!made[dev]) {
-    if (hipEventCreate(&base[dev]) == hipSuccess && hipEventRecord(base[dev], 0) == hipSuccess && hipEventSynchronize(base[dev]) == hipSuccess) made[dev] = true;
-    else return nullptr;
-  }
-  return base[dev];
+  std::lock_guard<std::mutex> lk(g_time_base_mu);
+  return time_base_locked(dev, false);
+}
+int msm_time_base_reset() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lk(g_time_base_mu);
+  return time_base_locked(dev, true) ? ZKHIP_OK : ZKHIP_ERR_HIP;
+}
+
+// ZKHIP_DEBUG_DUMP=<dir>: the last launch's bucket populations and per-wave clocks of k_accumulate, for tools/acc_probe.py
+// (synchronous copies: a measurement aid, never on in a timed run)
+static void debug_dump(MsmCtx* ctx) {
+  const char* dir = getenv("ZKHIP_DEBUG_DUMP");
+  if (!dir || !ctx->dbg_times) return;
+  const size_t nb = ctx->B * (size_t)ctx->W, nw = (size_t)ctx->T / 64 + 8;
+  std::vector<uint32_t> cnt(nb);
+  std::vector<uint64_t> tm(4 * nw);
+  if (hipMemcpy(cnt.data(), ctx->counts, nb * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
+  if (hipMemcpy(tm.data(), ctx->dbg_times, nw * 32, hipMemcpyDeviceToHost) != hipSuccess) return;
+  char path[512];
+  snprintf(path, sizeof path, "%s/acc_K%d_c%d_m%d.bin", dir, ctx->K, ctx->c, ctx->merged);
+  FILE* f = fopen(path, "wb");
+  if (!f) return;
+  const uint64_t hdr[8] = {nb, nw, ctx->last_S, ctx->last_T, (uint64_t)ctx->last_tight, (uint64_t)ctx->K, (uint64_t)ctx->c, (uint64_t)ctx->merged};
+  fwrite(hdr, 8, 8, f);
+  fwrite(cnt.data(), 4, nb, f);
+  fwrite(tm.data(), 8, 4 * nw, f);
+  fclose(f);
 }
 
 static void read_accumulate_times(MsmCtx* ctx) {
+  debug_dump(ctx);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev_acc0, ctx->ev_acc1);
   ctx->last_accumulate_ms = ms;
@@ -1144,8 +1200,14 @@ static void read_accumulate_times(MsmCtx* ctx) {
   }
 }
 
-int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t total_terms) {
   memset(ctx, 0, sizeof *ctx);
+  // terms of ALL jobs of one launch sequence together: K * max_n unless the caller knows better (a proving key's five query vectors
+  // differ in length and a third of the B query is the point at infinity: the wrapping key has 192,664 finite bases where
+  // 5 * 65,535 = 327,675 would be planned - slices, boundary slots and the slot array's zero fill all scale with this bound)
+  if (total_terms == 0 || total_terms > (size_t)K * max_n) total_terms = (size_t)K * max_n;
+  if (total_terms < max_n && K == 1) total_terms = max_n;
+  ctx->total_terms = total_terms;
   (void)msm_time_base();
   if (K < 1 || K > MSM_MAX_JOBS || (!merged && K != 1)) return ZKHIP_ERR_ARG;
   ctx->K = K;
@@ -1175,7 +1237,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
   // spinning on the stream (several prover instances wait side by side and share the cores with the witness generators)
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done, hipEventBlockingSync | hipEventDisableTiming));
   if ((size_t)ctx->Wd * max_n >= ((size_t)1 << 31)) return ZKHIP_ERR_ARG;   // entry = 31-bit point index + sign
-  if ((size_t)ctx->Wd * max_n * K >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;  // positions in the entry list are 32-bit
+  if ((size_t)ctx->Wd * total_terms >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;  // positions in the entry list are 32-bit
   // geometry of the bucket sort: parts of 2^LB buckets (LB <= 10: k_bucket_sort keeps a part's counters in LDS); small bucket
   // windows get smaller parts so that k_bucket_sort still has about a thousand workgroups to spread over the chip
   {
@@ -1193,14 +1255,14 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
     ctx->hist_len = (nb >> LB) * (nbx ? nbx : 1) + 1;
   }
   HIP_TRY(hipMalloc(&ctx->hist, ctx->hist_len * 4));
-  HIP_TRY(hipMalloc(&ctx->pairs, ((size_t)K * ctx->Wd * max_n + 1) * sizeof(uint2)));
+  HIP_TRY(hipMalloc(&ctx->pairs, ((size_t)ctx->Wd * total_terms + 1) * sizeof(uint2)));
   HIP_TRY(hipMalloc(&ctx->counts, nb * 4));
   HIP_TRY(hipMalloc(&ctx->offsets, nb * 4));
   HIP_TRY(hipMalloc(&ctx->block_tot, ((nb > ctx->hist_len ? nb : ctx->hist_len) / 1024 + 2) * 4));
-  HIP_TRY(hipMalloc(&ctx->entries, (size_t)K * ctx->Wd * max_n * 4));
+  HIP_TRY(hipMalloc(&ctx->entries, ((size_t)ctx->Wd * total_terms + 1) * 4));
   // batched-affine levels: bounds on the level sizes, the buffers of their outputs
   {
-    size_t m = (size_t)K * ctx->Wd * max_n;
+    size_t m = (size_t)ctx->Wd * total_terms;
     ctx->aff_levels = choose_aff_levels(m, nb);
     ctx->aff_forced = msm_forced_aff_levels();
     ctx->aff_m = (uint32_t)env_int("ZKHIP_AFF_M", 64, 4, 512);
@@ -1243,6 +1305,7 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K) {
     if ((size_t)ctx->slot_stride * 108 * 4 >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;
   }
   HIP_TRY(hipMalloc(&ctx->buckets, (size_t)ctx->slot_stride * 108 * 4));
+  if (getenv("ZKHIP_DEBUG_DUMP")) HIP_TRY(hipMalloc(&ctx->dbg_times, ((size_t)ctx->T / 64 + 8) * 32));
   HIP_TRY(hipMalloc(&ctx->fix_list, ((size_t)ctx->T / 5 + 2) * sizeof(uint2)));     // buckets of more than four F pieces: at most T / 5
   HIP_TRY(hipMalloc(&ctx->fix_short, ((size_t)ctx->T / 2 + 2) * sizeof(uint2)));    // buckets of two to four F pieces: at most T / 2
   // reduction scratch: S ping-pong (<= nb/L each) and R arrays (sum over levels <= nb/L * L/(L-1)), R sums
@@ -1265,7 +1328,7 @@ void msm_plan_free(MsmCtx* ctx) {
                   ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi,
                   ctx->colS[0], ctx->colS[1], ctx->hilo, ctx->pbuf[0], ctx->pbuf[1], ctx->aff_scratch,
                   ctx->lcnt[0], ctx->lcnt[1], ctx->lcnt[2], ctx->lcnt[3], ctx->loff[0], ctx->loff[1], ctx->loff[2], ctx->loff[3],
-                  ctx->fix_list, ctx->fix_short};
+                  ctx->fix_list, ctx->fix_short, ctx->dbg_times};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->win_host) (void)hipHostFree(ctx->win_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1312,6 +1375,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   for (int k = 0; k < K; k++) {
     if (jobs[k].n > ctx->max_n) return ZKHIP_ERR_ARG;
     n_eff += (jobs[k].n_finite && jobs[k].n_finite < jobs[k].n) ? jobs[k].n_finite : jobs[k].n;
+    if (n_eff > ctx->total_terms) return ZKHIP_ERR_ARG;          // (the entry list and the slices are sized for total_terms)
     if (merged && jobs[k].n && (jobs[k].table_stride < jobs[k].n || (size_t)(merged == 2 ? 378 : Wd) * jobs[k].table_stride >= ((size_t)1 << 31))) return ZKHIP_ERR_ARG;
     n_tot += jobs[k].n;
   }
@@ -1416,17 +1480,22 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     S_run = (uint32_t)S; T_run = (uint32_t)((m + S - 1) / S);
   }
   const int tight = (ctx->one_stream || dense) ? 0 : env_int("ZKHIP_TIGHT_SLICES", 1, 0, 1);      // (a streaming prover shares the chip: see slice_len)
-  HIP_TRY(hipMemsetAsync(ctx->buckets, 0, (size_t)ctx->slot_stride * 108 * 4, st));
+  // all-zero ZZ = infinity is what every reader of a slot tests first (mem_is_inf; X, Y, ZZZ of an infinite slot are copied along at
+  // most, never used): only the 27 ZZ rows of the limb-major array need the zero fill - a quarter of the bytes
+  HIP_TRY(hipMemsetAsync(ctx->buckets + (size_t)CZZ * 27 * ctx->slot_stride, 0, (size_t)ctx->slot_stride * 27 * 4, st));
+  if (ctx->dbg_times) HIP_TRY(hipMemsetAsync(ctx->dbg_times, 0, ((size_t)ctx->T / 64 + 8) * 32, st));
   if (ctx->acc_gate) HIP_TRY(hipStreamWaitEvent(st, ctx->acc_gate, 0));
   if (ctx->aff_levels == 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
   const uint32_t* acc_entries = dense ? nullptr : ctx->entries;
+  static const int acc_prio = env_int("ZKHIP_ACC_PRIO", 0, 0, 1);
   if (ctx->K == 1 || dense)
     hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off, cur_cnt,
-                       (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list);
+                       (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio);
   else
     hipLaunchKernelGGL(k_accumulate<MSM_MAX_JOBS>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off,
-                       cur_cnt, (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list);
+                       cur_cnt, (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
+  ctx->last_S = S_run; ctx->last_T = T_run; ctx->last_tight = tight;
   // fold the F pieces of the buckets that have several (lists made by k_accumulate), then L + F for every cut bucket
   if (T_run > 2) {
     const bool fold_quads = T_run < (1u << 18) && ctx->quad_below > 1024;     // a small launch that has the chip to itself is latency-bound

@@ -149,12 +149,14 @@ int auto_table_window(size_t n) {
 }
 
 // table_c = 0: plain plan with the automatic window;  > 0: merged plan (bases are a window table built for table_c)
-int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1, int naf = 0) {
+// total: bound on the terms of all K jobs of a launch together (0: K * n)
+int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1, int naf = 0, size_t total = 0) {
   const int c = table_c ? table_c : auto_window(n), merged = table_c ? (naf ? 2 : 1) : 0;
+  if (total == 0 || total > (size_t)K * n) total = (size_t)K * n;
   if (*ready && cx->pending) return fail(ZKHIP_ERR_STATE, "an MSM submitted on this context has not been collected (zkhip_msm_collect)");
-  if (*ready && cx->max_n >= n && cx->c == c && cx->merged == merged && cx->K == K && cx->aff_forced == msm_forced_aff_levels()) return ZKHIP_OK;
+  if (*ready && cx->max_n >= n && cx->total_terms >= total && cx->c == c && cx->merged == merged && cx->K == K && cx->aff_forced == msm_forced_aff_levels()) return ZKHIP_OK;
   if (*ready) { msm_plan_free(cx); *ready = false; }
-  int rc = msm_plan_init(cx, n, c, merged, K);
+  int rc = msm_plan_init(cx, n, c, merged, K, total);
   if (rc != ZKHIP_OK) {
     snprintf(t_err, sizeof t_err, "msm_plan_init: %s", cx->errbuf);
     msm_plan_free(cx);          // whatever was allocated before the failure
@@ -627,6 +629,7 @@ void zkhip_crs_free(zkhip_crs* c) {
 int zkhip_last_prove_timings(double out_ms[8]) {
   const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();
   if (!out_ms || dev < 0) return ZKHIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g.dev[dev].mu);
   memcpy(out_ms, g.dev[dev].ps.ms, sizeof g.dev[0].ps.ms);
   return ZKHIP_OK;
 }
@@ -682,7 +685,12 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     // table-backed key: the five MSMs share ONE launch sequence (one sort, one accumulation launch over all five entry
     // lists, one reduction chain with a bucket window per MSM) - a fifth of the launches, five times the lanes in each.
     // (A plan that does not fit the engine's 32-bit entry positions is refused with ZKHIP_ERR_ARG: one sequence per MSM then.)
-    rc = ensure_ctx(&ps.ctx[ZK_MSM_SLOTS], &ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf);
+    size_t total = 0;
+    for (int j = 0; j < 5; j++) {                     // (the rule of msm_launch_multi: a base at infinity never produces an entry)
+      const size_t nf = jobs[j].len == jobs[j].b->len ? jobs[j].b->n_finite : 0;
+      total += (nf && nf < jobs[j].len) ? nf : jobs[j].len;
+    }
+    rc = ensure_ctx(&ps.ctx[ZK_MSM_SLOTS], &ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf, total ? total : 1);
     if (rc == ZKHIP_OK && ps.quad_below) { ps.ctx[ZK_MSM_SLOTS].quad_below = ps.quad_below; ps.ctx[ZK_MSM_SLOTS].one_stream = 1; }
     if (rc == ZKHIP_ERR_ARG) batched = false;
     else if (rc != ZKHIP_OK) return rc;
@@ -793,7 +801,11 @@ static int finish_impl(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], 
 int zkhip_groth16_finish(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
                          const uint64_t delta_g2[24], const uint64_t sums_jac[180], const uint64_t r_m[6], const uint64_t s_m[6],
                          uint64_t proof_affine[72]) {
-  return finish_impl(alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, sums_jac, r_m, s_m, proof_affine, cur_dev() >= 0 ? &g.dev[cur_dev()].ps.ms[7] : nullptr);
+  double tail_ms = 0;
+  const int rc = finish_impl(alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, sums_jac, r_m, s_m, proof_affine, &tail_ms);
+  const int dev = cur_dev();
+  if (rc == ZKHIP_OK && dev >= 0) { std::lock_guard<std::mutex> lk(g.dev[dev].mu); g.dev[dev].ps.ms[7] = tail_ms; }
+  return rc;
 }
 
 int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6],
@@ -812,8 +824,10 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
     if (rc != ZKHIP_OK) return rc;
   }
   t_prove_dev = crs->device;      // zkhip_last_prove_timings reads the device of this thread's last proof
-  return finish_impl(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine,
-                     &g.dev[crs->device].ps.ms[7], &pre);
+  double tail_ms = 0;
+  const int rc = finish_impl(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine, &tail_ms, &pre);
+  if (rc == ZKHIP_OK) { std::lock_guard<std::mutex> lk(g.dev[crs->device].mu); g.dev[crs->device].ps.ms[7] = tail_ms; }   // (two threads may prove through this entry point)
+  return rc;
 }
 
 // ---- prover instances: one proof in flight each, several instances per GPU -------------------------------------------
@@ -823,9 +837,11 @@ struct zkhip_prover {
   R1csDev* rd;          // own copy of the constraint system + QAP work buffers
   ProveState ps;
   std::mutex mu;
+  bool slice = false;                    // crs is a slice of the key (zkhip_prover_new_slice): partial sums only
+  size_t a_lo = 0, h_lo = 0, l_lo = 0;   // where the slice starts in the A / B, H and L queries
 };
 
-int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prover** out) {
+static int prover_new_impl(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, bool slice, size_t a_lo, size_t h_lo, size_t l_lo, zkhip_prover** out) {
   if (!crs || !cs || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
   BIND(crs);
   R1csDev* rd = nullptr;
@@ -835,15 +851,24 @@ int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prov
     if (rc != ZKHIP_OK) return rc;
   }
   const size_t m = rd->n_vars, l = rd->n_primary, d = (size_t)1 << rd->log_d;
-  if (crs->n_vars != m || crs->n_primary != l || crs->domain_size != d || crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) {
+  bool ok = crs->n_vars == m && crs->n_primary == l && crs->domain_size == d;
+  if (ok && !slice) ok = crs->A->len == m && crs->H->len == d - 1 && crs->L->len == m - l - 1;
+  if (ok && slice) ok = a_lo + crs->A->len <= m && h_lo + crs->H->len <= d - 1 && l_lo + crs->L->len <= m - l - 1;
+  if (!ok) {
     r1cs_free(rd);
-    return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+    return fail(ZKHIP_ERR_ARG, slice ? "key slice out of range for this constraint system" : "proving key and constraint system do not match");
   }
   zkhip_prover* p = new zkhip_prover();
   p->device = crs->device;
   p->crs = crs; p->rd = rd;
+  p->slice = slice; p->a_lo = a_lo; p->h_lo = h_lo; p->l_lo = l_lo;
   *out = p;
   return ZKHIP_OK;
+}
+
+int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prover** out) { return prover_new_impl(crs, cs, false, 0, 0, 0, out); }
+int zkhip_prover_new_slice(const zkhip_crs* crs_slice, const zkhip_r1cs_desc* cs, size_t a_lo, size_t h_lo, size_t l_lo, zkhip_prover** out) {
+  return prover_new_impl(crs_slice, cs, true, a_lo, h_lo, l_lo, out);
 }
 
 void zkhip_prover_free(zkhip_prover* p) {
@@ -863,8 +888,15 @@ int zkhip_prover_prove_dev(zkhip_prover* p, const void* d_z, const uint64_t r_m[
   if (!d_z) return fail(ZKHIP_ERR_ARG, "null pointer");
   return prover_prove_impl(p, nullptr, (const uint64_t*)d_z, r_m, s_m, proof_affine);
 }
+int zkhip_prover_prove_partial(zkhip_prover* p, const uint64_t* z, uint64_t sums_jac[180]) {
+  if (!p || !z || !sums_jac) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(p);
+  std::lock_guard<std::mutex> lk(p->mu);
+  return prove_partial(p->ps, p->crs, p->rd, z, p->a_lo, p->h_lo, p->l_lo, sums_jac);
+}
 static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t* d_z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]) {
   if (!p || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (p->slice) return fail(ZKHIP_ERR_STATE, "this prover holds a slice of the key: zkhip_prover_prove_partial");
   BIND(p);                                    // called from pipeline / application threads that never ran zkhip_init
   std::lock_guard<std::mutex> lk(p->mu);
   uint64_t sums[180];
@@ -1116,12 +1148,21 @@ void zkhip_keypair_free(zkhip_keypair* kp) { delete kp; }
 int zkhip_last_accumulate_interval(float out_ms[2]) {
   const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();
   if (!out_ms || dev < 0) return ZKHIP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g.dev[dev].mu);
   out_ms[0] = g.dev[dev].ps.last_acc_interval[0]; out_ms[1] = g.dev[dev].ps.last_acc_interval[1];
   return ZKHIP_OK;
 }
 float zkhip_last_accumulate_ms(void) {
   const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();       // where this thread's last MSM / proof ran
-  return dev >= 0 ? g.dev[dev].ps.last_accumulate_ms : 0.f;
+  if (dev < 0) return 0.f;
+  std::lock_guard<std::mutex> lk(g.dev[dev].mu);
+  return g.dev[dev].ps.last_accumulate_ms;
+}
+// The origin of zkhip_last_accumulate_interval's time base is recorded again, now: the values are FLOAT milliseconds since the origin,
+// so a caller that compares intervals (bench.py's union of overlapping launches) re-bases at the start of its timed region.
+int zkhip_reset_time_base(void) {
+  BIND_CUR();
+  return msm_time_base_reset();
 }
 
 // ---- witness generation on the GPU (witness.hip) ---------------------------------------------------------------------------
@@ -1304,5 +1345,131 @@ int zkhip_jac_add(const uint64_t a[36], const uint64_t b[36], uint64_t out[36]) 
   r.X.to_limbs(out); r.Y.to_limbs(out + 12); r.Z.to_limbs(out + 24);
   return ZKHIP_OK;
 }
+
+// ---- handle-owned MSM streams ---------------------------------------------------------------------------------------------
+// zkhip_msm_submit / collect above address eight PROCESS-WIDE slot numbers: two threads streaming MSMs on one device collide.  A
+// zkhip_msm_stream owns its contexts (streams, work space), like a zkhip_prover: any number of them run side by side.
+struct zkhip_msm_stream {
+  int device = 0;
+  const zkhip_bases* bases = nullptr;
+  int depth = 0;
+  std::vector<MsmCtx> ctx;
+  std::vector<char> ready;
+  std::vector<uint64_t> ticket_of;       // per slot: the ticket in flight there, 0 = free
+  std::vector<void*> d_stage;            // per slot: device copy of host scalars (zkhip_msm_stream_submit_host)
+  std::vector<size_t> stage_cap;
+  uint64_t next_ticket = 1;
+  float last_accumulate_ms = 0.f, last_interval[2] = {0.f, 0.f};
+  std::mutex mu;
+};
+
+int zkhip_msm_stream_new(const zkhip_bases* bases, int depth, zkhip_msm_stream** out) {
+  if (!bases || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (depth < 1 || depth > 16) return fail(ZKHIP_ERR_ARG, "depth must be in [1, 16]");
+  BIND(bases);
+  zkhip_msm_stream* st = new zkhip_msm_stream();
+  st->device = bases->device; st->bases = bases; st->depth = depth;
+  st->ctx.resize(depth); st->ready.assign(depth, 0); st->ticket_of.assign(depth, 0);
+  st->d_stage.assign(depth, nullptr); st->stage_cap.assign(depth, 0);
+  for (auto& c : st->ctx) memset(&c, 0, sizeof c);
+  *out = st;
+  return ZKHIP_OK;
+}
+
+void zkhip_msm_stream_free(zkhip_msm_stream* st) {
+  if (!st) return;
+  (void)bind_dev(st->device);
+  for (int k = 0; k < st->depth; k++) {
+    if (st->ready[k]) {
+      if (st->ctx[k].pending) { uint64_t drop[36]; (void)msm_finish(&st->ctx[k], drop); }      // never free work space under a running launch
+      msm_plan_free(&st->ctx[k]);
+    }
+    if (st->d_stage[k]) (void)hipFree(st->d_stage[k]);
+  }
+  delete st;
+}
+
+static int msm_stream_submit_impl(zkhip_msm_stream* st, size_t offset, const void* d_scalars, const uint64_t* h_scalars, size_t len,
+                                  int scalars_montgomery, uint64_t* ticket) {
+  if (!st || !ticket || (len && !d_scalars && !h_scalars)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(st);
+  std::lock_guard<std::mutex> lk(st->mu);
+  const zkhip_bases* b = st->bases;
+  if (offset > b->len || len > b->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
+  int slot = -1;
+  for (int k = 0; k < st->depth; k++) if (!st->ticket_of[k]) { slot = k; break; }
+  if (slot < 0) return fail(ZKHIP_ERR_STATE, "every slot of this stream is in flight: collect a result first");
+  MsmCtx* cx = &st->ctx[slot];
+  bool rdy = st->ready[slot] != 0;
+  int rc = ensure_ctx(cx, &rdy, len ? len : 1, b->table_c, 1, b->table_naf);
+  st->ready[slot] = rdy ? 1 : 0;
+  if (rc != ZKHIP_OK) return rc;
+  if (h_scalars && len) {
+    // host scalars: one asynchronous copy in front of the MSM's kernels, on the context's own stream (truly asynchronous from pinned
+    // memory - zkhip_host_alloc -, staged by the runtime from pageable memory); the copies of the MSMs in flight overlap their kernels
+    if (st->stage_cap[slot] < len) {
+      if (st->d_stage[slot]) { (void)hipFree(st->d_stage[slot]); st->d_stage[slot] = nullptr; st->stage_cap[slot] = 0; }
+      API_HIP(hipMalloc(&st->d_stage[slot], len * 48));
+      st->stage_cap[slot] = len;
+    }
+    API_HIP(hipMemcpyAsync(st->d_stage[slot], h_scalars, len * 48, hipMemcpyHostToDevice, cx->stream));
+    d_scalars = st->d_stage[slot];
+  }
+  rc = msm_launch(cx, b->d_pts + offset, b->d_inf ? b->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len, scalars_montgomery, b->len);
+  if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", cx->errbuf); return rc; }
+  st->ticket_of[slot] = st->next_ticket;
+  *ticket = st->next_ticket++;
+  return ZKHIP_OK;
+}
+int zkhip_msm_stream_submit(zkhip_msm_stream* st, size_t offset, const void* d_scalars, size_t len, int scalars_montgomery, uint64_t* ticket) {
+  return msm_stream_submit_impl(st, offset, d_scalars, nullptr, len, scalars_montgomery, ticket);
+}
+int zkhip_msm_stream_submit_host(zkhip_msm_stream* st, size_t offset, const uint64_t* scalars, size_t len, int scalars_montgomery, uint64_t* ticket) {
+  return msm_stream_submit_impl(st, offset, nullptr, scalars, len, scalars_montgomery, ticket);
+}
+
+int zkhip_msm_stream_collect(zkhip_msm_stream* st, uint64_t ticket, uint64_t out_jac[36]) {
+  if (!st || !out_jac) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(st);
+  std::lock_guard<std::mutex> lk(st->mu);
+  int slot = -1;
+  for (int k = 0; k < st->depth; k++) {
+    if (!st->ticket_of[k]) continue;
+    if (ticket ? st->ticket_of[k] == ticket : (slot < 0 || st->ticket_of[k] < st->ticket_of[slot])) slot = k;    // ticket 0: the oldest
+  }
+  if (slot < 0) return fail(ZKHIP_ERR_STATE, ticket ? "no such ticket in flight on this stream" : "nothing in flight on this stream");
+  MsmCtx* cx = &st->ctx[slot];
+  st->ticket_of[slot] = 0;                  // (msm_finish clears `pending` whatever it returns: the slot is free again)
+  int rc = msm_finish(cx, out_jac);
+  if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", cx->errbuf); return rc; }
+  st->last_accumulate_ms = cx->last_accumulate_ms; st->last_interval[0] = cx->last_acc_begin_ms; st->last_interval[1] = cx->last_acc_end_ms;
+  return ZKHIP_OK;
+}
+float zkhip_msm_stream_last_accumulate_ms(zkhip_msm_stream* st) {
+  if (!st) return 0.f;
+  std::lock_guard<std::mutex> lk(st->mu);
+  return st->last_accumulate_ms;
+}
+int zkhip_msm_stream_last_accumulate_interval(zkhip_msm_stream* st, float out_ms[2]) {
+  if (!st || !out_ms) return fail(ZKHIP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> lk(st->mu);
+  out_ms[0] = st->last_interval[0]; out_ms[1] = st->last_interval[1];
+  return ZKHIP_OK;
+}
+
+// pinned host memory for callers without a HIP runtime of their own (source of zkhip_msm_stream_submit_host's asynchronous copies)
+int zkhip_host_alloc(size_t bytes, void** out) {
+  BIND_CUR();
+  if (!out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  API_HIP(hipHostMalloc(out, bytes ? bytes : 1));
+  return ZKHIP_OK;
+}
+int zkhip_host_free(void* p) {
+  if (p) API_HIP(hipHostFree(p));
+  return ZKHIP_OK;
+}
+
+// (multi_device.cpp: a worker thread's failure text travels to the thread that called the library)
+void zkhip_internal_set_error(const char* msg) { snprintf(t_err, sizeof t_err, "%s", msg ? msg : ""); }
 
 }  // extern "C"

@@ -196,6 +196,7 @@ class ApplicationPool:
         self.name, self.vk_json, self.num_proofs = name, vk_json, num_proofs
         self.vk_limbs = E.nested_verification_key_from_json(vk_json)
         self._heap, self._order = [], itertools.count()
+        self.quarantined = []          # transactions of batches that failed for good (see requeue / drop)
 
     def add_tx(self, tx):
         heapq.heappush(self._heap, (-tx["fee_in_wei"], next(self._order), tx))
@@ -213,21 +214,55 @@ class ApplicationPool:
     def get_next_batch(self):
         return [e[2] for e in self.pop_batch_entries()]
 
-    def requeue(self, entries):
-        """A batch that was popped but not proved (prover or GPU error): back into the queue with its fee order and arrival order."""
+    def requeue(self, entries, max_failures=3):
+        """A batch that was popped but not proved because of a TRANSIENT prover / device error goes back into the queue with its fee
+        order and arrival order - at most `max_failures` times per transaction: after that it is set aside (`quarantined`) like a
+        batch that failed deterministically, so that one poisonous high-fee transaction cannot block the pool for ever.
+        Returns the number of transactions that went back."""
+        back = 0
         for e in entries:
-            heapq.heappush(self._heap, e)
+            e[2]["failures"] = e[2].get("failures", 0) + 1
+            if e[2]["failures"] >= max_failures:
+                self.quarantined.append(e[2])
+            else:
+                heapq.heappush(self._heap, e)
+                back += 1
+        return back
+
+    def drop(self, entries):
+        """A batch whose proof failed for a reason that will not go away (malformed or degenerate input): the reference loses it
+        (aggregator_server.cpp:283-340 pops the batch before proving and never puts it back); kept aside for the operator."""
+        self.quarantined.extend(e[2] for e in entries)
 
 
 # ---------------------------------------------------------------------------------------------- provers
+class TransientProverError(RuntimeError):
+    """A prover failure that says nothing about the batch (lost device, exhausted memory): the batch may be retried."""
+
+
+def is_transient_failure(e):
+    """Which prover failures keep a batch in its pool: the library's HIP / state / device codes and TransientProverError.
+    ValueError (input checks), ZKHIP_ERR_ARG (witness generation met a degenerate point, sizes do not match) and everything
+    unknown are properties of the batch."""
+    if isinstance(e, TransientProverError):
+        return True
+    return getattr(e, "code", None) in (-2, -3, -4)                # ZKHIP_ERR_NO_DEVICE, ZKHIP_ERR_HIP, ZKHIP_ERR_STATE
+
+
 class GpuProver:
     """The wrapping prover behind the service: circuit, keypair (file or fresh setup), HBM-resident key, streaming pipeline."""
     snark_name = "GROTH16"
 
-    def __init__(self, keypair_file=None, device=0, gpu_slots=24, witness_workers=10, gpu_witness=False):
+    def __init__(self, keypair_file=None, device=0, gpu_slots=24, witness_workers=10, gpu_witness=False, devices=None):
+        """devices: the GPUs of the node this ONE server process drives (the reference server is one process that owns its prover:
+        aggregator_server.cpp:106-118, 390-416) - a resident copy of the key and a streaming pipeline on each, behind a dispatcher
+        (zkhip_dispatcher_*); an index may repeat (two contexts on one GPU).  None / one entry: that GPU alone (`device`)."""
         from . import zkhip
         self.zk = zkhip
-        self.gpu_slots = gpu_slots
+        devices = [int(d) for d in devices] if devices else [int(device)]
+        device = devices[0]
+        self.devices = devices
+        self.gpu_slots = gpu_slots * len(devices)        # (the handler pool is as deep as the node has proofs in flight)
         zkhip.init(device)
         self.agg = zkhip.AggregatorCircuit(BATCH_SIZE, NUM_INPUTS_PER_NESTED_PROOF)
         desc = zkhip.r1cs_desc_from_aggregator(self.agg)
@@ -244,8 +279,14 @@ class GpuProver:
             raise ValueError("invalid VK")
         # a server proves a stream of batches: the larger kind of window table pays.  The option travels with
         # THIS key (zkhip_key_opts), not with the process: another key loaded on another thread keeps its own.
-        self.crs = self.kp.upload_crs(zkhip.key_opts(table_naf=True if os.environ.get("ZKHIP_TABLE_NAF") is None else None))
-        self.pipe = zkhip.AggregatorPipeline(self.agg, self.crs, gpu_slots=gpu_slots, witness_workers=witness_workers, gpu_witness=gpu_witness)
+        opts = zkhip.key_opts(table_naf=True if os.environ.get("ZKHIP_TABLE_NAF") is None else None)
+        if len(devices) > 1:
+            self.crs = None                               # (the dispatcher uploads a copy of the key to every entry of the list)
+            self.pipe = zkhip.AggregatorDispatcher(self.agg, self.kp, devices, opts, gpu_slots=gpu_slots, witness_workers=witness_workers,
+                                                   gpu_witness=gpu_witness)
+        else:
+            self.crs = self.kp.upload_crs(opts)
+            self.pipe = zkhip.AggregatorPipeline(self.agg, self.crs, gpu_slots=gpu_slots, witness_workers=witness_workers, gpu_witness=gpu_witness)
 
     def verification_key_json(self):
         return E.verification_key_to_json(self.vk)
@@ -267,7 +308,10 @@ class GpuProver:
         return E.extended_proof_to_json(proof, prim)
 
     def close(self):
-        self.pipe.free(); self.crs.free(); self.kp.free(); self.agg.free()
+        self.pipe.free()
+        if self.crs is not None:
+            self.crs.free()
+        self.kp.free(); self.agg.free()
 
 
 # ---------------------------------------------------------------------------------------------- service
@@ -345,10 +389,16 @@ class AggregatorService:
                 vk_limbs = pool.vk_limbs
             try:
                 ep = self.prover.prove(vk_limbs, [tx["proof"] for tx in batch], [tx["inputs"] for tx in batch])
-            except Exception:
-                # the batch was taken out of the pool under the lock; a prover / GPU error must not lose the transactions in it
+            except Exception as e:                                                        # noqa: BLE001
+                # The batch was taken out of the pool under the lock.  A TRANSIENT failure (the device, the HIP runtime, the
+                # library's state) must not lose the transactions in it: they go back in their old order, a bounded number of
+                # times.  Anything else is a property of the batch (a degenerate nested proof, a bad input count): putting it back
+                # at the head of a fee-ordered queue would make every later call pop it and fail again - the reference drops it.
                 with self.mu:
-                    pool.requeue(entries)
+                    if is_transient_failure(e):
+                        pool.requeue(entries)
+                    else:
+                        pool.drop(entries)
                 raise
             resp = message_class("zecale_proto.AggregatedTransaction")()
             resp.application_name = name
@@ -454,10 +504,13 @@ def main(argv=None):
                     help="file to load the keypair from (generated and written there when missing)")
     ap.add_argument("--endpoint", default=DEFAULT_ENDPOINT)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--devices", default="", help="comma list of GPUs this one process drives (replicas behind a dispatcher), e.g. 0,1,2,3,4,5,6,7; "
+                                                  "overrides --device")
     ap.add_argument("--gpu-witness", action="store_true", help="generate the assignments on the GPU (fewer host cores per GPU)")
     args = ap.parse_args(argv)
     print("[INFO] Init params of both curves")
-    prover = GpuProver(args.keypair, device=args.device, gpu_witness=args.gpu_witness)
+    prover = GpuProver(args.keypair, device=args.device, gpu_witness=args.gpu_witness,
+                       devices=[int(x) for x in args.devices.split(",")] if args.devices else None)
     print("[INFO] Circuit has %d constraints" % prover.agg.num_constraints)
     print("[INFO] Setup successful, starting the server...")
     server, port, _ = serve(prover, args.endpoint)

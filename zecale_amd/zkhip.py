@@ -29,11 +29,20 @@ EXPORTS = [
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
     "zkhip_last_accumulate_interval", "zkhip_crs_upload_ex", "zkhip_crs_upload_slice_ex", "zkhip_bases_precompute_ex", "zkhip_crs_table_kind", "zkhip_crs_finite_terms",
+    "zkhip_reset_time_base", "zkhip_host_alloc", "zkhip_host_free",
+    "zkhip_msm_stream_new", "zkhip_msm_stream_submit", "zkhip_msm_stream_submit_host", "zkhip_msm_stream_collect", "zkhip_msm_stream_last_accumulate_ms",
+    "zkhip_msm_stream_last_accumulate_interval", "zkhip_msm_stream_free", "zkhip_prover_new_slice", "zkhip_prover_prove_partial",
+    "zkhip_dispatcher_new", "zkhip_dispatcher_size", "zkhip_dispatcher_submit", "zkhip_dispatcher_wait", "zkhip_dispatcher_stats", "zkhip_dispatcher_free",
+    "zkhip_multi_prover_new", "zkhip_multi_prover_size", "zkhip_multi_prover_prove", "zkhip_multi_prover_timings", "zkhip_multi_prover_free",
 ]
 
 
 class ZkhipError(RuntimeError):
-    pass
+    """A failed C ABI call.  `code` is the library's return code (include/zkhip.h: ZKHIP_ERR_ARG -1, _NO_DEVICE -2, _HIP -3, _STATE -4)."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 c_u64p_t = ctypes.POINTER(ctypes.c_uint64)
@@ -134,6 +143,31 @@ def load():
     lib.zkhip_prover_free.argtypes = [ctypes.c_void_p]
     lib.zkhip_prover_last_accumulate_ms.argtypes = [ctypes.c_void_p]
     lib.zkhip_prover_last_accumulate_ms.restype = ctypes.c_float
+    vpp = ctypes.POINTER(ctypes.c_void_p)
+    lib.zkhip_host_alloc.argtypes = [ctypes.c_size_t, vpp]
+    lib.zkhip_host_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_msm_stream_new.argtypes = [ctypes.c_void_p, ctypes.c_int, vpp]
+    lib.zkhip_msm_stream_submit.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, c_u64p]
+    lib.zkhip_msm_stream_submit_host.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, c_u64p]
+    lib.zkhip_msm_stream_collect.argtypes = [ctypes.c_void_p, ctypes.c_uint64, c_u64p]
+    lib.zkhip_msm_stream_last_accumulate_ms.argtypes = [ctypes.c_void_p]
+    lib.zkhip_msm_stream_last_accumulate_ms.restype = ctypes.c_float
+    lib.zkhip_msm_stream_last_accumulate_interval.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.zkhip_msm_stream_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_prover_new_slice.argtypes = [ctypes.c_void_p, ctypes.POINTER(R1csDesc), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vpp]
+    lib.zkhip_prover_prove_partial.argtypes = [ctypes.c_void_p, c_u64p, c_u64p]
+    lib.zkhip_dispatcher_new.argtypes = [ctypes.c_void_p, ctypes.POINTER(CrsDesc), ctypes.POINTER(KeyOpts), ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_uint, vpp]
+    lib.zkhip_dispatcher_size.argtypes = [ctypes.c_void_p]
+    lib.zkhip_dispatcher_submit.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p, c_u64p, c_u64p]
+    lib.zkhip_dispatcher_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint64, c_u64p, c_u64p]
+    lib.zkhip_dispatcher_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.zkhip_dispatcher_free.argtypes = [ctypes.c_void_p]
+    lib.zkhip_multi_prover_new.argtypes = [ctypes.POINTER(CrsDesc), ctypes.POINTER(R1csDesc), ctypes.POINTER(KeyOpts), ctypes.POINTER(ctypes.c_int), ctypes.c_int, vpp]
+    lib.zkhip_multi_prover_size.argtypes = [ctypes.c_void_p]
+    lib.zkhip_multi_prover_prove.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
+    lib.zkhip_multi_prover_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+    lib.zkhip_multi_prover_free.argtypes = [ctypes.c_void_p]
     lib.zkhip_aggregator_pipeline_new.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.zkhip_aggregator_pipeline_submit.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p, c_u64p, ctypes.POINTER(ctypes.c_uint64)]
     lib.zkhip_aggregator_pipeline_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint64, c_u64p, c_u64p]
@@ -145,7 +179,7 @@ def load():
 def _check(rc):
     if rc != 0:
         lib = load()
-        raise ZkhipError(f"zkhip error {rc} ({lib.zkhip_strerror(rc).decode()}): {lib.zkhip_last_error().decode()}")
+        raise ZkhipError(f"zkhip error {rc} ({lib.zkhip_strerror(rc).decode()}): {lib.zkhip_last_error().decode()}", rc)
 
 
 def _p(a):
@@ -251,6 +285,62 @@ class Bases:
         out = np.zeros(36, dtype=np.uint64)
         _check(load().zkhip_msm_dev(self.handle, offset, ctypes.c_void_p(dev_ptr), n, int(montgomery), _p(out)))
         return out
+
+
+class MsmStream:
+    """A stream of MSMs over one resident base set behind a handle (zkhip_msm_stream_*): `depth` MSMs in flight on contexts the
+    stream owns.  submit() returns a ticket, collect(ticket) the Jacobian sum (ticket 0 / None: the oldest in flight)."""
+
+    def __init__(self, bases, depth=8):
+        h = ctypes.c_void_p()
+        _check(load().zkhip_msm_stream_new(bases.handle, depth, ctypes.byref(h)))
+        self.handle, self.depth, self._bases = h, depth, bases
+
+    def submit(self, dev_ptr, n, offset=0, montgomery=True):
+        t = ctypes.c_uint64(0)
+        _check(load().zkhip_msm_stream_submit(self.handle, offset, ctypes.c_void_p(dev_ptr), n, int(montgomery), ctypes.byref(t)))
+        return t.value
+
+    def submit_host(self, host_ptr, n, offset=0, montgomery=True):
+        """host_ptr: address of n x 6 u64 in host memory (a numpy array's ctypes.data, or a PinnedBuffer's ptr); it must stay valid
+        until the ticket is collected."""
+        t = ctypes.c_uint64(0)
+        _check(load().zkhip_msm_stream_submit_host(self.handle, offset, ctypes.c_void_p(host_ptr), n, int(montgomery), ctypes.byref(t)))
+        return t.value
+
+    def collect(self, ticket=None):
+        out = np.zeros(36, dtype=np.uint64)
+        _check(load().zkhip_msm_stream_collect(self.handle, int(ticket or 0), _p(out)))
+        return out
+
+    def last_accumulate_ms(self):
+        return float(load().zkhip_msm_stream_last_accumulate_ms(self.handle))
+
+    def last_accumulate_interval(self):
+        t = (ctypes.c_float * 2)()
+        _check(load().zkhip_msm_stream_last_accumulate_interval(self.handle, t))
+        return float(t[0]), float(t[1])
+
+    def free(self):
+        if self.handle:
+            load().zkhip_msm_stream_free(self.handle)
+            self.handle = None
+
+
+class PinnedBuffer:
+    """Pinned host memory owned by the library (zkhip_host_alloc) holding a copy of `host_array`: the source of asynchronous uploads."""
+
+    def __init__(self, host_array):
+        a = np.ascontiguousarray(host_array)
+        p = ctypes.c_void_p()
+        _check(load().zkhip_host_alloc(a.nbytes, ctypes.byref(p)))
+        self.ptr, self.nbytes = p.value, a.nbytes
+        ctypes.memmove(self.ptr, a.ctypes.data, a.nbytes)
+
+    def free(self):
+        if self.ptr:
+            load().zkhip_host_free(ctypes.c_void_p(self.ptr))
+            self.ptr = None
 
 
 class DeviceBuffer:
@@ -646,6 +736,84 @@ class AggregatorPipeline:
             self.handle = None
 
 
+def _int_list(devices):
+    d = [int(x) for x in devices]
+    return (ctypes.c_int * len(d))(*d), len(d)
+
+
+class AggregatorDispatcher:
+    """The GPUs of a node behind ONE streaming prover (zkhip_dispatcher_*): a resident copy of the key and a pipeline per entry of
+    `devices` (an index may repeat: two contexts on one GPU), every batch goes to the entry with the fewest batches outstanding.
+    Same submit / wait as AggregatorPipeline.  keypair: a Keypair (its proving half is uploaded to every entry)."""
+
+    def __init__(self, agg, keypair, devices, opts=None, gpu_slots=24, witness_workers=10, gpu_witness=False):
+        d = CrsDesc()
+        _check(load().zkhip_keypair_crs_desc(keypair.handle, ctypes.byref(d)))
+        arr, n = _int_list(devices)
+        h = ctypes.c_void_p()
+        _check(load().zkhip_dispatcher_new(agg.handle, ctypes.byref(d), ctypes.byref(opts) if opts is not None else None, arr, n,
+                                           gpu_slots, witness_workers, 1 if gpu_witness else 0, ctypes.byref(h)))
+        self.handle, self._agg, self._kp = h, agg, keypair
+        self.n_primary = agg.num_primary_inputs()
+        self.size = n
+
+    def submit(self, nested_vk, nested_proofs, nested_inputs, r, s):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+        vk, pr, inp, r, s = c(nested_vk), c(nested_proofs), c(nested_inputs), c(r), c(s)
+        k, npf = self._agg.inputs_per_nested_proof, self._agg.num_proofs
+        assert vk.size == 60 + 12 * (k + 1) and pr.size == 48 * npf and inp.size == 6 * k * npf and r.size == 6 and s.size == 6
+        t = ctypes.c_uint64(0)
+        _check(load().zkhip_dispatcher_submit(self.handle, _p(vk), _p(pr), _p(inp), _p(r), _p(s), ctypes.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        prim = np.zeros((self.n_primary, 6), dtype=np.uint64)
+        proof = np.zeros(72, dtype=np.uint64)
+        _check(load().zkhip_dispatcher_wait(self.handle, ticket, _p(prim), _p(proof)))
+        return prim, proof
+
+    def stats(self):
+        """Batches handed to each entry of the device list so far."""
+        out = (ctypes.c_size_t * self.size)()
+        _check(load().zkhip_dispatcher_stats(self.handle, out))
+        return list(out)
+
+    def free(self):
+        if self.handle:
+            load().zkhip_dispatcher_free(self.handle)
+            self.handle = None
+
+
+class MultiProver:
+    """One proof over a key partitioned across `devices` (zkhip_multi_prover_*): a slice and a prover instance per entry, host
+    threads side by side, partial sums added on the host, one tail.  The proof equals the whole-key proof limb for limb."""
+
+    def __init__(self, keypair, r1cs_desc, devices, opts=None):
+        d = CrsDesc()
+        _check(load().zkhip_keypair_crs_desc(keypair.handle, ctypes.byref(d)))
+        arr, n = _int_list(devices)
+        h = ctypes.c_void_p()
+        _check(load().zkhip_multi_prover_new(ctypes.byref(d), ctypes.byref(r1cs_desc), ctypes.byref(opts) if opts is not None else None, arr, n, ctypes.byref(h)))
+        self.handle, self._kp, self._desc, self.size = h, keypair, r1cs_desc, n
+
+    def prove(self, z, r, s):
+        z = np.ascontiguousarray(z, dtype=np.uint64).reshape(-1, 6)
+        r, s = (np.ascontiguousarray(a, dtype=np.uint64).reshape(6) for a in (r, s))
+        out = np.zeros(72, dtype=np.uint64)
+        _check(load().zkhip_multi_prover_prove(self.handle, _p(z), _p(r), _p(s), _p(out)))
+        return out
+
+    def timings(self):
+        t = (ctypes.c_double * 3)()
+        _check(load().zkhip_multi_prover_timings(self.handle, t))
+        return dict(zip(["slowest_slice", "host_additions", "host_tail"], list(t)))
+
+    def free(self):
+        if self.handle:
+            load().zkhip_multi_prover_free(self.handle)
+            self.handle = None
+
+
 class Keypair:
     """Groth16 keypair from a trusted setup on the GPU (mirror of wsnark::generate_setup / keypair)."""
 
@@ -752,6 +920,11 @@ def jac_add(a, b):
 
 def last_accumulate_ms():
     return float(load().zkhip_last_accumulate_ms())
+
+
+def reset_time_base():
+    """Record the origin of the accumulate intervals again (float milliseconds lose resolution far from their origin)."""
+    _check(load().zkhip_reset_time_base())
 
 
 def last_accumulate_interval():
