@@ -305,3 +305,24 @@ def test_table_2_22_closed_form(zk, oracle_lib):
     exp = O.jac_to_affine(O.scalar_mul(g, np.array(R.int_to_limbs(R.to_mont(dot, R.R_MOD, 6), 6), dtype=np.uint64)))
     assert (got == exp).all()
     b.free()
+
+
+def test_headline_2_20_uniform_scalars_eight_in_flight_against_the_oracle(zk, oracle_lib):
+    """BASELINE configs[1] as bench.py's headline runs it (this comparison lived in bench.py only): 2^20 bases with
+    their window table resident, scalars UNIFORM in [0, r) as Montgomery residues, EIGHT MSMs in flight on a handle-owned stream
+    (zkhip_msm_stream_*), every result compared with ONE libff-shaped multi_exp of the C oracle at the full size."""
+    O = oracle_lib
+    n = 1 << 20
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(0x5EED, n), montgomery=False)
+    scal = random_fr_uniform(0xABC0, n)
+    exp = O.jac_to_affine(O.msm(bases, scal))
+    b = zk.Bases.upload(bases).precompute()
+    assert b.table_window == 20
+    dev = zk.DeviceBuffer(scal)
+    stream = zk.MsmStream(b, depth=8)
+    tickets = [stream.submit(dev.ptr, n) for _ in range(8)]
+    with pytest.raises(zk.ZkhipError):
+        stream.submit(dev.ptr, n)
+    for t in tickets:
+        assert (zk.jac_to_affine(stream.collect(t)) == exp).all()
+    stream.free(); dev.free(); b.free()

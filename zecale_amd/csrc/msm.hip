@@ -1487,7 +1487,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   if (ctx->acc_gate) HIP_TRY(hipStreamWaitEvent(st, ctx->acc_gate, 0));
   if (ctx->aff_levels == 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
   const uint32_t* acc_entries = dense ? nullptr : ctx->entries;
-  static const int acc_prio = env_int("ZKHIP_ACC_PRIO", 0, 0, 1);
+  static const int acc_prio = env_int("ZKHIP_ACC_PRIO", 1, 0, 1);     // (see k_accumulate: the wave that is behind asks for priority; 0 = the arbiter's own order)
   if (ctx->K == 1 || dense)
     hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off, cur_cnt,
                        (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio);
