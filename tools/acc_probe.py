@@ -38,23 +38,29 @@ def read_dump(path):
 
 
 def slice_stats(cnt, S_host, T, tight):
-    """Replays the kernel's slicing on the host: runs opened per slice, F pieces."""
+    """Replays the kernel's slicing on the host (slices of equal WEIGHT: 1 for the first entry of a bucket, 8 for every other one):
+    runs opened, F pieces, additions, iterations of a wave."""
+    cnt = cnt.astype(np.int64)
     M = int(cnt.sum())
-    S = S_host
-    if tight:
-        s_ = -(-M // T)
-        S = min(S_host, 16) if s_ < 16 else s_
-    off = np.concatenate([[0], np.cumsum(cnt, dtype=np.int64)])[:-1]
     ne = cnt > 0
-    first = off[ne] // S                     # slice in which the bucket starts
-    last = (off[ne] + cnt[ne] - 1) // S
-    pieces = last - first + 1                # runs this bucket contributes (one per slice it touches)
-    lanes = -(-M // S)
+    w = np.where(ne, 8 * cnt - 7, 0)
+    G = int(w.sum())
+    a_host = 8 * S_host
+    A = a_host
+    if tight:
+        a = (G + T) // T
+        A = min(a_host, 128) if a < 128 else min(a, a_host)
+    goff = (np.cumsum(w) - w)[ne]
+    c = cnt[ne]
+    t_first = goff // A
+    t_last = np.where(c >= 2, (goff + 1 + 8 * (c - 2)) // A, t_first)
+    pieces = t_last - t_first + 1
     runs = int(pieces.sum())
     fpieces = pieces - 1
-    return dict(M=M, S=S, lanes=lanes, runs=runs, runs_per_slice=runs / max(lanes, 1),
+    lanes = (G - 1) // A + 1 if G else 0
+    return dict(M=M, S=A / 8.0, lanes=lanes, runs=runs, runs_per_slice=runs / max(lanes, 1),
                 cut_buckets=int((fpieces > 0).sum()), short=int(((fpieces >= 2) & (fpieces <= 4)).sum()), long=int((fpieces > 4).sum()),
-                additions=M - runs)
+                additions=M - runs, iterations=-(-A // 8))
 
 
 def main():
@@ -127,7 +133,7 @@ def main():
                         wave_us_p99=round(float(np.percentile(dur, 99)), 1), wave_us_max=round(float(dur.max()), 1),
                         begin_us_p50=round(float(np.percentile(beg, 50)), 1), begin_us_max=round(float(beg.max()), 1),
                         end_us_p01=round(float(np.percentile(end, 1)), 1), end_us_p50=round(float(np.percentile(end, 50)), 1), end_us_max=round(float(end.max()), 1),
-                        us_per_iteration_p50=round(float(np.percentile(dur, 50)) / st["S"], 2))
+                        us_per_iteration_p50=round(float(np.percentile(dur, 50)) / st["iterations"], 2), iterations=st["iterations"])
         if args.prove_stream:
             import threading
             saved = os.environ.pop("ZKHIP_DEBUG_DUMP", None)

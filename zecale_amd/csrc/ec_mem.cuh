@@ -177,6 +177,10 @@ __device__ __forceinline__ void lds_st_packed(uint32_t* base, const Fq& v) {   /
 // rare same-x path.  Eight single products in the rolled loop (one multiplier body, one squarer body), then
 // Y3 = R (Q - X3) + (-Y1) PPP as ONE dual product with one Montgomery reduction (fp_mul2): 13,149 v_mad_u64_u32 per addition
 // (6 x 1,458 + 2 x 1,107 + 2,187) instead of 13,878, and one lazy subtraction less.  Five field elements live at most.
+// (Prefetching the NEXT addition's point under this one was measured twice and lost twice: carried in registers in round 3 (+30 spilled
+// dwords: 11.5 -> 12.1 ms at 2^20), and in round 4 as three LDS-DMA loads per point - global_load_lds_dword into a scratch row, no
+// destination register - issued after this addition's last gather: 334 -> 325 wrapping proofs/s, 82.6 -> 80.8 Mscalar/s.  The
+// gathers are not what the kernel waits for; the extra requests cost more than the latency they hide.)
 __device__ __forceinline__ bool madd_lds_regy(const XyzzRef& acc, uint32_t* xs, uint32_t* zz, uint32_t* zzz, Fq& ty, const AffPacked* p, bool neg) {
   Fq T0, T1, T2, T3;      // (deliberately not initialised: every one is written by the step before the first that reads it, and zeroing
                           //  them costs 108 moves per addition)

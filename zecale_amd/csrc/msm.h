@@ -48,6 +48,7 @@ struct MsmCtx {
   uint2* pairs;
   size_t hist_len;
   uint32_t *counts, *offsets, *block_tot, *entries;
+  uint32_t* goff;       // slice weights in front of every bucket (nb + 1 values): see k_accumulate
   uint2* fix_list;      // (first, last) F slot of the buckets cut into more than four F pieces (k_accumulate -> k_fixup_fold)
   uint2* fix_short;     // (first F slot, number of F pieces) of the buckets with two to four (k_accumulate -> k_fixup_fold)
   uint32_t *buckets, *segS[2], *segR, *sumR[2], *Rlevels, *colS[2], *hilo;

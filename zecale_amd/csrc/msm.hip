@@ -357,15 +357,48 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ out, co
   for (int k = 0; k < 4; k++) if (base + k < m) out[base + k] += add;
 }
 
-// Bucket accumulation, load-balanced: lane t owns the fixed-size slice [tS, (t+1)S) of the
-// bucket-sorted entry list, whatever buckets it crosses.  A run of entries that covers a whole
-// bucket is accumulated straight into that bucket's slot; a run cut by a slice boundary goes to a
-// per-slice boundary slot (F = the slice starts inside the bucket, L = the slice ends inside it)
-// and k_fixup stitches the pieces.  All slots live in ONE limb-major array (one buffer
-// descriptor): [0, nb) buckets, [nb, nb+T) F slots, [nb+T, nb+2T) L slots.  Every lane performs
-// exactly S point operations, so waves do not wait on their most loaded lane (thread-per-bucket
-// loses ~45 % to the spread of bucket populations).  The array is zero-filled beforehand
-// (all-zero = infinity), so empty buckets need no work.
+// Bucket accumulation, load-balanced: lane t owns a SLICE of the bucket-sorted entry list, whatever buckets it crosses.  A run of
+// entries that covers a whole bucket is accumulated straight into that bucket's slot; a run cut by a slice boundary goes to a
+// per-slice boundary slot (F = the slice starts inside the bucket, L = the slice ends inside it) and k_fixup stitches the pieces.
+// All slots live in ONE limb-major array (one buffer descriptor): [0, nb) buckets, [nb, nb+T) F slots, [nb+T, nb+2T) L slots.
+// Slices have equal WEIGHT, not equal length (round 4): the first entry of a bucket only OPENS a run - loads, no field arithmetic -
+// so it weighs ZK_W_FIRST = 1 where an entry that is ADDED to a running sum weighs ZK_W_NEXT = 8.  Every lane then performs the same
+// number of additions (to within one) and the openings ride along inside the iteration of the addition that follows them; with
+// slices of equal length (rounds 1-3) every opening took a whole iteration of its wave: 7 % of the lane-iterations of a wrapping
+// proof's launch, 5 % at 2^20 terms, did nothing.  (Thread-per-bucket loses ~45 % to the spread of bucket populations.)
+// goff[b] = the weight in front of bucket b (exclusive scan of 8 count - 7 over the non-empty buckets, nb + 1 values); the entry at
+// position p of bucket b starts at weight G(p) = goff[b] for p = offsets[b], goff[b] + 1 + 8 (p - offsets[b] - 1) otherwise; slice t
+// holds the entries with t A <= G(p) < (t + 1) A.  The slot array's ZZ rows are zero-filled beforehand (all-zero ZZ = infinity), so
+// empty buckets need no work.
+#define ZK_W_NEXT 8u
+#define ZK_W_FIRST 1u
+__global__ void __launch_bounds__(256) k_slice_weights(const uint32_t* __restrict__ counts, uint32_t* __restrict__ w, size_t nb) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nb) return;
+  const uint32_t c = i < nb ? counts[i] : 0u;
+  w[i] = c ? ZK_W_NEXT * c - (ZK_W_NEXT - ZK_W_FIRST) : 0u;
+}
+// first position p with G(p) >= x (M if there is none); *b_out: a bucket at or before the one that holds p
+__device__ __forceinline__ uint32_t slice_pos(const uint32_t* __restrict__ goff, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                              uint32_t nb, uint32_t M, uint64_t x, uint32_t* b_out) {
+  if (x >= (uint64_t)goff[nb]) { *b_out = nb - 1; return M; }
+  uint32_t lo = 0, hi = nb;   // last b with goff[b] <= x: a non-empty bucket (an empty one repeats the value of the next non-empty one)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((uint64_t)goff[mid] <= x) lo = mid; else hi = mid;
+  }
+  *b_out = lo;
+  const uint32_t g = goff[lo], off = offsets[lo], cnt = counts[lo];
+  if ((uint64_t)g >= x) return off;
+  const uint32_t j = (uint32_t)((x - g - ZK_W_FIRST + (ZK_W_NEXT - 1)) / ZK_W_NEXT) + 1u;      // first j >= 1 with g + 1 + 8 (j - 1) >= x
+  return off + (j < cnt ? j : cnt);
+}
+// slice of the entry at position p of bucket b
+__device__ __forceinline__ uint32_t slice_of(const uint32_t* __restrict__ goff, const uint32_t* __restrict__ offsets, uint32_t b, uint32_t p, uint32_t A) {
+  const uint32_t off = offsets[b];
+  const uint64_t G = (uint64_t)goff[b] + (p == off ? 0u : ZK_W_FIRST + (uint64_t)ZK_W_NEXT * (p - off - 1));
+  return (uint32_t)(G / A);
+}
 __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offsets, uint32_t nb, uint32_t pos) {
   // last b with offsets[b] <= pos  (offsets is non-decreasing; empty buckets repeat the next offset)
   uint32_t lo = 0, hi = nb;   // invariant: offsets[lo] <= pos, (hi == nb or offsets[hi] > pos)
@@ -388,33 +421,37 @@ template <int NJ> __device__ __forceinline__ const AffPacked* base_of(const Base
   return r;
 }
 
-// Slice length.  The host sizes the slices for the entries that CAN occur (digit positions x finite bases); the list the sort
-// produced may be shorter - zero digits produce no entry (a boolean-heavy witness: most of them), recoded scalars have fewer
-// digits than positions.  A launch that has the chip to itself (tight != 0) then shortens the slices so that all T lanes of the
-// grid get work: S = ceil(M / T), at least 16, never above the host's S (so the slot array still fits).  A prover that shares the
-// chip with others keeps the longer slices (fewer cut buckets to stitch; the chip is full anyway).
-__device__ __forceinline__ uint32_t slice_len(uint32_t M, uint32_t T, uint32_t S_host, int tight) {
-  if (!tight) return S_host;
-  const uint32_t s_ = (M + T - 1) / T;
-  return s_ < 16u ? (S_host < 16u ? S_host : 16u) : s_;
+// Slice weight A.  The host sizes the slices for the entries that CAN occur (digit positions x finite bases: S_host entries each); the
+// list the sort produced may be shorter - zero digits produce no entry (a boolean-heavy witness: most of them), recoded scalars
+// have fewer digits than positions.  A launch that has the chip to itself (tight != 0) then shrinks the slices so that all T lanes
+// of the grid get work: A = ceil((G + 1) / T), at least 16 additions' worth, never above the host's (so the slot array still fits).
+// A prover that shares the chip with others keeps the longer slices (fewer cut buckets to stitch; the chip is full anyway).
+__device__ __forceinline__ uint32_t slice_weight(uint32_t G, uint32_t T, uint32_t S_host, int tight) {
+  const uint32_t a_host = S_host * ZK_W_NEXT;
+  if (!tight) return a_host;
+  const uint32_t a = (uint32_t)(((uint64_t)G + T) / T), a_min = 16u * ZK_W_NEXT;
+  if (a < a_min) return a_host < a_min ? a_host : a_min;
+  return a < a_host ? a : a_host;
 }
 
 // entries == nullptr: the sorted list IS the dense point array bp.p[0] (the output of the batched-affine levels, k_affine_level):
 // entry k is point k, never negated; a point may be the level encoding of infinity (skipped).
 template <int NJ>
 __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, const uint32_t* __restrict__ entries,
-                                                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ goff,
                                                         uint32_t nb, uint32_t S_host, int tight, uint32_t T, uint32_t* __restrict__ slots,
                                                         uint32_t stride, uint32_t* __restrict__ fix_cnt /* [2] */, uint2* __restrict__ fix_short, uint2* __restrict__ fix_long,
                                                         uint64_t* __restrict__ dbg_times /* null, or [waves][4]: tools/acc_probe.py */, int prio_mode) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t dbg_t0 = dbg_times ? wall_clock64() : 0;
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
-  const uint32_t S = slice_len(M, T, S_host, tight);
-  uint32_t pos0 = t * S;
-  if (t >= T || pos0 >= M) return;
-  uint32_t pos1 = min(pos0 + S, M);
-  uint32_t b = bucket_of(offsets, nb, pos0);
+  const uint32_t A = slice_weight(goff[nb], T, S_host, tight);
+  if (t >= T) return;
+  uint32_t b, b1_;
+  const uint32_t pos0 = slice_pos(goff, offsets, counts, nb, M, (uint64_t)t * A, &b);
+  if (pos0 >= M) return;
+  const uint32_t pos1 = slice_pos(goff, offsets, counts, nb, M, (uint64_t)(t + 1) * A, &b1_);
+  while (offsets[b] + counts[b] <= pos0) b++;          // (the slice may start right behind the last entry of the bucket the search found)
   {
     // A bucket cut by slice boundaries leaves an L piece (slice t0, where it starts) and F pieces in the slices t0+1 .. t1.  The
     // slice that holds the FIRST F piece of a bucket with several of them puts the bucket on a list: (first F slot, number of F
@@ -422,8 +459,9 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
     // wave and list.
     uint32_t span = 0, tF0 = 0;
     if (offsets[b] < pos0) {
-      tF0 = offsets[b] / S + 1;
-      span = (offsets[b] + counts[b] - 1) / S - offsets[b] / S;       // number of F pieces
+      const uint32_t t0 = slice_of(goff, offsets, b, offsets[b], A);
+      tF0 = t0 + 1;
+      span = slice_of(goff, offsets, b, offsets[b] + counts[b] - 1, A) - t0;       // number of F pieces
       if (t != tF0) span = 0;
     }
     const bool is_short = span >= 2 && span <= 4, is_long = span > 4;
@@ -456,48 +494,64 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   Fq ty = fp_zero<FqParams>();     // Y of the running accumulator, carried in registers across the additions of a run
   const bool dense = entries == nullptr;
   uint32_t e_next = dense ? pos0 : entries[pos0];
-  for (uint32_t k = pos0; k < pos1; k++) {
+  // The SIMD's arbiter serves its OLDEST wave first: of the two waves that share a SIMD one runs at full speed and the other on
+  // what is left, so a launch of a single machine fill ends with a third of its time at one wave per SIMD (78 % of the
+  // multiplier's rate; measured: waves 0 .. 1023 of 2,000 end at 1.6 ms, the others at 2.55 ms).  The wave that is behind asks
+  // for the higher priority, by quarters of its slice: both advance together and end together.
+  const uint32_t len4 = (pos1 - pos0) >> 2, q1 = pos0 + len4, q2 = q1 + len4, q3 = q2 + len4;
+  uint32_t k = pos0;
+  while (k < pos1) {
     if (prio_mode) {
-      // The SIMD's arbiter serves its OLDEST wave first: of the two waves that share a SIMD one runs at full speed and the other on
-      // what is left, so a launch of a single machine fill ends with a third of its time at one wave per SIMD (78 % of the
-      // multiplier's rate; measured: waves 0 .. 1023 of 2,000 end at 1.6 ms, the others at 2.55 ms).  The wave that is behind asks
-      // for the higher priority, by quarters of its slice: both advance together and end together.
-      const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((k - pos0) << 2) / S));
-      if (q == 0) __builtin_amdgcn_s_setprio(3);
-      else if (q == 1) __builtin_amdgcn_s_setprio(2);
-      else if (q == 2) __builtin_amdgcn_s_setprio(1);
+      const uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)k), a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1),
+                     a2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q2), a3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q3);
+      if (kk < a1) __builtin_amdgcn_s_setprio(3);
+      else if (kk < a2) __builtin_amdgcn_s_setprio(2);
+      else if (kk < a3) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
-    if (k == bend) {
-      if (!first) {
-        if (!inf) {   // close the finished run
-          mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));
-          mem_st(acc, CY, ty);
+    // ---- run boundaries and run openings: memory operations only.  The lanes that are in the middle of a run wait here for the few
+    // that close one and open the next; whoever leaves this loop with k < pos1 has an addition to do.
+    for (;;) {
+      if (k == bend) {
+        if (!first) {
+          if (!inf) {   // close the finished run
+            mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));
+            mem_st(acc, CY, ty);
+          }
+          b++;
+          while (offsets[b] + counts[b] <= k) b++;     // next non-empty bucket
         }
-        b++;
-        while (offsets[b] + counts[b] <= k) b++;     // next non-empty bucket
+        first = false;
+        bend = offsets[b] + counts[b];
+        const bool starts = (k == offsets[b]), ends = (bend <= pos1);
+        const uint32_t slot = (starts && ends) ? b : (!starts ? nb + t : nb + T + t);
+        acc.voff = slot * 4u;
+        inf = true;
       }
-      first = false;
-      bend = offsets[b] + counts[b];
-      bool starts = (k == offsets[b]), ends = (bend <= pos1);
-      uint32_t slot = (starts && ends) ? b : (!starts ? nb + t : nb + T + t);
-      acc.voff = slot * 4u;
-      inf = true;
+      if (!inf) break;
+      // open a run with entry k (also after a run cancelled to infinity in the middle of its bucket)
+      const uint32_t e = e_next;
+      if (k + 1 < pos1) e_next = dense ? k + 1 : entries[k + 1];
+      const AffPacked* p = (dense ? bp.p[0] : base_of<NJ>(bp, b >> bshift)) + (e & 0x7fffffffu);
+      k++;
+      if (!(dense && p->x[23] == ZK_AFF_INF_WORD)) {               // (dense lists: a pair of the levels below may have cancelled)
+#pragma unroll
+        for (int i = 0; i < 24; i++) xs[i * ZK_LDS_STRIDE] = p->x[i];       // packed words straight into LDS
+        ty = aff_ld_y(p, (e >> 31) != 0);
+        lds_st(zz, fp_one<FqParams>());
+        lds_st(zzz, fp_one<FqParams>());
+        inf = false;
+      }
+      if (k >= pos1 || (k != bend && !inf)) break;
     }
-    uint32_t e = e_next;
+    if (k >= pos1) break;
+    // ---- one addition
+    const uint32_t e = e_next;
     if (k + 1 < pos1) e_next = dense ? k + 1 : entries[k + 1];        // fetched a whole addition ahead of its use
     const AffPacked* p = (dense ? bp.p[0] : base_of<NJ>(bp, b >> bshift)) + (e & 0x7fffffffu);
-    bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_digit_pass drops them)
-    if (dense && p->x[23] == ZK_AFF_INF_WORD) continue;        // a pair of the levels below cancelled
-    if (inf) {
-#pragma unroll
-      for (int i = 0; i < 24; i++) xs[i * ZK_LDS_STRIDE] = p->x[i];       // packed words straight into LDS
-      ty = aff_ld_y(p, neg);
-      lds_st(zz, fp_one<FqParams>());
-      lds_st(zzz, fp_one<FqParams>());
-      inf = false;
-      continue;
-    }
+    const bool neg = (e >> 31) != 0;        // (bases at infinity never reach the entry list: k_digit_pass drops them)
+    k++;
+    if (dense && p->x[23] == ZK_AFF_INF_WORD) continue;
     if (madd_lds_regy(acc, xs, zz, zzz, ty, p, neg)) inf = fp_is_zero_2p(lds_ld(zz));   // same-x path may have cancelled to infinity
   }
   if (!inf) {
@@ -769,15 +823,17 @@ __global__ void __launch_bounds__(256, 2) k_fixup_fold(const uint32_t* __restric
 }
 
 // final stitch: the slice in which a cut bucket STARTS owns it: bucket = L[t0] + F[t0+1] (folded).
-__global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+__global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ goff,
                                                    uint32_t nb, uint32_t S_host, int tight, uint32_t T, uint32_t* __restrict__ slots, uint32_t stride) {
   ADD_SCRATCH_DECL(false);
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // throughput-bound (one addition per slice): one lane each
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
-  const uint32_t S = slice_len(M, T, S_host, tight);
-  uint32_t pos0 = t * S;
-  if (t >= T || pos0 >= M) return;
-  uint32_t pos1 = min(pos0 + S, M);
+  const uint32_t A = slice_weight(goff[nb], T, S_host, tight);
+  if (t >= T) return;
+  uint32_t b0_, b1_;
+  const uint32_t pos0 = slice_pos(goff, offsets, counts, nb, M, (uint64_t)t * A, &b0_);
+  if (pos0 >= M) return;
+  const uint32_t pos1 = slice_pos(goff, offsets, counts, nb, M, (uint64_t)(t + 1) * A, &b1_);
   uint32_t b = bucket_of(offsets, nb, pos1 - 1);
   uint32_t bend = offsets[b] + counts[b];
   if (bend <= pos1 || offsets[b] < pos0) return;      // not cut at this slice's end, or started earlier
@@ -1258,6 +1314,8 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t to
   HIP_TRY(hipMalloc(&ctx->pairs, ((size_t)ctx->Wd * total_terms + 1) * sizeof(uint2)));
   HIP_TRY(hipMalloc(&ctx->counts, nb * 4));
   HIP_TRY(hipMalloc(&ctx->offsets, nb * 4));
+  HIP_TRY(hipMalloc(&ctx->goff, (nb + 1) * 4));
+  if ((size_t)ctx->Wd * total_terms * ZK_W_NEXT >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;      // slice weights are 32-bit
   HIP_TRY(hipMalloc(&ctx->block_tot, ((nb > ctx->hist_len ? nb : ctx->hist_len) / 1024 + 2) * 4));
   HIP_TRY(hipMalloc(&ctx->entries, ((size_t)ctx->Wd * total_terms + 1) * 4));
   // batched-affine levels: bounds on the level sizes, the buffers of their outputs
@@ -1328,7 +1386,7 @@ void msm_plan_free(MsmCtx* ctx) {
                   ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi,
                   ctx->colS[0], ctx->colS[1], ctx->hilo, ctx->pbuf[0], ctx->pbuf[1], ctx->aff_scratch,
                   ctx->lcnt[0], ctx->lcnt[1], ctx->lcnt[2], ctx->lcnt[3], ctx->loff[0], ctx->loff[1], ctx->loff[2], ctx->loff[3],
-                  ctx->fix_list, ctx->fix_short, ctx->dbg_times};
+                  ctx->fix_list, ctx->fix_short, ctx->dbg_times, ctx->goff};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->win_host) (void)hipHostFree(ctx->win_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1459,6 +1517,14 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   }
   const bool dense = ctx->aff_levels > 0;
   if (dense) bp.p[0] = ctx->pbuf[(ctx->aff_levels - 1) & 1];
+  // slice weights: goff = exclusive scan of (8 count - 7) over the non-empty buckets of the list k_accumulate sums (nb + 1 values)
+  {
+    const unsigned gb = nblk(nb + 1, 1024);
+    hipLaunchKernelGGL(k_slice_weights, dim3(nblk(nb + 1, 256)), dim3(256), 0, st, cur_cnt, ctx->goff, nb);
+    hipLaunchKernelGGL(k_scan_local, dim3(gb), dim3(256), 0, st, ctx->goff, ctx->goff, ctx->block_tot, nb + 1);
+    hipLaunchKernelGGL(k_scan_tot, dim3(1), dim3(1024), 0, st, ctx->block_tot, (size_t)gb);
+    hipLaunchKernelGGL(k_scan_add, dim3(gb), dim3(256), 0, st, ctx->goff, ctx->block_tot, nb + 1);
+  }
   HIP_TRY(hipMemsetAsync(ctx->block_tot, 0, 8, st));   // block_tot[0], [1] are reused as the lengths of the two stitching lists (scans are done)
   // slice length for THIS n (the plan's slot array is sized for max_n)
   uint32_t S_run, T_run;
@@ -1489,11 +1555,11 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   const uint32_t* acc_entries = dense ? nullptr : ctx->entries;
   static const int acc_prio = env_int("ZKHIP_ACC_PRIO", 1, 0, 1);     // (see k_accumulate: the wave that is behind asks for priority; 0 = the arbiter's own order)
   if (ctx->K == 1 || dense)
-    hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off, cur_cnt,
+    hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off, cur_cnt, ctx->goff,
                        (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio);
   else
     hipLaunchKernelGGL(k_accumulate<MSM_MAX_JOBS>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off,
-                       cur_cnt, (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio);
+                       cur_cnt, ctx->goff, (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
   ctx->last_S = S_run; ctx->last_T = T_run; ctx->last_tight = tight;
   // fold the F pieces of the buckets that have several (lists made by k_accumulate), then L + F for every cut bucket
@@ -1509,7 +1575,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     else hipLaunchKernelGGL(k_fixup_fold<false>, dim3(sblocks + 512), dim3(256), 0, st, ctx->block_tot, ctx->fix_short, ctx->fix_list, sblocks,
                             (uint32_t)nb, ctx->buckets, ctx->slot_stride);
   }
-  hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, (uint32_t)nb, S_run, tight, T_run,
+  hipLaunchKernelGGL(k_fixup, dim3(nblk(T_run, 256)), dim3(256), 0, st, cur_off, cur_cnt, ctx->goff, (uint32_t)nb, S_run, tight, T_run,
                      ctx->buckets, ctx->slot_stride);
   HIP_TRY(hipGetLastError());
 
