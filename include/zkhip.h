@@ -172,7 +172,13 @@ typedef struct {
 typedef struct zkhip_r1cs zkhip_r1cs;
 int zkhip_r1cs_upload(const zkhip_r1cs_desc* d, zkhip_r1cs** out);
 void zkhip_r1cs_free(zkhip_r1cs* r);
-unsigned zkhip_r1cs_log_domain(const zkhip_r1cs* r);   /* log2 of the QAP domain size d */
+unsigned zkhip_r1cs_log_domain(const zkhip_r1cs* r);   /* ceil(log2) of the QAP domain size d */
+/* The QAP's evaluation domain is the one libfqfft's get_evaluation_domain picks for n_constraints + n_primary + 1 points (reached from
+ * r1cs_gg_ppzksnark_generator / _prover through aggregator_circuit.tcc:108, :168; libfqfft is an absent sub-submodule: the rule is
+ * restated from its published source): a power of two (basic_radix2_domain), else 2^k + 2^r points (step_radix2_domain) - the
+ * wrapping circuit's 44,188 points get 32,768 + 16,384 = 49,152, not 65,536.  d is also the proving key's domain_size (H query: d - 1). */
+size_t zkhip_r1cs_domain_size(const zkhip_r1cs* r);
+size_t zkhip_domain_size(size_t min_size);              /* host code: the domain size for min_size points */
 
 /* replaces: protoboard::is_satisfied() under DEBUG (aggregator_circuit.tcc:159-164); *ok = 1/0 */
 int zkhip_r1cs_is_satisfied(zkhip_r1cs* r, const uint64_t* z, int* ok);
@@ -370,6 +376,11 @@ int zkhip_last_accumulate_interval(float out_ms[2]);
  * of resolution for ~8 s, 0.06 ms after an hour).  A caller that compares intervals records the origin again at the start of its
  * timed region (calling thread's library device). */
 int zkhip_reset_time_base(void);
+/* The Fq multiplier's own peak on the calling thread's library device, measured NOW: dependent chains of 761-bit Montgomery products
+ * at the accumulation kernel's occupancy, chip-wide products per second (~25 ms of device time).  The bound that binds this path is
+ * the integer multiplier, and its rate differs between boxes and power states of the same model: a measurement states
+ * its fraction against the peak of the run it was taken in. */
+int zkhip_measure_fq_mul_rate(double* fq_mul_per_s);
 
 /* replaces: libff::Fr<wppT>::random_element() as r1cs_gg_ppzksnark_prover draws the proof's randomisers r, s (reached from
  * aggregator_circuit.tcc:168) and the generator its toxic waste: one field element uniform in Fr, 6 Montgomery limbs, from the

@@ -120,9 +120,28 @@ def qap_log_d(n, n_primary):
     return int(load().oracle_qap_log_d(ctypes.c_size_t(n), ctypes.c_size_t(n_primary)))
 
 
+def domain_size(min_size):
+    """Size of the evaluation domain libfqfft picks for min_size points (a power of two, or 2^k + 2^r: step_radix2_domain)."""
+    fn = load().oracle_domain_size
+    fn.restype = ctypes.c_size_t
+    return int(fn(ctypes.c_size_t(min_size)))
+
+
+def qap_domain_size(n, n_primary):
+    return domain_size(n + n_primary + 1)
+
+
+def domain_fft(a, inverse=False, coset=False):
+    """FFT / iFFT / cosetFFT / icosetFFT over the domain of len(a) points (len(a) must be a size domain_size returns)."""
+    x = np.array(a, dtype=np.uint64).reshape(-1, 6).copy()
+    assert domain_size(x.shape[0]) == x.shape[0]
+    load().oracle_domain_fft(_p(x), ctypes.c_size_t(x.shape[0]), int(inverse), int(coset))
+    return x
+
+
 def qap_h(A, B, C, z, n, n_primary):
     """A, B, C: (row_ptr u32[n+1], col u32[nnz], val u64[nnz,6]) CSR triples; z: [m,6]."""
-    d = 1 << qap_log_d(n, n_primary)
+    d = qap_domain_size(n, n_primary)
     h = np.zeros((d, 6), dtype=np.uint64)
     args = []
     for (rp, col, val) in (A, B, C):

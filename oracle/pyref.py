@@ -244,20 +244,143 @@ def r1cs_is_satisfied(A, B, C, z):
                for a, b, c in zip(A, B, C))
 
 
+def _ceil_log2(n):
+    k = 0
+    while (1 << k) < n:
+        k += 1
+    return k
+
+
+def evaluation_domain_size(min_size):
+    """Size of the domain libfqfft's get_evaluation_domain picks for `min_size` points over a field of high 2-adicity [UPSTREAM-RECALL:
+    libfqfft/evaluation_domain/get_evaluation_domain.tcc - the libfqfft sources are absent from the reference tree]: a power of two
+    gets basic_radix2_domain; otherwise step_radix2_domain, of size min_size itself when min_size = 2^k + 2^r, else of size
+    2^k + 2^ceil(log2(min_size - 2^k)) with 2^k the largest power of two below min_size (which is the next power of two - a
+    basic_radix2_domain again - when the remainder rounds up to 2^k).  The wrapping circuit's 44,183 constraints + 5 get 32,768 +
+    16,384 = 49,152 points, not 65,536."""
+    assert min_size >= 1
+    if min_size & (min_size - 1) == 0:
+        return min_size
+    big = 1 << (_ceil_log2(min_size) - 1)
+    small = min_size - big
+    return big + (1 << _ceil_log2(small))
+
+
+def qap_domain_size(n_constraints, n_primary):
+    return evaluation_domain_size(n_constraints + n_primary + 1)
+
+
 def qap_domain_log(n_constraints, n_primary):
-    need = n_constraints + n_primary + 1
-    log_d = 0
-    while (1 << log_d) < need:
-        log_d += 1
-    return log_d
+    """ceil(log2) of the domain size (the size itself for power-of-two domains)."""
+    return _ceil_log2(qap_domain_size(n_constraints, n_primary))
+
+
+class EvalDomain:
+    """libfqfft's basic_radix2_domain (m a power of two) or step_radix2_domain (m = big + small, both powers of two, small < big):
+    the points are big_omega^i (i < big) followed by omega small_omega^i (i < small), with omega of order 2 big, big_omega = omega^2
+    and small_omega of order small; Z(x) = (x^big - 1)(x^small - omega^small)  [UPSTREAM-RECALL: step_radix2_domain.tcc]."""
+
+    def __init__(self, m):
+        assert m >= 1 and evaluation_domain_size(m) == m
+        self.m = m
+        if m & (m - 1) == 0:
+            self.big, self.small = m, 0
+            self.log_big = _ceil_log2(m)
+        else:
+            self.big = 1 << (_ceil_log2(m) - 1)
+            self.small = m - self.big
+            self.log_big = _ceil_log2(self.big)
+            self.log_small = _ceil_log2(self.small)
+            self.omega = fr_root_of_unity(self.log_big + 1)
+
+    def points(self):
+        if not self.small:
+            w = fr_root_of_unity(self.log_big)
+            return [pow(w, i, R_MOD) for i in range(self.m)]
+        bw, sw = self.omega * self.omega % R_MOD, fr_root_of_unity(self.log_small)
+        return [pow(bw, i, R_MOD) for i in range(self.big)] + [self.omega * pow(sw, i, R_MOD) % R_MOD for i in range(self.small)]
+
+    def vanishing(self, x):
+        if not self.small:
+            return (pow(x, self.m, R_MOD) - 1) % R_MOD
+        return (pow(x, self.big, R_MOD) - 1) * (pow(x, self.small, R_MOD) - pow(self.omega, self.small, R_MOD)) % R_MOD
+
+    def fft(self, a):
+        """coefficients (m of them) -> evaluations at points()"""
+        a = [x % R_MOD for x in a]
+        assert len(a) == self.m
+        if not self.small:
+            return fft_domain(a, self.log_big)
+        B, S, w = self.big, self.small, self.omega
+        c = [(a[i] + a[i + B]) % R_MOD if i < S else a[i] for i in range(B)]         # x^(B + i) = x^i on the big subgroup
+        d, wi = [], 1
+        for i in range(B):                                                             # x^B = -1 on the coset omega <small_omega>
+            d.append(wi * ((a[i] - a[i + B]) if i < S else a[i]) % R_MOD)
+            wi = wi * w % R_MOD
+        e = [sum(d[i + j * S] for j in range(B // S)) % R_MOD for i in range(S)]      # (small_omega^i)^S = 1
+        return fft(c, w * w % R_MOD) + fft(e, fr_root_of_unity(self.log_small))
+
+    def ifft(self, v):
+        """evaluations at points() -> coefficients"""
+        v = [x % R_MOD for x in v]
+        assert len(v) == self.m
+        if not self.small:
+            return ifft_domain(v, self.log_big)
+        B, S, w = self.big, self.small, self.omega
+        c = ifft_domain(v[:B], self.log_big)                                           # c[i] as in fft()
+        e = ifft_domain(v[B:], self.log_small)
+        w_inv, two_inv = inv_mod(w, R_MOD), inv_mod(2, R_MOD)
+        a = [0] * self.m
+        for i in range(S, B):
+            a[i] = c[i]
+        for i in range(S):
+            # e[i] = d[i] + sum_{j >= 1} d[i + j S], and d[k] = omega^k c[k] for k >= S
+            di = (e[i] - sum(pow(w, i + j * S, R_MOD) * c[i + j * S] for j in range(1, B // S))) % R_MOD
+            diff = di * pow(w_inv, i, R_MOD) % R_MOD                                   # a[i] - a[i + B]
+            a[i] = (c[i] + diff) * two_inv % R_MOD
+            a[B + i] = (c[i] - diff) * two_inv % R_MOD
+        return a
+
+    def coset_fft(self, a, g=FR_GENERATOR):
+        s, out = 1, []
+        for x in a:
+            out.append(x * s % R_MOD)
+            s = s * g % R_MOD
+        return self.fft(out)
+
+    def icoset_fft(self, v, g=FR_GENERATOR):
+        g_inv, s, res = inv_mod(g, R_MOD), 1, []
+        for x in self.ifft(v):
+            res.append(x * s % R_MOD)
+            s = s * g_inv % R_MOD
+        return res
+
+    def lagrange_at(self, tau):
+        """L_j(tau) = Z(tau) / ((tau - x_j) Z'(x_j)) for every point x_j"""
+        zt = self.vanishing(tau)
+        pts = self.points()
+        out = []
+        if not self.small:
+            m_inv = inv_mod(self.m, R_MOD)
+            for x in pts:                                                              # Z'(x_j) = m / x_j
+                out.append(zt * x % R_MOD * m_inv % R_MOD * inv_mod((tau - x) % R_MOD, R_MOD) % R_MOD)
+            return out
+        B, S, ws = self.big, self.small, pow(self.omega, self.small, R_MOD)
+        for j, x in enumerate(pts):
+            if j < B:                                                                  # x^B = 1:  Z'(x) = B (x^S - omega^S) / x
+                dz = B * (pow(x, S, R_MOD) - ws) % R_MOD
+            else:                                                                      # x^S = omega^S, x^B = -1:  Z'(x) = -2 S omega^S / x
+                dz = (-2 * S * ws) % R_MOD
+            out.append(zt * x % R_MOD * inv_mod(dz * ((tau - x) % R_MOD) % R_MOD, R_MOD) % R_MOD)
+        return out
 
 
 def qap_witness_map(A, B, C, z, n_primary):
-    """Coefficients h_0..h_{d-2} (returned with length d; h_{d-1} = 0) of
-    H = (A(X)B(X) - C(X)) / Z(X); extra rows aA[n+k] = z_k, k = 0..l (input consistency)."""
+    """Coefficients h_0..h_{d-2} (returned with length d; h_{d-1} = 0) of H = (A(X)B(X) - C(X)) / Z(X) over the domain libfqfft picks
+    for n + l + 1 points (evaluation_domain_size); extra rows aA[n+k] = z_k, k = 0..l (input consistency).  Returns (h, d)."""
     n = len(A)
-    log_d = qap_domain_log(n, n_primary)
-    d = 1 << log_d
+    d = qap_domain_size(n, n_primary)
+    dom = EvalDomain(d)
     aA = [0] * d
     aB = [0] * d
     aC = [0] * d
@@ -267,15 +390,12 @@ def qap_witness_map(A, B, C, z, n_primary):
         aC[i] = r1cs_eval_row(C[i], z)
     for k in range(n_primary + 1):
         aA[n + k] = z[k] % R_MOD
-    cA = ifft_domain(aA, log_d)
-    cB = ifft_domain(aB, log_d)
-    cC = ifft_domain(aC, log_d)
-    eA = coset_fft_domain(cA, log_d)
-    eB = coset_fft_domain(cB, log_d)
-    eC = coset_fft_domain(cC, log_d)
-    z_inv = inv_mod(pow(FR_GENERATOR, d, R_MOD) - 1, R_MOD)  # Z(g w^i) = g^d - 1 on the coset
-    eH = [((x * y - w) % R_MOD) * z_inv % R_MOD for x, y, w in zip(eA, eB, eC)]
-    return icoset_fft_domain(eH, log_d), log_d
+    eA = dom.coset_fft(dom.ifft(aA))
+    eB = dom.coset_fft(dom.ifft(aB))
+    eC = dom.coset_fft(dom.ifft(aC))
+    zs = [dom.vanishing(FR_GENERATOR * x % R_MOD) for x in dom.points()]             # (constant on the coset of a radix-2 domain only)
+    eH = [((x * y - w) % R_MOD) * inv_mod(zv, R_MOD) % R_MOD for x, y, w, zv in zip(eA, eB, eC, zs)]
+    return dom.icoset_fft(eH), d
 
 
 def poly_eval(coeffs, x, mod=R_MOD):
@@ -285,28 +405,18 @@ def poly_eval(coeffs, x, mod=R_MOD):
     return acc
 
 
-def lagrange_evals_at(log_d, tau):
-    """L_i(tau) for the radix-2 domain of size 2^log_d, i = 0..d-1."""
-    d = 1 << log_d
-    omega = fr_root_of_unity(log_d)
-    zt = (pow(tau, d, R_MOD) - 1) % R_MOD
-    d_inv = inv_mod(d, R_MOD)
-    out = []
-    w = 1
-    for _ in range(d):
-        # L_i(t) = Z(t) * w^i / (d * (t - w^i))
-        out.append(zt * w % R_MOD * d_inv % R_MOD * inv_mod((tau - w) % R_MOD, R_MOD) % R_MOD)
-        w = w * omega % R_MOD
-    return out
+def lagrange_evals_at(d, tau):
+    """L_i(tau) for the evaluation domain of size d (a size evaluation_domain_size returns), i = 0..d-1."""
+    return EvalDomain(d).lagrange_at(tau)
 
 
 def groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
     """Trapdoor-side QAP evaluation: returns dict with At[i], Bt[i], Ct[i] (i < n_vars),
-    Zt, log_d.  n_vars counts the constant ONE (so z has length n_vars)."""
+    Zt, d (domain size), log_d (its ceil log2).  n_vars counts the constant ONE (so z has length n_vars)."""
     n = len(A)
-    log_d = qap_domain_log(n, n_primary)
-    d = 1 << log_d
-    L = lagrange_evals_at(log_d, tau)
+    d = qap_domain_size(n, n_primary)
+    dom = EvalDomain(d)
+    L = dom.lagrange_at(tau)
     At = [0] * n_vars
     Bt = [0] * n_vars
     Ct = [0] * n_vars
@@ -319,14 +429,13 @@ def groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
             Ct[i] = (Ct[i] + c * L[j]) % R_MOD
     for k in range(n_primary + 1):
         At[k] = (At[k] + L[n + k]) % R_MOD
-    Zt = (pow(tau, d, R_MOD) - 1) % R_MOD
-    return dict(At=At, Bt=Bt, Ct=Ct, Zt=Zt, log_d=log_d)
+    return dict(At=At, Bt=Bt, Ct=Ct, Zt=dom.vanishing(tau), d=d, log_d=_ceil_log2(d))
 
 
 def groth16_generate_keypair(A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
     """CRS in affine big-int points (tiny circuits only)."""
     s = groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta)
-    d = 1 << s["log_d"]
+    d = s["d"]
     delta_inv = inv_mod(delta, R_MOD)
     pk = dict(
         alpha_g1=ec_mul(alpha, G1_GEN), beta_g1=ec_mul(beta, G1_GEN), beta_g2=ec_mul(beta, G2_GEN),
@@ -338,7 +447,7 @@ def groth16_generate_keypair(A, B, C, n_vars, n_primary, tau, alpha, beta, delta
                  for j in range(d - 1)],
         L_query=[ec_mul((beta * s["At"][i] + alpha * s["Bt"][i] + s["Ct"][i]) % R_MOD * delta_inv % R_MOD,
                         G1_GEN) for i in range(n_primary + 1, n_vars)],
-        log_d=s["log_d"], n_primary=n_primary,
+        log_d=s["log_d"], d=d, n_primary=n_primary,
     )
     vk = dict(
         alpha_g1=pk["alpha_g1"], beta_g2=pk["beta_g2"], delta_g2=pk["delta_g2"],
@@ -351,9 +460,8 @@ def groth16_generate_keypair(A, B, C, n_vars, n_primary, tau, alpha, beta, delta
 def groth16_prove(pk, A, B, C, z, r, s):
     """Proof (A in G1, B in G2, C in G1) per SURVEY App. B.1 with injected (r, s)."""
     l = pk["n_primary"]
-    h, log_d = qap_witness_map(A, B, C, z, l)
-    d = 1 << log_d
-    assert log_d == pk["log_d"]
+    h, d = qap_witness_map(A, B, C, z, l)
+    assert d == pk["d"]
     assert h[d - 1] == 0
     evA = msm_naive(z, pk["A_query"])
     evB2 = msm_naive(z, pk["B_query_g2"])
@@ -375,8 +483,7 @@ def groth16_expected_proof_from_trapdoor(A, B, C, z, n_primary, tau, alpha, beta
     single scalar multiples of the generators."""
     n_vars = len(z)
     st = groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta)
-    h, log_d = qap_witness_map(A, B, C, z, n_primary)
-    d = 1 << log_d
+    h, d = qap_witness_map(A, B, C, z, n_primary)
     a_t = sum(zi * x for zi, x in zip(z, st["At"])) % R_MOD
     b_t = sum(zi * x for zi, x in zip(z, st["Bt"])) % R_MOD
     delta_inv = inv_mod(delta, R_MOD)

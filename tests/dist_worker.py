@@ -52,7 +52,7 @@ def cpu_key(A, B, C, m, l, trapdoor):
     """Proving key of a small system with known toxic waste: exponents from oracle/pyref, group elements by the C oracle."""
     tau, alpha, beta, delta = trapdoor
     st = R.groth16_setup_scalars(A, B, C, m, l, tau, alpha, beta, delta)
-    d = 1 << st["log_d"]
+    d = st["d"]
     dinv = pow(delta, -1, R.R_MOD)
     g1, g2 = aff_limbs(R.G1_GEN), aff_limbs(R.G2_GEN)
     fb = lambda g, xs: (np.array([O.jac_to_affine(O.scalar_mul(g, fr_limbs(x % R.R_MOD))) for x in xs], dtype=np.uint64).reshape(-1, 24)

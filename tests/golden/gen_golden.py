@@ -111,23 +111,24 @@ def small_r1cs(rng, n_constraints, n_primary, n_aux):
     return A, B, C, z
 
 
-def gen_groth16(rng):
+def gen_groth16(rng, n_constraints=5):
     n_primary = 2
-    A, B, C, z = small_r1cs(rng, 5, n_primary, 4)
+    A, B, C, z = small_r1cs(rng, n_constraints, n_primary, 4)
     tau, alpha, beta, delta = (rng.randrange(1, R.R_MOD) for _ in range(4))
     r, s = rng.randrange(R.R_MOD), rng.randrange(R.R_MOD)
     pk, vk = R.groth16_generate_keypair(A, B, C, len(z), n_primary, tau, alpha, beta, delta)
     proof = R.groth16_prove(pk, A, B, C, z, r, s)
     expect = R.groth16_expected_proof_from_trapdoor(A, B, C, z, n_primary, tau, alpha, beta, delta, r, s)
     assert proof == expect
-    h, log_d = R.qap_witness_map(A, B, C, z, n_primary)
+    h, d = R.qap_witness_map(A, B, C, z, n_primary)
+    log_d = R.qap_domain_log(len(A), n_primary)
     # pairing check of the proof under the vk with the reference's verification equation
     assert R.bw6_groth16_verify(dict(alpha=vk["alpha_g1"], beta=vk["beta_g2"], delta=vk["delta_g2"], ABC=vk["ABC_g1"]),
                                 dict(a=proof[0], b=proof[1], c=proof[2]), z[1:1 + n_primary])
     rows = lambda M: [[[i, hx(c)] for i, c in row] for row in M]
     return dict(n_primary=n_primary, A=rows(A), B=rows(B), C=rows(C), z=[hx(x) for x in z],
                 trapdoor=dict(tau=hx(tau), alpha=hx(alpha), beta=hx(beta), delta=hx(delta)), r=hx(r), s=hx(s),
-                log_d=log_d, h=[hx(x) for x in h],
+                log_d=log_d, d=d, h=[hx(x) for x in h],
                 pk=dict(alpha_g1=pt(pk["alpha_g1"]), beta_g1=pt(pk["beta_g1"]), beta_g2=pt(pk["beta_g2"]),
                         delta_g1=pt(pk["delta_g1"]), delta_g2=pt(pk["delta_g2"]),
                         A=[pt(p) for p in pk["A_query"]], B2=[pt(p) for p in pk["B_query_g2"]],
@@ -138,10 +139,36 @@ def gen_groth16(rng):
                 proof=dict(a=pt(proof[0]), b=pt(proof[1]), c=pt(proof[2])))
 
 
+def gen_step_domain(rng):
+    """Round 4: the evaluation domains libfqfft picks for sizes that are not powers of two (step_radix2_domain: 2^k + 2^r points).
+    FFT / iFFT / cosetFFT / icosetFFT vectors, each checked against naive evaluation at the domain's points, and a Groth16 instance
+    of 7 constraints + 2 inputs + 1 = 10 = 8 + 2 points whose proof passes the pinned pairing check."""
+    vecs = []
+    for d in (3, 6, 10, 12, 24, 40):
+        dom = R.EvalDomain(d)
+        a = [rng.randrange(R.R_MOD) for _ in range(d)]
+        pts = dom.points()
+        assert dom.fft(a) == [R.poly_eval(a, x) for x in pts]
+        assert dom.coset_fft(a) == [R.poly_eval(a, R.FR_GENERATOR * x % R.R_MOD) for x in pts]
+        assert dom.ifft(dom.fft(a)) == a and dom.icoset_fft(dom.coset_fft(a)) == a
+        vecs.append(dict(d=d, input=[hx(x) for x in a], fft=[hx(x) for x in dom.fft(a)], ifft=[hx(x) for x in dom.ifft(a)],
+                         coset_fft=[hx(x) for x in dom.coset_fft(a)], icoset_fft=[hx(x) for x in dom.icoset_fft(a)]))
+    sizes = {str(m): R.evaluation_domain_size(m) for m in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 13, 17, 33, 100, 1025, 44188, 92060, 1048573, 4194301)}
+    g = gen_groth16(rng, n_constraints=7)
+    assert g["d"] == 10
+    return dict(domain_sizes=sizes, fft_vectors=vecs, groth16=g)
+
+
 def main():
+    if "--step-only" in sys.argv:          # (the other files are unchanged by round 4: their domains are powers of two)
+        with open(os.path.join(HERE, "step_domain.json"), "w") as f:
+            json.dump(gen_step_domain(random.Random(0x57E9)), f, indent=0)
+        print("wrote step_domain")
+        return
     rng = random.Random(0x5EED)
     files = dict(field_vectors=gen_fields(rng), curve_vectors=gen_curve(rng), msm_vectors=gen_msm(rng),
                  ntt_vectors=gen_ntt(rng), groth16_small=gen_groth16(rng))
+    files["step_domain"] = gen_step_domain(random.Random(0x57E9))
     for name, data in files.items():
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(data, f, indent=0)

@@ -137,7 +137,7 @@ def crs_from_trapdoor(zk, A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
     """Proving key with known toxic waste: exponents from oracle/pyref (big ints), group elements by the
     product's fixed-base kernel (checked against the oracle in test_msm_gpu)."""
     st = R.groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta)
-    d = 1 << st["log_d"]
+    d = st["d"]               # the domain libfqfft picks: a power of two or 2^k + 2^r (oracle/pyref.py evaluation_domain_size)
     dinv = pow(delta, -1, R.R_MOD)
     g1, g2 = aff_limbs(R.G1_GEN), aff_limbs(R.G2_GEN)
     can = lambda xs: np.array([R.int_to_limbs(x % R.R_MOD, 6) for x in xs], dtype=np.uint64).reshape(-1, 6)
@@ -152,4 +152,4 @@ def crs_from_trapdoor(zk, A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
     pk = dict(vk=vk, alpha_g1=fb(g1, [alpha])[0], beta_g1=fb(g1, [beta])[0], beta_g2=fb(g2, [beta])[0],
               delta_g1=fb(g1, [delta])[0], delta_g2=fb(g2, [delta])[0],
               A=fb(g1, st["At"]), B2=fb(g2, st["Bt"]), B1=fb(g1, st["Bt"]), H=fb(g1, hs), L=fb(g1, ls))
-    return pk, st["log_d"]
+    return pk, d

@@ -63,8 +63,17 @@ def test_cpp_mirror_setup_prove_verify_and_stream(zk, tmp_path):
 
 
 def test_two_prover_contexts_in_one_process(tmp_path):
+    """tests/cpp/multi_device.cpp through the C++ adapter: hip_proving_key over a device list (two contexts on GPU 0:
+    the wrapping key partitioned, zkhip_multi_prover) returns the whole-key proof limb for limb, and aggregator_circuit::open_node_stream
+    over the same list (replicas behind zkhip_dispatcher) proves and verifies eight batches on both entries."""
     exe = _build(tmp_path, "multi_device")
     path, _, _ = _fixture_file(tmp_path)
     out = subprocess.run([str(exe), str(path)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "same_as_whole_key=1 verifies=1" in out.stdout, out.stdout
+    lines = out.stdout.splitlines()
+    assert any(ln.startswith("PARTITIONED devices=2") and ln.endswith("same_as_whole_key=1") for ln in lines), out.stdout
+    assert "PARTITIONED verifies=1" in lines and "DONE" in lines, out.stdout
+    rep = [ln for ln in lines if ln.startswith("REPLICAS")]
+    assert rep and "entries=2 verified=8 of 8" in rep[0], out.stdout
+    per = [int(x) for x in rep[0].rsplit("=", 1)[1].split(",")]
+    assert sum(per) == 8 and min(per) >= 1, out.stdout

@@ -60,23 +60,23 @@ def test_synthetic_circuit_vs_oracle_and_trapdoor(zk, oracle_lib, key_mode, n, b
     m = len(z)
     rng = random.Random(5)
     tau, alpha, beta, delta, r, s = (rng.randrange(1, R.R_MOD) for _ in range(6))
-    pk, log_d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta)
+    pk, d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta)
     Ac, Bc, Cc = csr_from_rows(A), csr_from_rows(B), csr_from_rows(C)
     zl = fr_array(z)
     r1 = zk.R1cs(Ac, Bc, Cc, m, n_primary)
-    assert r1.log_d == log_d and r1.is_satisfied(zl)
+    # n = 3000: 3,005 points -> 2,048 + 1,024 (libfqfft's step_radix2_domain); n = 4000: 4,005 -> 4,096 (basic_radix2_domain)
+    assert r1.domain_size == d == O.qap_domain_size(n, n_primary) == {3000: 3072, 4000: 4096}[n] and r1.is_satisfied(zl)
     h = r1.qap_h(zl)
     h_or = O.qap_h(Ac, Bc, Cc, zl, n, n_primary)
     assert (h == h_or).all()
     assert (h[-1] == 0).all()
-    crs = zk.Crs(pk, m, n_primary, 1 << log_d)
+    crs = zk.Crs(pk, m, n_primary, d)
     proof = zk.groth16_prove(crs, r1, zl, fr_limbs(r), fr_limbs(s))
     proof_or = O.groth16_prove(pk, zl, n_primary, h_or, fr_limbs(r), fr_limbs(s))
     assert (proof == proof_or).all()
     # trapdoor closed form: A = (alpha + a(tau) + r delta) G1 etc. with h from the oracle
     st = R.groth16_setup_scalars(A, B, C, m, n_primary, tau, alpha, beta, delta)
     hi = fr_ints(h_or)
-    d = 1 << log_d
     a_t = sum(zi * x for zi, x in zip(z, st["At"])) % R.R_MOD
     b_t = sum(zi * x for zi, x in zip(z, st["Bt"])) % R.R_MOD
     dinv = pow(delta, -1, R.R_MOD)
@@ -118,8 +118,8 @@ def test_key_partitioned_prover_matches_whole_key(zk):
     m = len(z)
     rng = random.Random(9)
     tau, alpha, beta, delta, r, s = (rng.randrange(1, R.R_MOD) for _ in range(6))
-    pk, log_d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta)
-    d = 1 << log_d
+    pk, d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta)
+    assert d == 2048 + 512                               # 2,505 points: a step domain with four rows per column
     r1 = zk.R1cs(csr_from_rows(A), csr_from_rows(B), csr_from_rows(C), m, n_primary)
     zl = fr_array(z)
     whole = zk.Crs(pk, m, n_primary, d)
@@ -154,7 +154,7 @@ def test_full_size_2_20_key_modes_agree(zk):
         return rp, cols, bench.random_fr_canonical(int(rng.integers(1 << 30)), n * terms)
     csr = (rand_csr(2), rand_csr(2), rand_csr(2))
     r1 = zk.R1cs(*csr, m, l)
-    d = 1 << r1.log_d
+    d = r1.domain_size
     assert d == 1 << 20
     g1 = bench.g1_generator_limbs()
     consts = dict(alpha_g1=g1, beta_g1=g1, beta_g2=g1, delta_g1=g1, delta_g2=g1)
@@ -205,7 +205,7 @@ def _full_size_proof_verifies(zk, log_n):
     A = (rp, a_idx, ones); B = (rp, b_idx, ones); C = (rp, np.arange(l + 1, m, dtype=np.uint32), ones)
     desc, keep = zk.make_r1cs_desc(A, B, C, m, l)
     r1 = zk.R1cs(A, B, C, m, l)
-    assert r1.log_d == log_n and r1.is_satisfied(z)
+    assert r1.log_d == log_n and r1.domain_size == 1 << log_n and r1.is_satisfied(z)
     kp = zk.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
     crs = kp.upload_crs()
     proof = zk.groth16_prove(crs, r1, z, fr_limbs(0xabcdef), fr_limbs(0xfedcba))
@@ -238,3 +238,47 @@ def test_full_size_2_22_proof_verifies(zk):
     """BASELINE configs[3]'s size on ONE GPU (the 8-GPU form partitions this key): 2^22 constraints, 4.2 M-point query vectors with
     their window tables (69 GB of HBM), the same end-to-end check as at 2^20."""
     _full_size_proof_verifies(zk, 22)
+
+
+def test_step_domain_golden_instance(zk):
+    """tests/golden/step_domain.json: 7 constraints + 2 inputs + 1 = 10 = 8 + 2 points (libfqfft's step_radix2_domain) - the
+    coefficients of H and the proof that oracle/pyref.py computed (its transforms checked against naive evaluation, the proof
+    against the pinned pairing check), limb for limb."""
+    g = golden("step_domain.json")["groth16"]
+    pts = lambda L: np.array([aff_limbs(pt_from_json(p)) for p in L]).reshape(-1, 24)
+    pk = {k: (aff_limbs(pt_from_json(v)) if k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2") else pts(v)) for k, v in g["pk"].items()}
+    A, B, C = (csr_from_rows(g[k]) for k in "ABC")
+    z = fr_array([h2i(x) for x in g["z"]])
+    r1 = zk.R1cs(A, B, C, len(g["z"]), g["n_primary"])
+    assert r1.domain_size == 10 == zk.domain_size(10) and r1.log_d == 4 and r1.is_satisfied(z)
+    assert fr_ints(r1.qap_h(z)) == [h2i(x) for x in g["h"]]
+    crs = zk.Crs(pk, len(g["z"]), g["n_primary"], 10)
+    proof = zk.groth16_prove(crs, r1, z, fr_limbs(h2i(g["r"])), fr_limbs(h2i(g["s"])))
+    assert aff_point(proof[:24]) == pt_from_json(g["proof"]["a"])
+    assert aff_point(proof[24:48]) == pt_from_json(g["proof"]["b"])
+    assert aff_point(proof[48:]) == pt_from_json(g["proof"]["c"])
+    crs.free(); r1.free()
+
+
+@pytest.mark.parametrize("points,domain", [(3, 3), (6, 6), (11, 12), (1025, 1025), (1030, 1032), (2500, 2560), (4100, 4100), (6000, 6144), (20000, 20480),
+                                           (33000, 33024)])
+def test_step_domains_qap_against_the_oracle(zk, oracle_lib, points, domain):
+    """The QAP map over the domains libfqfft picks for sizes that are not powers of two (2^k + 2^r points), against the C oracle:
+    one row per column up to a thousand (1,025 = 1,024 + 1: the whole big part folds into ONE point), parts below and above the
+    2^12 points from which a transform's input order is transposed, the two parts in different orders (4,100 = 4,096 + 4)."""
+    O = oracle_lib
+    l = 1
+    n = points - l - 1
+    rng = np.random.default_rng(points)
+    m = n + l + 1 + 5
+    import bench
+    def rand_csr(terms):
+        cols = rng.integers(0, m, size=(n, terms), dtype=np.uint32).reshape(-1)
+        rp = (np.arange(n + 1, dtype=np.uint32) * terms)
+        return rp, cols, bench.random_fr_canonical(int(rng.integers(1 << 30)), n * terms)
+    csr = (rand_csr(2), rand_csr(1), rand_csr(2))
+    z = bench.random_fr_canonical(7 + points, m)
+    r1 = zk.R1cs(*csr, m, l)
+    assert r1.domain_size == domain == O.qap_domain_size(n, l) == zk.domain_size(points)
+    assert (r1.qap_h(z) == O.qap_h(*csr, z, n, l)).all()          # (an unsatisfied system: H is then a quotient with a remainder - the same one)
+    r1.free()

@@ -102,6 +102,9 @@ static inline int msm_table_levels(int c, int naf = 0) { return naf ? 378 : (378
 // Fills levels 1 .. levels-1:  table[w * n + i] = 2^(c w) P_i  in affine packed form.
 int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, int naf, char* errbuf, size_t errlen);
 
+// Fq multiplications per second of the whole device, measured now: dependent fp_mul chains at two waves per SIMD (~25 ms)
+int msm_measure_fqmul_rate(double* fq_mul_per_s, char* errbuf, size_t errlen);
+
 int fixed_base_mul(const uint64_t base_aff[24], const uint64_t* d_scalars, size_t n, int montgomery, uint64_t* d_out,
                    char* errbuf, size_t errlen);
 

@@ -1135,6 +1135,61 @@ __global__ void __launch_bounds__(256, 2) k_table_build(AffPacked* __restrict__ 
   }
 }
 
+// ---- the multiplier's own peak on THIS device, now (bench.py's fq_mul_frac divides by it) ----------------------------------------
+// Two dependent chains of fp_mul per lane at the accumulation's occupancy (78 KiB of LDS per 256-lane block = two waves per SIMD):
+// the kernel of tools/ubench/fqmul_occ_bench.hip inside the library.  The rate differs between boxes of the same model and between
+// power states (420 .. 495 G wave-mads/s seen in round 4), so a fraction against a constant measured once means little.
+__global__ void __launch_bounds__(256) k_fqmul_chain(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int iters) {
+  extern __shared__ uint32_t lds_occ[];
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  Fq x, y;
+#pragma unroll
+  for (int i = 0; i < 27; i++) { x.l[i] = (in[i] ^ (tid & 0xffu)) & M29; y.l[i] = (in[27 + i] ^ ((tid >> 8) & 0xffu)) & M29; }
+  x.l[26] &= 0x3fu; y.l[26] &= 0x3fu;
+  if (iters < 0) lds_occ[threadIdx.x] = x.l[0];       // (keeps the allocation)
+#pragma unroll 1
+  for (int it = 0; it < iters; it++) { x = fp_mul(x, y); y = fp_mul(y, x); }
+  uint32_t s_ = 0;
+#pragma unroll
+  for (int i = 0; i < 27; i++) s_ ^= x.l[i] + y.l[i];
+  out[tid] = s_;
+}
+
+int msm_measure_fqmul_rate(double* fq_mul_per_s, char* errbuf, size_t errlen) {
+  const int blocks = 256 * 2 * 4, iters = 100;
+  const size_t lds = 78 * 1024;
+  uint32_t *in = nullptr, *out = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  uint32_t h[54];
+  for (int i = 0; i < 54; i++) h[i] = (0x9e3779b9u * (uint32_t)(i + 1)) & M29;
+  hipError_t e = hipMalloc(&in, sizeof h);
+  if (e == hipSuccess) e = hipMalloc(&out, (size_t)blocks * 256 * 4);
+  if (e == hipSuccess) e = hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_fqmul_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  float ms = 0;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_fqmul_chain, dim3(blocks), dim3(256), lds, 0, in, out, 2);          // (code and clocks warm)
+    hipLaunchKernelGGL(k_fqmul_chain, dim3(blocks), dim3(256), lds, 0, in, out, iters);
+    e = hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_fqmul_chain, dim3(blocks), dim3(256), lds, 0, in, out, iters);
+    if (e == hipSuccess) e = hipEventRecord(e1, 0);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (in) (void)hipFree(in);
+  if (out) (void)hipFree(out);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (e != hipSuccess || ms <= 0) {
+    if (errbuf) snprintf(errbuf, errlen, "msm_measure_fqmul_rate: %s", hipGetErrorString(e));
+    return ZKHIP_ERR_HIP;
+  }
+  *fq_mul_per_s = (double)blocks * 256 * iters * 2 / (ms * 1e-3);
+  return ZKHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------

@@ -18,11 +18,17 @@ struct CsrDev {
 struct R1csDev {
   int spmv_log_lanes = 4;      // lanes per row of the sparse products: 2^4 (a proof alone) or 2^2 (a prover that shares the chip)
   size_t n_constraints = 0, n_vars = 0, n_primary = 0;   // n_vars counts the constant ONE
-  int log_d = 0;
+  // The evaluation domain (domain.hpp): d points - a power of two (small == 0, big == d), or big + small with both powers of two
+  // (libfqfft's step_radix2_domain).  log_d = ceil(log2 d).
+  size_t d = 0, big = 0, small = 0;
+  int log_d = 0, log_big = 0, log_small = 0;
   CsrDev A, B, C;
   // work buffers (packed device form, d elements each)
   uint32_t *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *tmp = nullptr, *z = nullptr;
-  uint32_t* zinv = nullptr;   // 1 / (g^d - 1), 14 limbs
+  uint32_t* zinv = nullptr;   // 1 / Z on the coset g x, 14 limbs per class: one class for a radix-2 domain (g^d - 1); a step domain has
+                              // big / small classes on its big part (by i mod (big / small)) and one more for its small part
+  // step domains: powers in packed device form - w^i (i < big), w^-i (i < small), g^i and g^-i (i < d) - and 1/2 (14 limbs)
+  uint32_t *pw_w = nullptr, *pw_winv = nullptr, *pw_g = nullptr, *pw_ginv = nullptr, *half = nullptr;
 };
 
 int r1cs_upload(const zkhip_r1cs_desc* d, R1csDev** out, char* err, size_t errlen);

@@ -7,6 +7,7 @@
 
 #include "ec.cuh"
 #include "host_field.hpp"
+#include "domain.hpp"
 #include "msm.h"
 #include "wait.h"
 #include "ntt.h"
@@ -505,6 +506,8 @@ void zkhip_r1cs_free(zkhip_r1cs* r) {
 }
 
 unsigned zkhip_r1cs_log_domain(const zkhip_r1cs* r) { return r ? (unsigned)r->dev->log_d : 0; }
+size_t zkhip_r1cs_domain_size(const zkhip_r1cs* r) { return r ? r->dev->d : 0; }
+size_t zkhip_domain_size(size_t min_size) { return host::eval_domain_size(min_size); }
 
 int zkhip_r1cs_is_satisfied(zkhip_r1cs* r, const uint64_t* z, int* ok) {
   if (!r || !z || !ok) return fail(ZKHIP_ERR_ARG, "null pointer");
@@ -521,7 +524,7 @@ int zkhip_qap_h(zkhip_r1cs* r, const uint64_t* z, uint64_t* h_out) {
   if (!r || !z || !h_out) return fail(ZKHIP_ERR_ARG, "null pointer");
   BIND(r);
   std::lock_guard<std::mutex> lk(g.dev[r->device].mu);
-  size_t d = (size_t)1 << r->dev->log_d;
+  size_t d = r->dev->d;
   Scratch sc;
   uint64_t *dz = nullptr, *dh = nullptr;
   API_HIP(sc.alloc((void**)&dz, r->dev->n_vars * 48));
@@ -643,7 +646,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
                          uint64_t sums[5 * 36], const uint64_t* d_z_ready = nullptr) {
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
-  const size_t m = rd->n_vars, l = rd->n_primary, d = (size_t)1 << rd->log_d;
+  const size_t m = rd->n_vars, l = rd->n_primary, d = rd->d;
   const size_t a_len = crs->A->len, h_len = crs->H->len, l_len = crs->L->len;
   if (crs->n_vars != m || crs->n_primary != l || crs->domain_size != d) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
   if (crs->B2->len != a_len || crs->B1->len != a_len || a_lo + a_len > m || h_lo + h_len > d - 1 || l_lo + l_len > m - l - 1)
@@ -817,7 +820,7 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
   TailPre pre;
   {
     std::lock_guard<std::mutex> lk(g.dev[crs->device].mu);
-    const size_t m = r1cs->dev->n_vars, l = r1cs->dev->n_primary, d = (size_t)1 << r1cs->dev->log_d;
+    const size_t m = r1cs->dev->n_vars, l = r1cs->dev->n_primary, d = r1cs->dev->d;
     if (crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
     tail_begin(pre, crs->delta_g1, crs->delta_g2, r_m, s_m);       // the key-only part of the tail runs under the device work
     int rc = prove_partial(g.dev[crs->device].ps, crs, r1cs->dev, z, 0, 0, 0, sums);
@@ -850,7 +853,7 @@ static int prover_new_impl(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, bool
     int rc = r1cs_upload(cs, &rd, t_err, sizeof t_err);
     if (rc != ZKHIP_OK) return rc;
   }
-  const size_t m = rd->n_vars, l = rd->n_primary, d = (size_t)1 << rd->log_d;
+  const size_t m = rd->n_vars, l = rd->n_primary, d = rd->d;
   bool ok = crs->n_vars == m && crs->n_primary == l && crs->domain_size == d;
   if (ok && !slice) ok = crs->A->len == m && crs->H->len == d - 1 && crs->L->len == m - l - 1;
   if (ok && slice) ok = a_lo + crs->A->len <= m && h_lo + crs->H->len <= d - 1 && l_lo + crs->L->len <= m - l - 1;
@@ -983,31 +986,16 @@ int zkhip_groth16_setup(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], cons
   if (!cs || !tau_m || !alpha_m || !beta_m || !delta_m || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
   const size_t n = cs->n_constraints, m = cs->n_vars, l = cs->n_primary;
   if (m < l + 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
-  int lg = 0;
-  while (((size_t)1 << lg) < n + l + 1) lg++;
-  if (lg > 22) return fail(ZKHIP_ERR_ARG, "domain larger than 2^22");
-  const size_t d = (size_t)1 << lg;
+  // the evaluation domain libfqfft picks for n + l + 1 points (domain.hpp): a power of two or 2^k + 2^r (step_radix2_domain)
+  const size_t d = eval_domain_size(n + l + 1);
+  if (d > ((size_t)1 << 22)) return fail(ZKHIP_ERR_ARG, "domain larger than 2^22");
   HFr tau = HFr::from_limbs(tau_m), alpha = HFr::from_limbs(alpha_m), beta = HFr::from_limbs(beta_m), delta = HFr::from_limbs(delta_m);
   if (delta.is_zero()) return fail(ZKHIP_ERR_ARG, "delta must be invertible");
-  // Lagrange basis at tau: L_j(tau) = Z(tau) w^j / (d (tau - w^j)), one batch inversion
-  HFr omega = HFr::from_limbs(FrParams::ROOT_2_46_64);
-  for (int i = 0; i < FrParams::TWO_ADICITY - lg; i++) omega = omega.sqr();
-  uint64_t e[1] = {(uint64_t)d};
-  HFr Zt = tau.pow_limbs(e, 1) - HFr::one();
-  std::vector<HFr> w(d), den(d), pref(d);
-  HFr acc = HFr::one(), wj = HFr::one();
-  for (size_t j = 0; j < d; j++) {
-    w[j] = wj; den[j] = tau - wj;
-    if (den[j].is_zero()) return fail(ZKHIP_ERR_ARG, "tau lies in the evaluation domain");
-    pref[j] = acc; acc = acc * den[j]; wj = wj * omega;
-  }
-  HFr inv_all = acc.inv(), dinv = HFr::from_u64((uint64_t)d).inv();
-  std::vector<HFr> Lg(d);
-  for (size_t j = d; j-- > 0;) {
-    HFr dj_inv = inv_all * pref[j];
-    inv_all = inv_all * den[j];
-    Lg[j] = Zt * w[j] * dinv * dj_inv;
-  }
+  // Lagrange basis at tau, one batch inversion
+  const EvalDomain dom(d);
+  const HFr Zt = dom.vanishing(tau);
+  std::vector<HFr> Lg;
+  if (!dom.lagrange_at(tau, Lg)) return fail(ZKHIP_ERR_ARG, "tau lies in the evaluation domain");
   std::vector<HFr> At(m, HFr::zero()), Bt(m, HFr::zero()), Ct(m, HFr::zero());
   auto accumulate = [&](const uint32_t* rp, const uint32_t* col, const uint64_t* val, std::vector<HFr>& out_) {
     for (size_t j = 0; j < n; j++)
@@ -1108,7 +1096,8 @@ int zkhip_keypair_read(const char* path, zkhip_keypair** out) {
   if (fread(hdr, 8, 8, f) != 8 || memcmp(&hdr[0], KP_MAGIC, 8) != 0) { fclose(f); return fail(ZKHIP_ERR_ARG, "not a keypair file (bad magic)"); }
   const uint64_t m = hdr[1], l = hdr[2], d = hdr[3];
   // the prover's domains stop at 2^22 points; a key has at most that many variables (one constraint defines at most one)
-  if (m < l + 1 || d < 1 || (d & (d - 1)) || m > ((uint64_t)1 << 23) || d > ((uint64_t)1 << 22)) { fclose(f); return fail(ZKHIP_ERR_ARG, "keypair file: implausible sizes"); }
+  // (the domain is one that get_evaluation_domain can return: a power of two or 2^k + 2^r - a fixed point of eval_domain_size)
+  if (m < l + 1 || d < 1 || host::eval_domain_size((size_t)d) != d || m > ((uint64_t)1 << 23) || d > ((uint64_t)1 << 22)) { fclose(f); return fail(ZKHIP_ERR_ARG, "keypair file: implausible sizes"); }
   // the header fixes the file's length: check it before any allocation is sized by it
   {
     const uint64_t pts = 5 + 3 * m + (d - 1) + (m - l - 1) + (l + 1), want = 64 + 8 * 24 * pts + 8;
@@ -1455,6 +1444,13 @@ int zkhip_msm_stream_last_accumulate_interval(zkhip_msm_stream* st, float out_ms
   std::lock_guard<std::mutex> lk(st->mu);
   out_ms[0] = st->last_interval[0]; out_ms[1] = st->last_interval[1];
   return ZKHIP_OK;
+}
+
+int zkhip_measure_fq_mul_rate(double* fq_mul_per_s) {
+  BIND_CUR();
+  if (!fq_mul_per_s) return fail(ZKHIP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> lk(g.dev[cur_dev()].mu);
+  return msm_measure_fqmul_rate(fq_mul_per_s, t_err, sizeof t_err);
 }
 
 // pinned host memory for callers without a HIP runtime of their own (source of zkhip_msm_stream_submit_host's asynchronous copies)

@@ -17,7 +17,7 @@ EXPORTS = [
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_msm_submit", "zkhip_msm_collect",
     "zkhip_device_alloc", "zkhip_device_free", "zkhip_device_copy_in", "zkhip_last_accumulate_ms",
     "zkhip_prover_set_streaming", "zkhip_set_table_naf", "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
-    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
+    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_domain_size", "zkhip_domain_size", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
     "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings", "zkhip_groth16_verify",
     "zkhip_crs_upload_slice", "zkhip_groth16_prove_partial", "zkhip_groth16_finish",
     "zkhip_bls12_377_groth16_verify", "zkhip_aggregator_new", "zkhip_aggregator_free", "zkhip_aggregator_num_constraints",
@@ -29,7 +29,7 @@ EXPORTS = [
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
     "zkhip_last_accumulate_interval", "zkhip_crs_upload_ex", "zkhip_crs_upload_slice_ex", "zkhip_bases_precompute_ex", "zkhip_crs_table_kind", "zkhip_crs_finite_terms",
-    "zkhip_reset_time_base", "zkhip_host_alloc", "zkhip_host_free",
+    "zkhip_reset_time_base", "zkhip_measure_fq_mul_rate", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_msm_stream_new", "zkhip_msm_stream_submit", "zkhip_msm_stream_submit_host", "zkhip_msm_stream_collect", "zkhip_msm_stream_last_accumulate_ms",
     "zkhip_msm_stream_last_accumulate_interval", "zkhip_msm_stream_free", "zkhip_prover_new_slice", "zkhip_prover_prove_partial",
     "zkhip_dispatcher_new", "zkhip_dispatcher_size", "zkhip_dispatcher_submit", "zkhip_dispatcher_wait", "zkhip_dispatcher_stats", "zkhip_dispatcher_free",
@@ -116,6 +116,10 @@ def load():
     lib.zkhip_r1cs_free.argtypes = [ctypes.c_void_p]
     lib.zkhip_r1cs_log_domain.argtypes = [ctypes.c_void_p]
     lib.zkhip_r1cs_log_domain.restype = ctypes.c_uint
+    lib.zkhip_r1cs_domain_size.argtypes = [ctypes.c_void_p]
+    lib.zkhip_r1cs_domain_size.restype = ctypes.c_size_t
+    lib.zkhip_domain_size.argtypes = [ctypes.c_size_t]
+    lib.zkhip_domain_size.restype = ctypes.c_size_t
     lib.zkhip_r1cs_is_satisfied.argtypes = [ctypes.c_void_p, c_u64p, ctypes.POINTER(ctypes.c_int)]
     lib.zkhip_qap_h.argtypes = [ctypes.c_void_p, c_u64p, c_u64p]
     lib.zkhip_crs_upload.argtypes = [ctypes.POINTER(CrsDesc), ctypes.POINTER(ctypes.c_void_p)]
@@ -442,6 +446,7 @@ class R1cs:
         self.handle = h
         self._keep = []
         self.log_d = int(load().zkhip_r1cs_log_domain(h))
+        self.domain_size = int(load().zkhip_r1cs_domain_size(h))     # a power of two, or 2^k + 2^r (libfqfft's step_radix2_domain)
 
     def is_satisfied(self, z):
         zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(self.n_vars, 6)
@@ -451,7 +456,7 @@ class R1cs:
 
     def qap_h(self, z):
         zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(self.n_vars, 6)
-        h = np.zeros((1 << self.log_d, 6), dtype=np.uint64)
+        h = np.zeros((self.domain_size, 6), dtype=np.uint64)
         _check(load().zkhip_qap_h(self.handle, _p(zz), _p(h)))
         return h
 
@@ -889,6 +894,7 @@ def r1cs_from_desc(desc):
     r.handle, r._keep = h, []
     r.n_vars, r.n_primary, r.n_constraints = desc.n_vars, desc.n_primary, desc.n_constraints
     r.log_d = int(load().zkhip_r1cs_log_domain(h))
+    r.domain_size = int(load().zkhip_r1cs_domain_size(h))
     return r
 
 
@@ -897,6 +903,11 @@ def aggregator_vk_hash(nested_vk, inputs_per_nested_proof=1):
     out = np.zeros(6, dtype=np.uint64)
     _check(load().zkhip_aggregator_vk_hash(_p(vk), inputs_per_nested_proof, _p(out)))
     return out
+
+
+def domain_size(min_size):
+    """Points of the evaluation domain libfqfft picks for min_size points (host code)."""
+    return int(load().zkhip_domain_size(min_size))
 
 
 def last_prove_timings():
@@ -920,6 +931,13 @@ def jac_add(a, b):
 
 def last_accumulate_ms():
     return float(load().zkhip_last_accumulate_ms())
+
+
+def measure_fq_mul_rate():
+    """Fq multiplications per second of the device, measured now (dependent fp_mul chains, two waves per SIMD)."""
+    v = ctypes.c_double(0)
+    _check(load().zkhip_measure_fq_mul_rate(ctypes.byref(v)))
+    return float(v.value)
 
 
 def reset_time_base():
