@@ -233,6 +233,11 @@ __device__ __forceinline__ bool madd_lds_regy(const XyzzRef& acc, uint32_t* xs, 
 // coordinate loads per addition (of B only: ZZ2 and ZZZ2 twice) and one accumulator store at the very end, where add_mem_s moves
 // ten loads and four stores per addition - the plain sums of the bucket reduction are bound by those round trips, not by the
 // multiplier.  `spill` is where the accumulator goes on the rare same-x path.  Returns true if that path ran.
+// (Round 4, measured and left out: loading every coordinate of B once - parking ZZ2 / ZZZ2 in the dead temporary, carrying them in `b`
+// across the loop's back edge, or a second call site of the multiplier for the product that shares the factor - takes the gathers
+// from six to four per addition, but the rolled loop already holds T0 .. T3, Y and both operands live at the 256-register limit:
+// the three forms compiled to 51 - 185 spilled registers where this one has 1.  Also without effect on the kernel's 368 us per
+// launch: testing B for infinity on the first row of its ZZ only, and wave priorities by progress as in k_accumulate.)
 __device__ __forceinline__ bool add_lds_regy(const XyzzRef& spill, uint32_t* xs, uint32_t* zz, uint32_t* zzz, Fq& ty, const XyzzRef& B) {
   Fq T0 = fp_zero<FqParams>(), T1 = T0, T2 = T0, T3 = T0;
   bool same_x = false;
