@@ -67,7 +67,46 @@ __device__ __forceinline__ Fp<PR> fp_mul_kara(Fp<PR> a, Fp<PR> b) {
   return r;
 }
 
-template <int KIND>   // 0: fp_mul chain, 1: fp_sqr chain, 2: fp_mul2 chain, 3: Karatsuba fp_mul chain
+// fp_mul with ONE accumulator carried through all columns (the source's own shape): hipcc splits the column sums of fp_mul over
+// several accumulators and joins them with a 64-bit addition per column (v_lshl_add_u64: as dear as a mad).  Here every mad is an
+// asm statement on the same register pair, so the chain cannot be split: 53 fewer 64-bit additions per product - if a wave's
+// dependent mads issue back to back.  MEASURED (profiles/r04_ubench_multiplier.txt): 22.0 G fp_mul/s against 20.3 - 21.8 for fp_mul
+// with two or four waves per SIMD, 12.8 against 17.4 with one.  Built into fp29.cuh's three multiplier bodies it made the
+// accumulation kernel 20 KB larger (114 KB: the scalar operands of the asm statements are re-materialised; the hot loop no longer fits
+// the 64 KB instruction cache) and the first run of the library built that way HUNG on the GPU box (killed after 420 s without
+// output; not debugged on shared hardware): not adopted.
+#define ZK_MAD(acc, x, y) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc")
+#define ZK_MAD_S(acc, x, c) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(c) : "vcc")
+template <class PR>
+__device__ __forceinline__ Fp<PR> fp_mul_chain(Fp<PR> a, Fp<PR> b) {
+  constexpr int N = PR::NL;
+  Fp<PR> r;
+  uint32_t m[N];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) ZK_MAD(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; i++) ZK_MAD_S(acc, m[i], PR::P[k - i]);
+    m[k] = ((uint32_t)acc * PR::PINV) & M29;
+    ZK_MAD_S(acc, m[k], PR::P[0]);
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) ZK_MAD(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) ZK_MAD_S(acc, m[i], PR::P[k - i]);
+    r.l[k - N] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  r.l[N - 1] = (uint32_t)acc;
+  return r;
+}
+
+template <int KIND>   // 0: fp_mul chain, 1: fp_sqr chain, 2: fp_mul2 chain, 3: Karatsuba fp_mul chain, 4: single-accumulator fp_mul
 __global__ void __launch_bounds__(256) k_chain(const uint32_t* in, uint32_t* out, int iters) {
   extern __shared__ uint32_t lds[];
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,6 +120,7 @@ __global__ void __launch_bounds__(256) k_chain(const uint32_t* in, uint32_t* out
     if (KIND == 1) { x = fp_sqr(x); y = fp_sqr(y); }
     if (KIND == 2) { x = fp_mul2(x, y, z, x); y = fp_mul2(y, x, z, y); }
     if (KIND == 3) { x = fp_mul_kara(x, y); y = fp_mul_kara(y, x); }
+    if (KIND == 4) { x = fp_mul_chain(x, y); y = fp_mul_chain(y, x); }
   }
   uint32_t s = 0;
   for (int i = 0; i < 27; i++) s ^= x.l[i] + y.l[i];
@@ -124,6 +164,7 @@ static bool check_kara() {
   CHECK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CHECK(hipFuncSetAttribute((const void*)k_chain<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CHECK(hipFuncSetAttribute((const void*)k_chain<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHECK(hipFuncSetAttribute((const void*)k_chain<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   k_chain<0><<<1, 64, 1024>>>(in, o0, 3);
   k_chain<3><<<1, 64, 1024>>>(in, o3, 3);
   CHECK(hipDeviceSynchronize());
@@ -131,18 +172,23 @@ static bool check_kara() {
   CHECK(hipMemcpy(a.data(), o0, words * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(b.data(), o3, words * 4, hipMemcpyDeviceToHost));
   bool ok = true;
   for (size_t i = 64; i < words; i++) ok = ok && a[i] == b[i];
+  k_chain<4><<<1, 64, 1024>>>(in, o3, 3);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipMemcpy(b.data(), o3, words * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 64; i < words; i++) ok = ok && a[i] == b[i];
   CHECK(hipFree(in)); CHECK(hipFree(o0)); CHECK(hipFree(o3));
   return ok;
 }
 
 int main() {
-  printf("Karatsuba multiplier equals fp_mul on 64 lanes x 6 chained products: %s\n", check_kara() ? "yes" : "NO");
+  printf("Karatsuba and single-accumulator multipliers equal fp_mul on 64 lanes x 6 chained products: %s\n", check_kara() ? "yes" : "NO");
   struct { size_t lds; int waves; double peak; } occ[] = {{150 * 1024, 1, 224.0}, {78 * 1024, 2, 415.0}, {38 * 1024, 4, 448.0}};
   for (auto& o : occ) {
     run<0>("fp_mul", 1458, o.lds, o.waves, o.peak);
     run<1>("fp_sqr", 1107, o.lds, o.waves, o.peak);
     run<2>("fp_mul2", 2187, o.lds, o.waves, o.peak);
     run<3>("fp_mul_kara (1,290 mads; rate in fp_mul-equivalents of 1,458)", 1458, o.lds, o.waves, o.peak);
+    run<4>("fp_mul_chain (one accumulator)", 1458, o.lds, o.waves, o.peak);
   }
   return 0;
 }
