@@ -1589,6 +1589,10 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
     if (fills < 1) fills = 1;
     size_t S = (m + lanes * fills - 1) / (lanes * fills);
     if (S < 16) S = 16;
+    // provers that share the chip (the streaming pipeline) take slices twice as long - half as many lanes a launch, half as many
+    // buckets cut by a slice boundary to stitch afterwards; the other proofs in flight fill the chip.  Measured on the wrapping key,
+    // 24 provers in flight, device side only: x1 349 proofs/s, x2 361, x3 358, x4 352 (tools/acc_probe.py --prove-stream).
+    if (ctx->one_stream) S *= (size_t)env_int("ZKHIP_STREAM_SLICE_MULT", 2, 1, 16);
     // a bucket should not span more than ~3 slices (the stitching folds 2 .. 4 pieces by one lane; longer chains go through a
     // workgroup each, which is for the few heavy buckets of a witness, not for every bucket of a small MSM with a narrow window)
     {

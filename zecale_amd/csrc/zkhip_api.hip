@@ -642,10 +642,9 @@ int zkhip_last_prove_timings(double out_ms[8]) {
 // the A / B queries (indices into z), [h_lo, h_lo + h_len) of the H query (indices into h), [l_lo, l_lo + l_len) of the
 // L query (indices into z[n_primary+1 ..]).  The whole key is the slice (0, n_vars), (0, d - 1), (0, n_vars - l - 1).
 // z: host assignment (uploaded here) - or d_z_ready: the assignment already in device memory, ABI form, complete (GPU witness)
-static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
-                         uint64_t sums[5 * 36], const uint64_t* d_z_ready = nullptr) {
-  using clk = std::chrono::steady_clock;
-  auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+// the cheap argument and size checks of a proof, before anything is started for it (the tail's scalar multiplications used to
+// be spawned before them)
+static int prove_check(const zkhip_crs* crs, const R1csDev* rd, size_t a_lo, size_t h_lo, size_t l_lo) {
   const size_t m = rd->n_vars, l = rd->n_primary, d = rd->d;
   const size_t a_len = crs->A->len, h_len = crs->H->len, l_len = crs->L->len;
   if (crs->n_vars != m || crs->n_primary != l || crs->domain_size != d) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
@@ -657,6 +656,17 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     return fail(ZKHIP_ERR_ARG, "the five query vectors of a proving key must share one kind of table");
   if (crs->B2->table_c != tc || crs->B1->table_c != tc || crs->H->table_c != tc || crs->L->table_c != tc)
     return fail(ZKHIP_ERR_ARG, "the five query vectors of a proving key must share one table window");
+  return ZKHIP_OK;
+}
+
+static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
+                         uint64_t sums[5 * 36], const uint64_t* d_z_ready = nullptr) {
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+  const size_t m = rd->n_vars, l = rd->n_primary;
+  const size_t a_len = crs->A->len, h_len = crs->H->len, l_len = crs->L->len;
+  { int rc_ = prove_check(crs, rd, a_lo, h_lo, l_lo); if (rc_ != ZKHIP_OK) return rc_; }
+  const int tc = crs->A->table_c;
   auto t0 = clk::now();
   if (!ps.st) API_HIP(hipStreamCreateWithFlags(&ps.st, hipStreamNonBlocking));
   if (!ps.ev_st) API_HIP(hipEventCreateWithFlags(&ps.ev_st, hipEventBlockingSync | hipEventDisableTiming));
@@ -822,6 +832,7 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
     std::lock_guard<std::mutex> lk(g.dev[crs->device].mu);
     const size_t m = r1cs->dev->n_vars, l = r1cs->dev->n_primary, d = r1cs->dev->d;
     if (crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+    { int rc_ = prove_check(crs, r1cs->dev, 0, 0, 0); if (rc_ != ZKHIP_OK) return rc_; }
     tail_begin(pre, crs->delta_g1, crs->delta_g2, r_m, s_m);       // the key-only part of the tail runs under the device work
     int rc = prove_partial(g.dev[crs->device].ps, crs, r1cs->dev, z, 0, 0, 0, sums);
     if (rc != ZKHIP_OK) return rc;
@@ -904,6 +915,7 @@ static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t*
   std::lock_guard<std::mutex> lk(p->mu);
   uint64_t sums[180];
   const zkhip_crs* c = p->crs;
+  { int rc_ = prove_check(c, p->rd, 0, 0, 0); if (rc_ != ZKHIP_OK) return rc_; }
   TailPre pre;
   tail_begin(pre, c->delta_g1, c->delta_g2, r_m, s_m);             // the key-only part of the tail runs under the device work
   int rc = prove_partial(p->ps, p->crs, p->rd, z, 0, 0, 0, sums, d_z);
