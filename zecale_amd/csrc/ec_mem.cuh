@@ -35,6 +35,15 @@ __device__ __forceinline__ XyzzRef make_ref(uint32_t* base, uint32_t stride, uin
 }
 enum { CX = 0, CY = 1, CZZ = 2, CZZZ = 3 };
 
+// a == 0 (mod p) for a in [0, 2p), for a value that is almost never zero (PP of an addition: zero only when the two points share
+// their x coordinate).  The full test reads all 27 limbs twice (~100 instructions in every addition); zero and p both show in the
+// LOWEST limb (0 or p's), so the full test runs only when some lane of the wave passes that necessary condition.
+__device__ __forceinline__ bool fp_is_zero_2p_rare(const Fq& a) {
+  const bool maybe = (a.l[0] == 0u) | (a.l[0] == FqParams::P[0]);
+  if (!__any(maybe)) return false;
+  return maybe && fp_is_zero_2p(a);
+}
+
 __device__ __forceinline__ Fq mem_ld(const XyzzRef& r, int c) {
   Fq v;
 #pragma unroll
@@ -128,7 +137,7 @@ __device__ __forceinline__ bool madd_mem(const XyzzRef& acc, const AffPacked* p,
     switch (step) {
       case 0: T0 = fp_sub<FqParams, 16>(r, mem_ld(acc, CX)); break;  // P  [18]
       case 1: T1 = fp_sub<FqParams, 4>(r, mem_ld(acc, CY)); break;   // R  [6]
-      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
+      case 2: T2 = r; same_x = fp_is_zero_2p_rare(r); break;              // PP
       case 3: T3 = r; break;                                         // PPP
       case 4: mem_st(acc, CZZ, r); break;
       case 5: mem_st(acc, CZZZ, r); break;
@@ -202,7 +211,7 @@ __device__ __forceinline__ bool madd_lds_regy(const XyzzRef& acc, uint32_t* xs, 
     switch (step) {
       case 0: T0 = fp_sub<FqParams, 16>(r, lds_ld_packed(xs)); break; // P  [18]
       case 1: T1 = fp_sub<FqParams, 4>(r, ty); break;                // R  [6]
-      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
+      case 2: T2 = r; same_x = fp_is_zero_2p_rare(r); break;              // PP
       case 3: T3 = r; break;                                         // PPP
       case 4: lds_st(zz, r); break;
       case 5: lds_st(zzz, r); break;
@@ -262,7 +271,7 @@ __device__ __forceinline__ bool add_lds_regy(const XyzzRef& spill, uint32_t* xs,
     switch (step) {
       case 0: T0 = r; break;                                         // U1
       case 1: T1 = fp_sub<FqParams, 2>(r, T0); break;                // P [4]
-      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
+      case 2: T2 = r; same_x = fp_is_zero_2p_rare(r); break;              // PP
       case 3: T1 = r; break;                                         // PPP
       case 4: T0 = r; break;                                         // Q
       case 5: lds_st(zz, r); break;
@@ -332,7 +341,7 @@ __device__ __forceinline__ void add_mem_s(const XyzzRef& A, const XyzzRef& B, ui
     switch (step) {
       case 0: T0 = r; break;                                         // U1
       case 1: T1 = fp_sub<FqParams, 2>(r, T0); break;                // P [4]
-      case 2: T2 = r; same_x = fp_is_zero_2p(r); break;              // PP
+      case 2: T2 = r; same_x = fp_is_zero_2p_rare(r); break;              // PP
       case 3: T1 = r; break;                                         // PPP
       case 4: T0 = r; break;                                         // Q
       case 5: lds_st(zz, r); break;

@@ -1172,11 +1172,15 @@ int msm_measure_fqmul_rate(double* fq_mul_per_s, char* errbuf, size_t errlen) {
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_fqmul_chain, dim3(blocks), dim3(256), lds, 0, in, out, 2);          // (code and clocks warm)
     hipLaunchKernelGGL(k_fqmul_chain, dim3(blocks), dim3(256), lds, 0, in, out, iters);
-    e = hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_fqmul_chain, dim3(blocks), dim3(256), lds, 0, in, out, iters);
-    if (e == hipSuccess) e = hipEventRecord(e1, 0);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    for (int rep = 0; rep < 4 && e == hipSuccess; rep++) {                                   // a PEAK: the fastest of four launches
+      float t = 0;
+      e = hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(k_fqmul_chain, dim3(blocks), dim3(256), lds, 0, in, out, iters);
+      if (e == hipSuccess) e = hipEventRecord(e1, 0);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+      if (e == hipSuccess && (ms == 0 || t < ms)) ms = t;
+    }
   }
   if (in) (void)hipFree(in);
   if (out) (void)hipFree(out);
