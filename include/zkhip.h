@@ -89,6 +89,9 @@ int zkhip_bases_precompute(zkhip_bases* b, int c);
 /* the same with the kind of table as an argument (zkhip_key_opts.table_naf: -1 default, 0 one level per window, 1 every bit position) */
 int zkhip_bases_precompute_ex(zkhip_bases* b, int c, int table_naf);
 int zkhip_bases_table_window(const zkhip_bases* b);      /* 0: no table */
+/* plain base set (no table): the window c of the bucket method for the MSMs over THIS set, 0 = by the number of terms (default),
+ * else 4 .. 18.  An option of the handle, like zkhip_key_opts of a key (the process-wide zkhip_set_msm_window is deprecated). */
+int zkhip_bases_set_window(zkhip_bases* b, int c);
 int zkhip_set_crs_precompute(int on);
 /* on = 1: window tables built from now on hold EVERY bit position (378 levels, sixteen times the memory) and scalars are recoded in
    non-adjacent form: an eighth fewer point additions per scalar, but measured slower once the tables outgrow the TLB (DESIGN.md

@@ -74,7 +74,7 @@ def test_prover_instances_match_the_plain_entry_point(zk):
 
 
 def test_naf_table_key_proves_the_same(zk):
-    """The proving key's window tables with every bit position and the scalars in non-adjacent form (zkhip_set_table_naf): the five
+    """The proving key's window tables with every bit position and the scalars in non-adjacent form (zkhip_key_opts.table_naf): the five
     MSMs of a wrapping proof - real witness scalars, a B query with points at infinity, the H coefficients - give the same proof
     as the default tables, through the plain entry point and through a streaming prover instance."""
     agg, desc, kp, nvk_l, proofs = _setup(zk)
@@ -84,11 +84,7 @@ def test_naf_table_key_proves_the_same(zk):
     crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
     expected = zk.groth16_prove(crs, r1, z, r, s_)
     crs.free()
-    zk.set_table_naf(1)
-    try:
-        crs2 = kp.upload_crs()
-    finally:
-        zk.set_table_naf(-1)
+    crs2 = kp.upload_crs(zk.key_opts(table_naf=True))
     assert (zk.groth16_prove(crs2, r1, z, r, s_) == expected).all()
     p = zk.Prover(crs2, desc)
     p.set_streaming(True)

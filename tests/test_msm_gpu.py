@@ -26,18 +26,22 @@ def affine_levels(request, zk):
     zk.set_affine_levels(-1)
 
 
-@pytest.fixture(params=[0, 1], ids=["windows", "naf"])
-def table_kind(request, zk):
-    """The table-backed cases run with both kinds of table: one level per window (default), and every bit position with the scalars
-    recoded in non-adjacent form (zkhip_set_table_naf: odd signed digits at arbitrary positions, the same group element)."""
-    zk.set_table_naf(request.param)
-    yield request.param
-    zk.set_table_naf(-1)
+@pytest.fixture(params=[False, True], ids=["windows", "naf"])
+def table_kind(request):
+    """The table-backed cases run with both kinds of table: one level per window, and every bit position with the scalars recoded in
+    non-adjacent form (odd signed digits at arbitrary positions, the same group element).  The kind is an option of the base set's
+    HANDLE (zkhip_bases_precompute_ex; round 4: these tests used to steer through the deprecated process-wide zkhip_set_table_naf)."""
+    return request.param
 
 
 def _msm_aff(zk, bases, scal, montgomery=True, window=0):
-    zk.set_msm_window(window)
-    return zk.jac_to_affine(zk.msm_raw(bases, scal, montgomery=montgomery))
+    """One MSM over a plain base set; the window is an option of the handle (zkhip_bases_set_window)."""
+    if len(bases) == 0:
+        return zk.jac_to_affine(zk.msm_raw(bases, scal, montgomery=montgomery))
+    b = zk.Bases.upload(bases).set_window(window)
+    out = zk.jac_to_affine(b.msm(scal, montgomery=montgomery))
+    b.free()
+    return out
 
 
 @pytest.mark.parametrize("window", [0, 5, 9])
@@ -137,7 +141,6 @@ def test_full_size_2_20_closed_form(zk, oracle_lib):
     to_int = lambda a: [int(x[0]) | int(x[1]) << 64 | int(x[2]) << 128 | int(x[3]) << 192 | int(x[4]) << 256 | int(x[5]) << 320
                         for x in a.tolist()]
     ki, si, ti = to_int(ks), to_int(s), to_int(t)
-    zk.set_msm_window(0)
     ms = b.msm(s, montgomery=False)
     mt = b.msm(t, montgomery=False)
     dot = sum(a * k for a, k in zip(si, ki)) % R.R_MOD
@@ -162,52 +165,47 @@ def test_heavy_buckets_are_stitched(zk, oracle_lib):
     scal[sel < 0.5] = one
     scal[(sel >= 0.5) & (sel < 0.7)] = scal[0]
     for window in (0, 8):
-        zk.set_msm_window(window)
-        got = zk.jac_to_affine(zk.msm_raw(bases, scal, montgomery=False))
+        got = _msm_aff(zk, bases, scal, montgomery=False, window=window)
         # oracle takes Montgomery scalars: convert canonical -> Montgomery on the oracle side
         scal_m = np.array([O.f_op("from_canonical", 1, s) for s in scal])
         assert (got == O.jac_to_affine(O.msm(bases, scal_m))).all()
-    zk.set_msm_window(0)
 
 
 # ---- window tables (zkhip_bases_precompute): same group element as the plain path and as the oracle ----
 
-@pytest.mark.usefixtures("table_kind")
 @pytest.mark.parametrize("window", [0, 5, 9, 13])
-def test_table_golden_vectors(zk, window):
+def test_table_golden_vectors(zk, window, table_kind):
     """Every golden MSM vector through a table-backed base set (includes infinity bases, P + (-P), r - 1)."""
     for case in golden("msm_vectors.json"):
         bases = np.array([aff_limbs(pt_from_json(p)) for p in case["bases"]])
         scal = fr_array([h2i(s) for s in case["scalars"]])
-        b = zk.Bases.upload(bases).precompute(window)
+        b = zk.Bases.upload(bases).precompute(window, table_naf=table_kind)
         assert b.table_window == (window or b.table_window) and b.table_window > 0
         got = aff_point(zk.jac_to_affine(b.msm(scal)))
         b.free()
         assert got == pt_from_json(case["result"]), case["name"]
 
 
-@pytest.mark.usefixtures("table_kind")
 @pytest.mark.parametrize("n,window", [(1 << 10, 0), (5000, 11), (1 << 14, 0), (1 << 14, 17), (3001, 20)])
-def test_table_random_vs_oracle(zk, oracle_lib, n, window):
+def test_table_random_vs_oracle(zk, oracle_lib, n, window, table_kind):
     O = oracle_lib
     bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(300 + n, n), montgomery=False)
     bases[7] = 0                                     # a base at infinity
     scal = random_fr_canonical(400 + n, n)
     scal[3] = 0
     scal[4, :] = 0; scal[4, 0] = 1
-    b = zk.Bases.upload(bases).precompute(window)
+    b = zk.Bases.upload(bases).precompute(window, table_naf=table_kind)
     exp = O.jac_to_affine(O.msm(bases, scal))
     assert (zk.jac_to_affine(b.msm(scal)) == exp).all()
     # sub-range of a table-backed set
     off, ln = 17, n - 100
     assert (zk.jac_to_affine(b.msm(scal[:ln], offset=off)) == O.jac_to_affine(O.msm(bases[off:off + ln], scal[:ln]))).all()
     with pytest.raises(zk.ZkhipError):
-        b.precompute(window)                         # only once
+        b.precompute(window, table_naf=table_kind)   # only once
     b.free()
 
 
-@pytest.mark.usefixtures("table_kind")
-def test_table_g2_and_witness_like(zk, oracle_lib):
+def test_table_g2_and_witness_like(zk, oracle_lib, table_kind):
     O = oracle_lib
     n = 4096
     bases = zk.fixed_base_mul(aff_limbs(R.G2_GEN), random_fr_canonical(501, n), montgomery=False)
@@ -216,13 +214,12 @@ def test_table_g2_and_witness_like(zk, oracle_lib):
     scal = fr_array([0 if s < 0.35 else 1 if s < 0.7 else int(x) for s, x in zip(sel, rng.integers(2, 1 << 62, n))])
     big = random_fr_canonical(502, n)
     scal[sel > 0.85] = big[sel > 0.85]
-    b = zk.Bases.upload(bases).precompute()
+    b = zk.Bases.upload(bases).precompute(table_naf=table_kind)
     assert (zk.jac_to_affine(b.msm(scal)) == O.jac_to_affine(O.msm(bases, scal))).all()
     b.free()
 
 
-@pytest.mark.usefixtures("table_kind")
-def test_table_point_of_order_two(zk, oracle_lib):
+def test_table_point_of_order_two(zk, oracle_lib, table_kind):
     """(1, 0) lies on G1's curve y^2 = x^3 - 1 and has order 2: every table level above 0 is the point at infinity.
     Not a proving-key element, but zkhip_msm is a general group operation."""
     O = oracle_lib
@@ -231,7 +228,7 @@ def test_table_point_of_order_two(zk, oracle_lib):
     bases[5] = aff_limbs((1, 0))
     assert O.on_curve(bases[5])
     scal = random_fr_canonical(602, n)
-    b = zk.Bases.upload(bases).precompute(6)
+    b = zk.Bases.upload(bases).precompute(6, table_naf=table_kind)
     assert (zk.jac_to_affine(b.msm(scal)) == O.jac_to_affine(O.msm(bases, scal))).all()
     b.free()
 
@@ -243,21 +240,19 @@ def test_table_full_size_2_20_matches_plain_path(zk):
     bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(61, n), montgomery=False)
     s = random_fr_canonical(62, n)
     b = zk.Bases.upload(bases)
-    zk.set_msm_window(0)
     plain = zk.jac_to_affine(b.msm(s, montgomery=False))
     b.precompute()
     assert (zk.jac_to_affine(b.msm(s, montgomery=False)) == plain).all()
     b.free()
 
 
-@pytest.mark.usefixtures("table_kind")
-def test_submit_collect_slots_in_flight(zk, oracle_lib):
+def test_submit_collect_slots_in_flight(zk, oracle_lib, table_kind):
     """zkhip_msm_submit / zkhip_msm_collect: two MSMs in flight on two slots return what the blocking call returns;
     a busy slot refuses a second submit, an idle slot has nothing to collect."""
     O = oracle_lib
     n = 6000
     bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(701, n), montgomery=False)
-    b = zk.Bases.upload(bases).precompute()
+    b = zk.Bases.upload(bases).precompute(table_naf=table_kind)
     scal = [random_fr_canonical(710 + i, n) for i in range(3)]
     dev = [zk.DeviceBuffer(s) for s in scal]
     exp = [O.jac_to_affine(O.msm(bases, s)) for s in scal]
@@ -325,4 +320,21 @@ def test_headline_2_20_uniform_scalars_eight_in_flight_against_the_oracle(zk, or
         stream.submit(dev.ptr, n)
     for t in tickets:
         assert (zk.jac_to_affine(stream.collect(t)) == exp).all()
+    stream.free(); dev.free(); b.free()
+
+
+def test_the_library_measures_its_multiplier_peak_and_rebases_its_clock(zk):
+    """zkhip_measure_fq_mul_rate: Fq products per second of this device, now (what bench.py's fq_mul_frac divides by: the rate differs
+    between boxes of the same model) - a plausible figure for an MI355X; zkhip_reset_time_base: the accumulate intervals restart near zero."""
+    rate = zk.measure_fq_mul_rate()
+    assert 8e9 < rate < 40e9, rate
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(801, 3000), montgomery=False)
+    b = zk.Bases.upload(bases)
+    stream = zk.MsmStream(b, depth=2)
+    dev = zk.DeviceBuffer(random_fr_canonical(802, 3000))
+    zk.reset_time_base()
+    stream.collect(stream.submit(dev.ptr, 3000))
+    t0, t1 = stream.last_accumulate_interval()
+    assert 0 <= t0 < t1 < 5000.0                     # milliseconds since the reset, not since the library first planned an MSM
+    assert abs((t1 - t0) - stream.last_accumulate_ms()) < 0.05
     stream.free(); dev.free(); b.free()

@@ -23,14 +23,16 @@ def _golden_case():
 
 
 @pytest.fixture(params=["tables+batched", "tables", "plain"])
-def key_mode(zk, request):
+def key_mode(request):
     """The three ways a proving key is held and its five MSMs are launched (all must give the same proof): window tables with
-    the five MSMs in one launch sequence (default), window tables with one launch sequence per MSM, plain base sets."""
-    zk.set_crs_precompute(request.param != "plain")
-    zk.set_batch_msms(request.param == "tables+batched")
-    yield request.param
-    zk.set_crs_precompute(True)
-    zk.set_batch_msms(True)
+    the five MSMs in one launch sequence (default), window tables with one launch sequence per MSM, plain base sets.  The mode is an
+    option of the KEY (zkhip_key_opts, resolved at upload; round 4: these tests used to steer through the deprecated process-wide
+    zkhip_set_crs_precompute / zkhip_set_batch_msms)."""
+    return request.param
+
+
+def _opts(zk, mode):
+    return zk.key_opts(precompute=mode != "plain", batch_msms=mode == "tables+batched")
 
 
 def test_golden_small_circuit(zk, key_mode):
@@ -43,7 +45,7 @@ def test_golden_small_circuit(zk, key_mode):
     zbad = z.copy(); zbad[3] = fr_limbs(12345)
     assert not r1.is_satisfied(zbad)
     assert fr_ints(r1.qap_h(z)) == [h2i(x) for x in g["h"]]
-    crs = zk.Crs(pk, len(g["z"]), g["n_primary"], 1 << g["log_d"])
+    crs = zk.Crs(pk, len(g["z"]), g["n_primary"], 1 << g["log_d"], opts=_opts(zk, key_mode))
     assert (crs.table_window > 0) == (key_mode != "plain")
     proof = zk.groth16_prove(crs, r1, z, fr_limbs(h2i(g["r"])), fr_limbs(h2i(g["s"])))
     assert aff_point(proof[:24]) == pt_from_json(g["proof"]["a"])
@@ -70,7 +72,7 @@ def test_synthetic_circuit_vs_oracle_and_trapdoor(zk, oracle_lib, key_mode, n, b
     h_or = O.qap_h(Ac, Bc, Cc, zl, n, n_primary)
     assert (h == h_or).all()
     assert (h[-1] == 0).all()
-    crs = zk.Crs(pk, m, n_primary, d)
+    crs = zk.Crs(pk, m, n_primary, d, opts=_opts(zk, key_mode))
     proof = zk.groth16_prove(crs, r1, zl, fr_limbs(r), fr_limbs(s))
     proof_or = O.groth16_prove(pk, zl, n_primary, h_or, fr_limbs(r), fr_limbs(s))
     assert (proof == proof_or).all()
@@ -168,16 +170,10 @@ def test_full_size_2_20_key_modes_agree(zk):
     z[0] = np.array(bench.zkhip_fr_one(), dtype=np.uint64)
     r, s = bench.random_fr_canonical(5, 1)[0], bench.random_fr_canonical(6, 1)[0]
     proofs = {}
-    try:
-        for mode in ("tables+batched", "tables", "plain"):
-            zk.set_crs_precompute(mode != "plain")
-            zk.set_batch_msms(mode == "tables+batched")
-            crs = zk.Crs(pk, m, l, d)
-            proofs[mode] = zk.groth16_prove(crs, r1, z, r, s)
-            crs.free()
-    finally:
-        zk.set_crs_precompute(True)
-        zk.set_batch_msms(True)
+    for mode in ("tables+batched", "tables", "plain"):
+        crs = zk.Crs(pk, m, l, d, opts=_opts(zk, mode))
+        proofs[mode] = zk.groth16_prove(crs, r1, z, r, s)
+        crs.free()
     assert (proofs["tables+batched"] == proofs["tables"]).all() and (proofs["tables"] == proofs["plain"]).all()
     assert proofs["plain"][:24].any()
     r1.free()

@@ -22,4 +22,5 @@ run msm_fetch        --pmc FETCH_SIZE --output-format csv -d $OUT/msm_fetch -o m
 run msm_write        --pmc WRITE_SIZE --output-format csv -d $OUT/msm_write -o msm -- python3 $ROOT/bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
 run calib_fetch      --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -o calib -- $ROOT/build/fetch_calib
 run calib_write      --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -o calib -- $ROOT/build/fetch_calib
+run prover_serial_trace --kernel-trace --stats --output-format csv -d $OUT/prover_serial_trace -o prover_serial -- python3 $ROOT/bench.py --workload prover --serial --steps 4 --warmup 1 --no-cpu-baseline
 ls -R $OUT | grep -c csv

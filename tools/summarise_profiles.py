@@ -12,7 +12,8 @@ DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 for d, pre, wl in (("msm_trace", "msm", "msm"), ("msm_only_trace", "msm", "msm_stream_only"), ("msm_serial_trace", "msm", "msm_serial"),
-                   ("prover_trace", "prover", "prover"), ("agg_trace", "agg", "aggregator"), ("agg_serial_trace", "agg_serial", "aggregator_serial")):
+                   ("prover_trace", "prover", "prover"), ("prover_serial_trace", "prover_serial", "prover_serial"),
+                   ("agg_trace", "agg", "aggregator"), ("agg_serial_trace", "agg_serial", "aggregator_serial")):
     src = os.path.join(SRC, d, pre + "_kernel_stats.csv")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(DST, f"{tag}_bench_{wl}_kernel_stats.csv"))
@@ -35,6 +36,20 @@ if solo and over:
         for k, (c, a, m) in sorted(solo.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
             if k in over and not k.startswith("zkhip::k_table") and not k.startswith("zkhip::k_fixed") and not k.startswith("zkhip::k_bases"):
                 f.write("%s,%.1f,%.1f,%.1f,%.1f,%.1f\n" % (k, c / n_solo, a, m, over[k][1], over[k][2]))
+
+
+# the same split for the 2^20 prover: one proof at a time against three provers in flight
+solo_p, over_p = _stats(os.path.join(SRC, "prover_serial_trace", "prover_serial_kernel_stats.csv")), _stats(os.path.join(SRC, "prover_trace", "prover_kernel_stats.csv"))
+if solo_p and over_p:
+    with open(os.path.join(DST, f"{tag}_prover_solo_vs_stream.csv"), "w") as f:
+        f.write("# per kernel of one 2^20-constraint Groth16 proof: total duration per proof (us) with ONE proof at a time (bench.py --workload prover --serial)\n")
+        f.write("# and with three provers in flight (bench.py --workload prover: launches of different proofs overlap in time, so their durations stretch)\n")
+        f.write("kernel,calls_per_proof,solo_us_per_proof,stream_us_per_proof\n")
+        n_solo = max(1, solo_p.get("zkhip::k_accumulate<5>", (1, 0, 0))[0])
+        n_over = max(1, over_p.get("zkhip::k_accumulate<5>", (1, 0, 0))[0])
+        for k, (c, a, m) in sorted(solo_p.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            if k in over_p and not k.startswith("zkhip::k_table") and not k.startswith("zkhip::k_fixed") and not k.startswith("zkhip::k_bases"):
+                f.write("%s,%.1f,%.1f,%.1f\n" % (k, c / n_solo, c * a / n_solo, over_p[k][0] * over_p[k][1] / n_over))
 
 
 def pmc(path):

@@ -28,6 +28,7 @@ struct zkhip_bases {
   int table_naf;     // 1: the table holds EVERY bit position (378 levels): scalars are recoded in non-adjacent form (msm.h, merged == 2)
   size_t n_finite;   // bases that are not the point at infinity (counted at upload)
   int device;        // the GPU that holds them
+  int plain_c = 0;   // plain base set: window of the MSMs over it (zkhip_bases_set_window; 0: by the number of terms)
 };
 
 struct zkhip_r1cs {
@@ -151,8 +152,8 @@ int auto_table_window(size_t n) {
 
 // table_c = 0: plain plan with the automatic window;  > 0: merged plan (bases are a window table built for table_c)
 // total: bound on the terms of all K jobs of a launch together (0: K * n)
-int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1, int naf = 0, size_t total = 0) {
-  const int c = table_c ? table_c : auto_window(n), merged = table_c ? (naf ? 2 : 1) : 0;
+int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1, int naf = 0, size_t total = 0, int plain_c = 0) {
+  const int c = table_c ? table_c : (plain_c ? plain_c : auto_window(n)), merged = table_c ? (naf ? 2 : 1) : 0;
   if (total == 0 || total > (size_t)K * n) total = (size_t)K * n;
   if (*ready && cx->pending) return fail(ZKHIP_ERR_STATE, "an MSM submitted on this context has not been collected (zkhip_msm_collect)");
   if (*ready && cx->max_n >= n && cx->total_terms >= total && cx->c == c && cx->merged == merged && cx->K == K && cx->aff_forced == msm_forced_aff_levels()) return ZKHIP_OK;
@@ -266,7 +267,7 @@ int zkhip_bases_upload_dev(const void* d_bases_affine, size_t len, zkhip_bases**
   if (!out || (len && !d_bases_affine)) return fail(ZKHIP_ERR_ARG, "null pointer");
   const int dev = cur_dev();
   std::lock_guard<std::mutex> lk(g.dev[dev].mu);
-  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len, 0, 0, len, dev};
+  zkhip_bases* b = new zkhip_bases{nullptr, nullptr, len, 0, 0, len, dev, 0};
   int rc = bases_upload_dev_impl(d_bases_affine, len, b);
   if (rc != ZKHIP_OK) { zkhip_bases_free(b); return rc; }      // whatever was allocated before the failure
   *out = b;
@@ -349,6 +350,13 @@ static int bases_precompute_mode(zkhip_bases* b, int c, int naf) {
   return ZKHIP_OK;
 }
 int zkhip_bases_table_window(const zkhip_bases* b) { return b ? b->table_c : 0; }
+int zkhip_bases_set_window(zkhip_bases* b, int c) {
+  if (!b) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (c != 0 && (c < 4 || c > 18)) return fail(ZKHIP_ERR_ARG, "window must be 0 (automatic) or in [4, 18]");
+  std::lock_guard<std::mutex> lk(g.dev[b->device].mu);
+  b->plain_c = c;
+  return ZKHIP_OK;
+}
 
 void zkhip_bases_free(zkhip_bases* b) {
   if (!b) return;
@@ -365,7 +373,7 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
   ProveState& ps = g.dev[bases->device].ps;
   std::lock_guard<std::mutex> lk(g.dev[bases->device].mu);
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
-  int rc = ensure_ctx(&ps.ctx[0], &ps.ready[0], len ? len : 1, bases->table_c, 1, bases->table_naf);
+  int rc = ensure_ctx(&ps.ctx[0], &ps.ready[0], len ? len : 1, bases->table_c, 1, bases->table_naf, 0, bases->plain_c);
   if (rc != ZKHIP_OK) return rc;
   rc = msm_run(&ps.ctx[0], bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                scalars_montgomery, bases->len, out_jac);
@@ -385,7 +393,7 @@ int zkhip_msm_submit(const zkhip_bases* bases, size_t offset, const void* d_scal
   if (offset > bases->len || len > bases->len - offset) return fail(ZKHIP_ERR_ARG, "offset + len exceeds the base set");
   MsmCtx* cx = &ps.ctx[slot];
   if (ps.ready[slot] && cx->pending) return fail(ZKHIP_ERR_STATE, "slot busy: collect its result first");
-  int rc = ensure_ctx(cx, &ps.ready[slot], len ? len : 1, bases->table_c, 1, bases->table_naf);
+  int rc = ensure_ctx(cx, &ps.ready[slot], len ? len : 1, bases->table_c, 1, bases->table_naf, 0, bases->plain_c);
   if (rc != ZKHIP_OK) return rc;
   // a stream of MSMs, optionally GATED (ZKHIP_MSM_GATE=1): the accumulation of this one waits for the end of the accumulation
   // submitted before it on another slot, so that two accumulations never share the chip.  Measured (tools/gate_ab.sh, 2^20 terms,
@@ -1402,7 +1410,7 @@ static int msm_stream_submit_impl(zkhip_msm_stream* st, size_t offset, const voi
   if (slot < 0) return fail(ZKHIP_ERR_STATE, "every slot of this stream is in flight: collect a result first");
   MsmCtx* cx = &st->ctx[slot];
   bool rdy = st->ready[slot] != 0;
-  int rc = ensure_ctx(cx, &rdy, len ? len : 1, b->table_c, 1, b->table_naf);
+  int rc = ensure_ctx(cx, &rdy, len ? len : 1, b->table_c, 1, b->table_naf, 0, b->plain_c);
   st->ready[slot] = rdy ? 1 : 0;
   if (rc != ZKHIP_OK) return rc;
   if (h_scalars && len) {

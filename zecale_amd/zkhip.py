@@ -29,7 +29,7 @@ EXPORTS = [
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
     "zkhip_last_accumulate_interval", "zkhip_crs_upload_ex", "zkhip_crs_upload_slice_ex", "zkhip_bases_precompute_ex", "zkhip_crs_table_kind", "zkhip_crs_finite_terms",
-    "zkhip_reset_time_base", "zkhip_measure_fq_mul_rate", "zkhip_host_alloc", "zkhip_host_free",
+    "zkhip_bases_set_window", "zkhip_reset_time_base", "zkhip_measure_fq_mul_rate", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_msm_stream_new", "zkhip_msm_stream_submit", "zkhip_msm_stream_submit_host", "zkhip_msm_stream_collect", "zkhip_msm_stream_last_accumulate_ms",
     "zkhip_msm_stream_last_accumulate_interval", "zkhip_msm_stream_free", "zkhip_prover_new_slice", "zkhip_prover_prove_partial",
     "zkhip_dispatcher_new", "zkhip_dispatcher_size", "zkhip_dispatcher_submit", "zkhip_dispatcher_wait", "zkhip_dispatcher_stats", "zkhip_dispatcher_free",
@@ -269,6 +269,12 @@ class Bases:
     @property
     def table_window(self):
         return load().zkhip_bases_table_window(self.handle)
+
+    def set_window(self, c):
+        """Plain base set: window of the MSMs over it (0 = by the number of terms); an option of this handle."""
+        load().zkhip_bases_set_window.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _check(load().zkhip_bases_set_window(self.handle, int(c)))
+        return self
 
     def free(self):
         if self.handle:
