@@ -20,6 +20,9 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "../../include/zkhip.h"
 
@@ -68,8 +71,17 @@ void finish_failed(zkhip_pipeline* p, const std::shared_ptr<Job>& j, int rc) {  
   p->cv_room.notify_one();
 }
 
+// The witness generators are the pipeline's CPU-heavy threads (7 ms on three threads per batch); the prover threads only enqueue
+// launches and sleep on events, but the GPU waits for them when they do not get a core at once.  The generators therefore run at a
+// lower scheduling priority (a per-thread nice value; the threads a generator spawns inherit it): ZKHIP_WITNESS_NICE, default 10.
+void lower_priority() {
+  static const int nice_by = [] { const char* e = getenv("ZKHIP_WITNESS_NICE"); int v = e ? atoi(e) : 10; return v < 0 || v > 19 ? 10 : v; }();
+  if (nice_by) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nice_by);
+}
+
 void witness_loop(zkhip_pipeline* p) {
   pthread_setname_np(pthread_self(), "zk-witness");
+  lower_priority();
   for (;;) {
     std::shared_ptr<Job> j;
     {
