@@ -16,7 +16,8 @@ struct CsrDev {
 };
 
 struct R1csDev {
-  int spmv_log_lanes = 4;      // lanes per row of the sparse products: 2^4 (a proof alone) or 2^2 (a prover that shares the chip)
+  int spmv_log_lanes = 4;      // lanes per row of the sparse products: 2^4 (a proof alone), 2^2 (a prover that shares the chip), 2^0 (short rows)
+  int spmv_log_lanes_alone = 4;   // what r1cs_upload chose for a proof alone (by the average row length)
   size_t n_constraints = 0, n_vars = 0, n_primary = 0;   // n_vars counts the constant ONE
   // The evaluation domain (domain.hpp): d points - a power of two (small == 0, big == d), or big + small with both powers of two
   // (libfqfft's step_radix2_domain).  log_d = ceil(log2 d).

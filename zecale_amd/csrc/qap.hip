@@ -285,6 +285,13 @@ static int r1cs_upload_impl(const zkhip_r1cs_desc* d, R1csDev* r, char* err, siz
   // the evaluation domain libfqfft picks for n + l + 1 points: a power of two, or 2^k + 2^r (step_radix2_domain; domain.hpp)
   const host::EvalDomain dom(host::eval_domain_size(d->n_constraints + d->n_primary + 1));
   if (dom.m > ((size_t)1 << 22)) { snprintf(err, errlen, "r1cs_upload: domain larger than 2^22"); return ZKHIP_ERR_ARG; }
+  // lanes per row of the sparse products: sixteen for a proof alone (a wrapping circuit has rows of 47 and 253 terms and fewer rows than the
+  // chip has lanes), ONE where the rows are short (a system of two-term rows, 2^20 of them: sixteen lanes a row made 1.7 ms of folding)
+  {
+    const size_t nnz = (size_t)d->a_row_ptr[d->n_constraints] + d->b_row_ptr[d->n_constraints] + d->c_row_ptr[d->n_constraints];
+    r->spmv_log_lanes_alone = (d->n_constraints && nnz <= 9 * d->n_constraints) ? 0 : 4;
+    r->spmv_log_lanes = r->spmv_log_lanes_alone;
+  }
   r->d = dom.m; r->big = dom.big; r->small = dom.small;
   r->log_d = host::ceil_log2(dom.m); r->log_big = dom.log_big; r->log_small = dom.log_small;
   size_t dd = dom.m;
@@ -371,7 +378,9 @@ static void spmv3(R1csDev* r, hipStream_t st) {
   for (int k = 0; k < 3; k++) { m.row_ptr[k] = M[k]->row_ptr; m.col[k] = M[k]->col; m.val[k] = M[k]->val; m.extra[k] = k == 0 ? (uint32_t)r->n_primary + 1 : 0u; }
   m.out[0] = r->bufA; m.out[1] = r->bufB; m.out[2] = r->bufC;
   const PartLayout lay = part_layout(r);
-  if (r->spmv_log_lanes == 2)
+  if (r->spmv_log_lanes == 0)
+    hipLaunchKernelGGL(k_spmv<0>, dim3((unsigned)(((size_t)d + 255) / 256), 3), dim3(256), 0, st, m, r->z, n, d, lay);
+  else if (r->spmv_log_lanes == 2)
     hipLaunchKernelGGL(k_spmv<2>, dim3((unsigned)(((size_t)d * 4 + 255) / 256), 3), dim3(256), 0, st, m, r->z, n, d, lay);
   else
     hipLaunchKernelGGL(k_spmv<4>, dim3((unsigned)(((size_t)d * 16 + 255) / 256), 3), dim3(256), 0, st, m, r->z, n, d, lay);

@@ -936,7 +936,7 @@ int zkhip_prover_set_streaming(zkhip_prover* p, int on) {
   std::lock_guard<std::mutex> lk(p->mu);
   // measured on the wrapping circuit: 212 -> 228 proofs/s with six provers in flight, 107 -> 98 one at a time
   p->ps.quad_below = on ? 1024u : 0u;
-  p->rd->spmv_log_lanes = on ? 2 : 4;
+  p->rd->spmv_log_lanes = on ? (p->rd->spmv_log_lanes_alone < 2 ? p->rd->spmv_log_lanes_alone : 2) : p->rd->spmv_log_lanes_alone;
   for (int k = 0; k <= ZK_MSM_SLOTS; k++) if (p->ps.ready[k]) { p->ps.ctx[k].quad_below = on ? 1024u : 65536u; p->ps.ctx[k].one_stream = on ? 1 : 0; }
   return ZKHIP_OK;
 }
