@@ -23,6 +23,7 @@ struct MsmJob {
                                  // sizes the slices of the accumulation to the entries that can actually occur
 };
 
+#define ZK_PRIO_BOARD_WORDS (8 * 8 * 2 * 16 * 4 * 16)
 struct MsmCtx {
   int c, W, L, logL;   // W: bucket windows (each owns 2^(c-1) buckets)
   int Wd;              // digits per scalar: W without a table; with a precomputed table all Wd digit positions share ONE bucket window
@@ -68,6 +69,8 @@ struct MsmCtx {
   // measurement aid (ZKHIP_DEBUG_DUMP=<dir>, tools/acc_probe.py): per-wave begin / end clocks of k_accumulate and, at collection, a dump
   // of the bucket populations; null / unused otherwise
   uint64_t* dbg_times;
+  uint32_t* prio_board;      // k_accumulate: iteration counts of the waves of a launch, one word per hardware wave slot (zeroed once)
+  uint32_t prio_seq;
   uint32_t last_S, last_T;           // slice length / slices of the last launch (before the kernel's own shortening, see slice_len)
   int last_tight;
   bool pending;       // an MSM has been enqueued by msm_launch and not yet collected by msm_finish

@@ -441,7 +441,8 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ goff,
                                                         uint32_t nb, uint32_t S_host, int tight, uint32_t T, uint32_t* __restrict__ slots,
                                                         uint32_t stride, uint32_t* __restrict__ fix_cnt /* [2] */, uint2* __restrict__ fix_short, uint2* __restrict__ fix_long,
-                                                        uint64_t* __restrict__ dbg_times /* null, or [waves][4]: tools/acc_probe.py */, int prio_mode) {
+                                                        uint64_t* __restrict__ dbg_times /* null, or [waves][4]: tools/acc_probe.py */, int prio_mode,
+                                                        uint32_t* prio_board /* null, or one word per hardware wave slot */, uint32_t prio_tag) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t dbg_t0 = dbg_times ? wall_clock64() : 0;
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
@@ -498,16 +499,39 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   // what is left, so a launch of a single machine fill ends with a third of its time at one wave per SIMD (78 % of the
   // multiplier's rate; measured: waves 0 .. 1023 of 2,000 end at 1.6 ms, the others at 2.55 ms).  The wave that is behind asks
   // for the higher priority, by quarters of its slice: both advance together and end together.
+  // ... by quarters of its slice when it cannot see its partner; when it can - both waves of a SIMD belong to this launch and post
+  // their iteration count in prio_board, one word per hardware wave slot (XCC, SE, SH, CU, SIMD, wave from HW_ID / XCC_ID), tagged
+  // with the launch - the wave that has done fewer iterations gets the SIMD: the two stay within one iteration of each other.
   const uint32_t len4 = (pos1 - pos0) >> 2, q1 = pos0 + len4, q2 = q1 + len4, q3 = q2 + len4;
-  uint32_t k = pos0;
+  uint32_t *board_mine = nullptr, *board_other = nullptr;
+  if (prio_mode && prio_board) {
+    const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;
+    const uint32_t simd = ((((xc * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u)) * 4u + ((hw >> 4) & 3u)) * 16u;
+    board_mine = prio_board + simd + (hw & 15u);
+    board_other = prio_board + simd + ((hw & 15u) ^ 1u);
+  }
+  uint32_t k = pos0, iter = 0;
   while (k < pos1) {
     if (prio_mode) {
-      const uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)k), a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1),
-                     a2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q2), a3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q3);
-      if (kk < a1) __builtin_amdgcn_s_setprio(3);
-      else if (kk < a2) __builtin_amdgcn_s_setprio(2);
-      else if (kk < a3) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
+      uint32_t other = 0;
+      if (board_mine) {
+        if ((threadIdx.x & 63u) == 0) __hip_atomic_store(board_mine, (prio_tag << 16) | (iter < 0xfffeu ? iter : 0xfffeu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        other = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(board_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+      if (board_mine && (other >> 16) == prio_tag) {
+        const uint32_t oi = other & 0xffffu;
+        if (iter < oi) __builtin_amdgcn_s_setprio(3);
+        else if (iter == oi) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      } else {
+        const uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)k), a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1),
+                       a2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q2), a3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q3);
+        if (kk < a1) __builtin_amdgcn_s_setprio(3);
+        else if (kk < a2) __builtin_amdgcn_s_setprio(2);
+        else if (kk < a3) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+      iter++;
     }
     // ---- run boundaries and run openings: memory operations only.  The lanes that are in the middle of a run wait here for the few
     // that close one and open the next; whoever leaves this loop with k < pos1 has an addition to do.
@@ -554,6 +578,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
     if (dense && p->x[23] == ZK_AFF_INF_WORD) continue;
     if (madd_lds_regy(acc, xs, zz, zzz, ty, p, neg)) inf = fp_is_zero_2p(lds_ld(zz));   // same-x path may have cancelled to infinity
   }
+  if (board_mine && (threadIdx.x & 63u) == 0) __hip_atomic_store(board_mine, (prio_tag << 16) | 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!inf) {
     mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));
     mem_st(acc, CY, ty);
@@ -1423,6 +1448,9 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t to
   }
   HIP_TRY(hipMalloc(&ctx->buckets, (size_t)ctx->slot_stride * 108 * 4));
   if (getenv("ZKHIP_DEBUG_DUMP")) HIP_TRY(hipMalloc(&ctx->dbg_times, ((size_t)ctx->T / 64 + 8) * 32));
+  HIP_TRY(hipMalloc(&ctx->prio_board, (size_t)ZK_PRIO_BOARD_WORDS * 4));          // 8 XCC x 8 SE x 2 SH x 16 CU x 4 SIMD x 16 wave slots
+  HIP_TRY(hipMemset(ctx->prio_board, 0, (size_t)ZK_PRIO_BOARD_WORDS * 4));
+  ctx->prio_seq = 0;
   HIP_TRY(hipMalloc(&ctx->fix_list, ((size_t)ctx->T / 5 + 2) * sizeof(uint2)));     // buckets of more than four F pieces: at most T / 5
   HIP_TRY(hipMalloc(&ctx->fix_short, ((size_t)ctx->T / 2 + 2) * sizeof(uint2)));    // buckets of two to four F pieces: at most T / 2
   // reduction scratch: S ping-pong (<= nb/L each) and R arrays (sum over levels <= nb/L * L/(L-1)), R sums
@@ -1445,7 +1473,7 @@ void msm_plan_free(MsmCtx* ctx) {
                   ctx->segS[0], ctx->segS[1], ctx->segR, ctx->sumR[0], ctx->sumR[1], ctx->Rlevels, ctx->win_abi,
                   ctx->colS[0], ctx->colS[1], ctx->hilo, ctx->pbuf[0], ctx->pbuf[1], ctx->aff_scratch,
                   ctx->lcnt[0], ctx->lcnt[1], ctx->lcnt[2], ctx->lcnt[3], ctx->loff[0], ctx->loff[1], ctx->loff[2], ctx->loff[3],
-                  ctx->fix_list, ctx->fix_short, ctx->dbg_times, ctx->goff};
+                  ctx->fix_list, ctx->fix_short, ctx->dbg_times, ctx->goff, ctx->prio_board};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->win_host) (void)hipHostFree(ctx->win_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1616,13 +1644,14 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   if (ctx->acc_gate) HIP_TRY(hipStreamWaitEvent(st, ctx->acc_gate, 0));
   if (ctx->aff_levels == 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
   const uint32_t* acc_entries = dense ? nullptr : ctx->entries;
-  static const int acc_prio = env_int("ZKHIP_ACC_PRIO", 1, 0, 1);     // (see k_accumulate: the wave that is behind asks for priority; 0 = the arbiter's own order)
+  static const int acc_prio = env_int("ZKHIP_ACC_PRIO", 1, 0, 2);      // 2: by quarters of the slice only (no board)
+  const uint32_t prio_tag = (++ctx->prio_seq & 0x7fffu) + 1u;     // (see k_accumulate: the wave that is behind asks for priority; 0 = the arbiter's own order)
   if (ctx->K == 1 || dense)
     hipLaunchKernelGGL(k_accumulate<1>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off, cur_cnt, ctx->goff,
-                       (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio);
+                       (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio, (acc_prio == 1 && !ctx->one_stream) ? ctx->prio_board : (uint32_t*)nullptr, prio_tag);
   else
     hipLaunchKernelGGL(k_accumulate<MSM_MAX_JOBS>, dim3(nblk(T_run, 256)), dim3(256), 0, st, bp, bshift, acc_entries, cur_off,
-                       cur_cnt, ctx->goff, (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio);
+                       cur_cnt, ctx->goff, (uint32_t)nb, S_run, tight, T_run, ctx->buckets, ctx->slot_stride, ctx->block_tot + 0, ctx->fix_short, ctx->fix_list, ctx->dbg_times, acc_prio, (acc_prio == 1 && !ctx->one_stream) ? ctx->prio_board : (uint32_t*)nullptr, prio_tag);
   HIP_TRY(hipEventRecord(ctx->ev_acc1, st));
   ctx->last_S = S_run; ctx->last_T = T_run; ctx->last_tight = tight;
   // fold the F pieces of the buckets that have several (lists made by k_accumulate), then L + F for every cut bucket
