@@ -72,11 +72,19 @@ def main():
                     "prover instances on a host thread each (no witness generation: the device's capacity, with less host noise)")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the --stream / --prove-stream measurement this many times")
     ap.add_argument("--gpu-slots", type=int, default=24)
+    ap.add_argument("--depth", type=int, default=0, help="--stream: batches the caller keeps outstanding (0 = gpu slots + witness workers + 2)")
     ap.add_argument("--witness-workers", type=int, default=10)
     ap.add_argument("--nested-inputs", type=int, default=1)
     ap.add_argument("--no-dump", action="store_true", help="no ZKHIP_DEBUG_DUMP (for counter passes: nothing but the proofs)")
     ap.add_argument("--keep", default="", help="directory that receives a copy of every raw dump (offline analysis)")
+    ap.add_argument("--cpus", default="", help="restrict the process to these CPUs before anything starts (e.g. 0-63,128-191)")
     args = ap.parse_args()
+    if args.cpus:
+        cp = set()
+        for part in args.cpus.split(','):
+            a, _, b = part.partition('-')
+            cp.update(range(int(a), int(b or a) + 1))
+        os.sched_setaffinity(0, cp)
     dump_dir = None
     if not args.no_dump:
         dump_dir = tempfile.mkdtemp(prefix="zkdump")
@@ -165,7 +173,7 @@ def main():
         if args.stream:
             saved = os.environ.pop("ZKHIP_DEBUG_DUMP", None)
             pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=args.gpu_slots, witness_workers=args.witness_workers)
-            depth = args.gpu_slots + args.witness_workers + 2
+            depth = args.depth or args.gpu_slots + args.witness_workers + 2
 
             def run(k):
                 tickets, last = [], None

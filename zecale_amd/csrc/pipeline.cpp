@@ -10,6 +10,8 @@
 // (own streams, own MSM work space, own QAP buffers) driven by its own host thread, so the accumulation kernels of one
 // proof fill the gaps in the reduction chains of another and the host stages overlap the device ones.
 // Built only on the C ABI (zkhip_aggregator_witness, zkhip_prover_*): a host-side scheduler, no device code.
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -39,6 +41,7 @@ struct Job {
 }  // namespace
 
 struct zkhip_pipeline {
+  std::atomic<uint64_t> st_wit_ns{0}, st_wit_n{0}, st_slot_wait_ns{0}, st_prove_ns{0}, st_prove_n{0};   // ZKHIP_PIPELINE_STATS: printed when the pipeline is freed
   zkhip_aggregator* agg = nullptr;
   size_t n_vars = 0, n_primary = 0, vk_words = 0, proofs_words = 0, inputs_words = 0;
   std::vector<zkhip_prover*> provers;
@@ -96,7 +99,10 @@ void witness_loop(zkhip_pipeline* p) {
     if (rc == ZKHIP_OK && !wf) rc = ZKHIP_ERR_ARG;
     if (rc == ZKHIP_OK) {
       j->z.resize(p->n_vars * 6);
+      const auto t0 = std::chrono::steady_clock::now();
       rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
+      p->st_wit_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      p->st_wit_n++;
     }
     std::lock_guard<std::mutex> lk(p->mu);
     if (rc != ZKHIP_OK) finish_failed(p, j, rc);
@@ -191,6 +197,7 @@ void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
   pthread_setname_np(pthread_self(), "zk-prover");
   for (;;) {
     std::shared_ptr<Job> j;
+    const auto t0 = std::chrono::steady_clock::now();
     {
       std::unique_lock<std::mutex> lk(p->mu);
       p->cv_gpu.wait(lk, [&] { return p->stop || !p->q_gpu.empty(); });
@@ -198,7 +205,11 @@ void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
       j = p->q_gpu.front();
       p->q_gpu.pop_front();
     }
+    const auto t1 = std::chrono::steady_clock::now();
     int rc = j->d_z ? zkhip_prover_prove_dev(pr, j->d_z, j->r, j->s, j->proof) : zkhip_prover_prove(pr, j->z.data(), j->r, j->s, j->proof);
+    p->st_slot_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    p->st_prove_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
+    p->st_prove_n++;
     std::lock_guard<std::mutex> lk(p->mu);
     j->rc = rc; j->done = true;
     if (j->d_z) {
@@ -223,7 +234,7 @@ int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int
 }
 
 int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, unsigned flags, zkhip_pipeline** out) {
-  if (!a || !crs || !out || gpu_slots < 1 || gpu_slots > 32 || witness_workers < 1 || witness_workers > 64) return ZKHIP_ERR_ARG;
+  if (!a || !crs || !out || gpu_slots < 1 || gpu_slots > 64 || witness_workers < 1 || witness_workers > 64) return ZKHIP_ERR_ARG;
   zkhip_r1cs_desc desc;
   int rc = zkhip_aggregator_get_r1cs(a, &desc);
   if (rc != ZKHIP_OK) return rc;
@@ -283,6 +294,10 @@ void zkhip_aggregator_pipeline_free(zkhip_pipeline* p) {
   }
   p->cv_wit.notify_all(); p->cv_gpu.notify_all(); p->cv_done.notify_all(); p->cv_room.notify_all(); p->cv_buf.notify_all(); p->cv_host.notify_all();
   for (auto& t : p->threads) t.join();
+  if (getenv("ZKHIP_PIPELINE_STATS") && p->st_prove_n)
+    fprintf(stderr, "zkhip pipeline: %llu proofs, %.2f ms in a prover each, provers waited %.2f ms per proof for an assignment; %llu host witnesses of %.2f ms\n",
+            (unsigned long long)p->st_prove_n.load(), p->st_prove_ns / 1e6 / p->st_prove_n, p->st_slot_wait_ns / 1e6 / p->st_prove_n,
+            (unsigned long long)p->st_wit_n.load(), p->st_wit_n ? p->st_wit_ns / 1e6 / p->st_wit_n : 0.0);
   for (zkhip_prover* q : p->provers) zkhip_prover_free(q);
   for (auto& q : p->slabs) zkhip_device_free(q.base);
   delete p;
