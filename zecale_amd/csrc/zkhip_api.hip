@@ -1,4 +1,5 @@
 // C ABI (include/zkhip.h) over the HIP engines.  No torch types, plain pointers and sizes.
+#include <math.h>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -563,12 +564,22 @@ static int crs_build_tables(zkhip_crs* c, const ResolvedOpts& o) {
   c->batch_msms = o.batch;
   if (!o.precompute) return ZKHIP_OK;
   size_t maxlen = c->A->len > c->H->len ? c->A->len : c->H->len;
-  const int tc = o.window ? o.window : auto_table_window(maxlen);
   zkhip_bases* all[5] = {c->A, c->B2, c->B1, c->H, c->L};
-  size_t total = 0;
-  for (zkhip_bases* b : all) total += b->len;
+  size_t total = 0, finite = 0;
+  for (zkhip_bases* b : all) { total += b->len; finite += b->n_finite; }
   // one kind of table for the whole key; an explicit request for the larger kind still respects the memory guard
   const int naf = (o.naf >= 0 ? (o.naf && naf_tables_fit(total)) : naf_tables_wanted(total)) ? 1 : 0;
+  int tc = o.window ? o.window : auto_table_window(maxlen);
+  if (!o.window && naf && finite > 0) {
+    // every-bit-position tables leave the window free of the table's layout: the five MSMs of a proof share one launch sequence,
+    // so what counts is the key's FINITE bases together - additions ~ finite * 378 / (c + 2), bucket reduction ~ 5 * 2^(c-1).
+    // Measured in a stream of proofs (tools/acc_probe.py --prove-stream): 176 k bases (the wrapping key) c = 14 / 15 / 16 ->
+    // 363 / 372-378 / 367 proofs/s; 370 k bases (nine inputs per nested proof) c = 15 / 16 / 17 -> 182 / 192 / 190.5.
+    const double copt = log2((double)finite) - 2.45;
+    tc = (int)(copt + 0.5);
+    if (tc < 9) tc = 9;
+    if (tc > 20) tc = 20;
+  }
   for (zkhip_bases* b : all) {
     int rc = bases_precompute_mode(b, tc, naf);
     if (rc != ZKHIP_OK) return rc;
