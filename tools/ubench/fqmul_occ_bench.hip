@@ -67,14 +67,12 @@ __device__ __forceinline__ Fp<PR> fp_mul_kara(Fp<PR> a, Fp<PR> b) {
   return r;
 }
 
-// fp_mul with ONE accumulator carried through all columns (the source's own shape): hipcc splits the column sums of fp_mul over
-// several accumulators and joins them with a 64-bit addition per column (v_lshl_add_u64: as dear as a mad).  Here every mad is an
-// asm statement on the same register pair, so the chain cannot be split: 53 fewer 64-bit additions per product - if a wave's
-// dependent mads issue back to back.  MEASURED (profiles/r04_ubench_multiplier.txt): 22.0 G fp_mul/s against 20.3 - 21.8 for fp_mul
-// with two or four waves per SIMD, 12.8 against 17.4 with one.  Built into fp29.cuh's three multiplier bodies it made the
-// accumulation kernel 20 KB larger (114 KB: the scalar operands of the asm statements are re-materialised; the hot loop no longer fits
-// the 64 KB instruction cache) and the first run of the library built that way HUNG on the GPU box (killed after 420 s without
-// output; not debugged on shared hardware): not adopted.
+// fp_mul with ONE accumulator carried through all columns (the source's own shape): hipcc re-associates the column sums of fp_mul
+// (the carry of the previous column is added LAST), runs eight columns side by side on eight register pairs and joins every column
+// with a 64-bit addition (v_lshl_add_u64: as dear as a mad).  KIND 4: every mad its own asm statement - the compiler then puts an
+// s_nop between any two of them (an inline asm's VGPR result read by the next instruction: gfx950's dst_sel forwarding hazard, assumed
+// for asm), 1,458 per product.  KIND 5 - 7 (fp29_chain.cuh, what the library now uses): asm BLOCKS of up to 13 mads, ~150 nops per
+// product.  profiles/r04_ubench_multiplier.txt.
 #define ZK_MAD(acc, x, y) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc")
 #define ZK_MAD_S(acc, x, c) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(c) : "vcc")
 template <class PR>
@@ -106,7 +104,8 @@ __device__ __forceinline__ Fp<PR> fp_mul_chain(Fp<PR> a, Fp<PR> b) {
   return r;
 }
 
-template <int KIND>   // 0: fp_mul chain, 1: fp_sqr chain, 2: fp_mul2 chain, 3: Karatsuba fp_mul chain, 4: single-accumulator fp_mul
+#include "../../zecale_amd/csrc/fp29_chain.cuh"
+template <int KIND>   // 5: fp_mul_chain2 (asm blocks of up to 13 mads), 0: fp_mul chain, 1: fp_sqr chain, 2: fp_mul2 chain, 3: Karatsuba fp_mul chain, 4: single-accumulator fp_mul
 __global__ void __launch_bounds__(256) k_chain(const uint32_t* in, uint32_t* out, int iters) {
   extern __shared__ uint32_t lds[];
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,6 +120,9 @@ __global__ void __launch_bounds__(256) k_chain(const uint32_t* in, uint32_t* out
     if (KIND == 2) { x = fp_mul2(x, y, z, x); y = fp_mul2(y, x, z, y); }
     if (KIND == 3) { x = fp_mul_kara(x, y); y = fp_mul_kara(y, x); }
     if (KIND == 4) { x = fp_mul_chain(x, y); y = fp_mul_chain(y, x); }
+    if (KIND == 5) { x = fp_mul_chain2(x, y); y = fp_mul_chain2(y, x); }
+    if (KIND == 6) { x = fp_sqr_chain(x); y = fp_sqr_chain(y); }
+    if (KIND == 7) { x = fp_mul2_chain(x, y, z, x); y = fp_mul2_chain(y, x, z, y); }
   }
   uint32_t s = 0;
   for (int i = 0; i < 27; i++) s ^= x.l[i] + y.l[i];
@@ -176,6 +178,19 @@ static bool check_kara() {
   CHECK(hipDeviceSynchronize());
   CHECK(hipMemcpy(b.data(), o3, words * 4, hipMemcpyDeviceToHost));
   for (size_t i = 64; i < words; i++) ok = ok && a[i] == b[i];
+  CHECK(hipFuncSetAttribute((const void*)k_chain<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  k_chain<5><<<1, 64, 1024>>>(in, o3, 3);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipMemcpy(b.data(), o3, words * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 64; i < words; i++) ok = ok && a[i] == b[i];
+  const int pairs[2][2] = {{1, 6}, {2, 7}};
+  for (auto& pr : pairs) {
+    if (pr[0] == 1) { k_chain<1><<<1, 64, 1024>>>(in, o0, 3); k_chain<6><<<1, 64, 1024>>>(in, o3, 3); }
+    else { k_chain<2><<<1, 64, 1024>>>(in, o0, 3); k_chain<7><<<1, 64, 1024>>>(in, o3, 3); }
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(a.data(), o0, words * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(b.data(), o3, words * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 64; i < words; i++) ok = ok && a[i] == b[i];
+  }
   CHECK(hipFree(in)); CHECK(hipFree(o0)); CHECK(hipFree(o3));
   return ok;
 }
@@ -189,6 +204,9 @@ int main() {
     run<2>("fp_mul2", 2187, o.lds, o.waves, o.peak);
     run<3>("fp_mul_kara (1,290 mads; rate in fp_mul-equivalents of 1,458)", 1458, o.lds, o.waves, o.peak);
     run<4>("fp_mul_chain (one accumulator)", 1458, o.lds, o.waves, o.peak);
+    run<5>("fp_mul_chain2 (one accumulator, asm blocks of <= 13 mads)", 1458, o.lds, o.waves, o.peak);
+    run<6>("fp_sqr_chain", 1107, o.lds, o.waves, o.peak);
+    run<7>("fp_mul2_chain", 2187, o.lds, o.waves, o.peak);
   }
   return 0;
 }

@@ -47,10 +47,23 @@ struct Fp {
   uint32_t l[NL];
 };
 
+// Device code: the three multiplier bodies below run every column's v_mad_u64_u32 as ONE dependent chain on one register pair
+// (fp29_chain.cuh: asm blocks, because hipcc re-associates the C++ column sums - carry last - and then needs a 64-bit addition per
+// column and eight accumulator pairs).  ZK_NO_ASM_CHAIN keeps the C++ bodies (host builds always use them).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM_CHAIN)
+#define ZK_ASM_CHAIN 1
+#include "fp29_chain.cuh"
+#else
+#define ZK_ASM_CHAIN 0
+#endif
+
 // r = a*b/R mod p.  Requires a*b < R*p*2^k' such that a*b/R + p fits (a, b < 2^10 p is ample);
 // limbs of a and b normalised (< 2^29).  Result < a*b/R + p  (< 2p when a*b < R*p).
 template <class PR>
 ZK_HD ZK_MULATTR Fp<PR> fp_mul(Fp<PR> a, Fp<PR> b) {
+#if ZK_ASM_CHAIN
+  return fp_mul_chain2<PR>(a, b);
+#endif
   constexpr int N = PR::NL;
   Fp<PR> r;
   uint32_t m[N];
@@ -81,6 +94,9 @@ ZK_HD ZK_MULATTR Fp<PR> fp_mul(Fp<PR> a, Fp<PR> b) {
 // r = a*a/R mod p; same bounds as fp_mul.  Off-diagonal products are computed once and doubled.
 template <class PR>
 ZK_HD ZK_MULATTR Fp<PR> fp_sqr(Fp<PR> a) {
+#if ZK_ASM_CHAIN
+  return fp_sqr_chain<PR>(a);
+#endif
   constexpr int N = PR::NL;
   Fp<PR> r;
   uint32_t m[N];
@@ -122,6 +138,9 @@ ZK_HD ZK_MULATTR Fp<PR> fp_sqr(Fp<PR> a) {
 // Requires normalised limbs and a*b + c*d < 2^10 R p; result < (a*b + c*d)/R + p.
 template <class PR>
 ZK_HD ZK_MULATTR Fp<PR> fp_mul2(Fp<PR> a, Fp<PR> b, Fp<PR> c, Fp<PR> d) {
+#if ZK_ASM_CHAIN
+  return fp_mul2_chain<PR>(a, b, c, d);
+#endif
   constexpr int N = PR::NL;
   Fp<PR> r;
   uint32_t m[N];
