@@ -337,7 +337,9 @@ int zkhip_gpu_witness_stats(zkhip_aggregator* a, size_t out[6]);
  * submit copies its inputs and returns a ticket (it blocks only while 4 x (gpu_slots + witness_workers) batches are
  * still unproved; finished batches wait for their collector and never block a submitter); wait blocks until that batch is done and returns the extended proof: primary inputs
  * (num_primary_inputs x 6 limbs: vk hash, packed results, nested inputs) and the proof (a | b | c, 72 limbs).
- * Every result is bit-identical to zkhip_aggregator_witness + zkhip_groth16_prove on the same inputs, r and s. */
+ * Every result is bit-identical to zkhip_aggregator_witness + zkhip_groth16_prove on the same inputs, r and s.
+ * gpu_slots and witness_workers: 1 .. 64 each.  ZKHIP_PIPELINE_STATS=1 in the environment prints, when a pipeline is freed, the time
+ * a proof spent in a prover, the time a prover waited for an assignment and the host witness time (stderr). */
 typedef struct zkhip_pipeline zkhip_pipeline;
 int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, zkhip_pipeline** out);
 /* flags: ZKHIP_PIPELINE_GPU_WITNESS - the witness workers generate the assignment on the GPU (zkhip_gpu_witness_run: each worker is
