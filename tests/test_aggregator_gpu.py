@@ -85,14 +85,21 @@ def test_naf_table_key_proves_the_same(zk):
     expected = zk.groth16_prove(crs, r1, z, r, s_)
     crs.free()
     crs2 = kp.upload_crs(zk.key_opts(table_naf=True))
+    # such a key picks its window from its finite bases (log2(176,280) - 2.45 -> 15; the default tables keep 16 for this size) ...
+    assert crs2.table_kind == 2 and crs2.table_window == 15 and sum(crs2.finite_terms()) == 176280
     assert (zk.groth16_prove(crs2, r1, z, r, s_) == expected).all()
+    # ... and an explicit window still wins
+    crs3 = kp.upload_crs(zk.key_opts(table_naf=True, window=13))
+    assert crs3.table_window == 13
+    assert (zk.groth16_prove(crs3, r1, z, r, s_) == expected).all()
+    crs3.free()
     p = zk.Prover(crs2, desc)
     p.set_streaming(True)
     assert (p.prove(z, r, s_) == expected).all()
     p.free(); crs2.free(); r1.free(); kp.free(); agg.free()
 
 
-@pytest.mark.parametrize("slots,workers", [(1, 1), (3, 2)])
+@pytest.mark.parametrize("slots,workers", [(1, 1), (3, 2), (40, 3)])
 def test_pipeline_matches_serial_path(zk, slots, workers):
     """Streaming aggregator (zkhip_aggregator_pipeline_*): every extended proof equals witness + groth16_prove done one
     after the other, whatever the number of GPU slots / witness workers and the order of completion; an invalid nested
@@ -118,6 +125,8 @@ def test_pipeline_matches_serial_path(zk, slots, workers):
     with pytest.raises(zk.ZkhipError):
         pipe.wait(12345)                                                # unknown ticket
     pipe.free()
+    with pytest.raises(zk.ZkhipError):
+        zk.AggregatorPipeline(agg, crs, gpu_slots=65, witness_workers=1)      # at most 64 prover instances
     crs.free(); r1.free(); kp.free(); agg.free()
 
 
