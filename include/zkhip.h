@@ -386,6 +386,11 @@ int zkhip_reset_time_base(void);
  * the integer multiplier, and its rate differs between boxes and power states of the same model: a measurement states
  * its fraction against the peak of the run it was taken in. */
 int zkhip_measure_fq_mul_rate(double* fq_mul_per_s);
+/* Test hook (no counterpart): the device build's three multiplier bodies - the code every kernel runs (fp29.cuh / fp29_chain.cuh) - on
+ * operands given limb by limb: field 0 = Fq (27 limbs of 29 bits), 1 = Fr (14); limbs_in holds n cases of (a, b, c, d), limbs_out
+ * receives n x { a b / R, a^2 / R, (a b + c d) / R } in the device's own form (R = 2^783 / 2^406).  Operands must respect the
+ * bodies' contract (limbs below 2^29 except the top one, products below 2^10 R p). */
+int zkhip_internal_field_selftest(int field, const uint32_t* limbs_in, size_t n, uint32_t* limbs_out);
 
 /* replaces: libff::Fr<wppT>::random_element() as r1cs_gg_ppzksnark_prover draws the proof's randomisers r, s (reached from
  * aggregator_circuit.tcc:168) and the generator its toxic waste: one field element uniform in Fr, 6 Montgomery limbs, from the

@@ -106,6 +106,7 @@ static inline int msm_table_levels(int c, int naf = 0) { return naf ? 378 : (378
 int msm_table_build(AffPacked* d_table, uint8_t* d_tinf, size_t n, int c, int naf, char* errbuf, size_t errlen);
 
 // Fq multiplications per second of the whole device, measured now: dependent fp_mul chains at two waves per SIMD (~25 ms)
+int msm_field_selftest(int field, const uint32_t* in_host, size_t n, uint32_t* out_host, char* errbuf, size_t errlen);
 int msm_measure_fqmul_rate(double* fq_mul_per_s, char* errbuf, size_t errlen);
 
 int fixed_base_mul(const uint64_t base_aff[24], const uint64_t* d_scalars, size_t n, int montgomery, uint64_t* d_out,

@@ -1219,6 +1219,41 @@ int msm_measure_fqmul_rate(double* fq_mul_per_s, char* errbuf, size_t errlen) {
   return ZKHIP_OK;
 }
 
+// The three multiplier bodies of the DEVICE build on operands given limb by limb (tests/test_field_gpu.py: the worst cases of the
+// column sums - every limb at 2^29 - 1, the top limb at the lazy bound - go through the same code the kernels run, and are checked
+// against big integers on the host): out[i] = { a b / R, a^2 / R, (a b + c d) / R } for case i = (a, b, c, d), NL limbs each.
+template <class PR>
+__global__ void __launch_bounds__(64) k_field_selftest(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int N = PR::NL;
+  Fp<PR> a, b, c, d;
+  for (int k = 0; k < N; k++) { a.l[k] = in[(i * 4 + 0) * N + k]; b.l[k] = in[(i * 4 + 1) * N + k]; c.l[k] = in[(i * 4 + 2) * N + k]; d.l[k] = in[(i * 4 + 3) * N + k]; }
+  const Fp<PR> m = fp_mul(a, b), q = fp_sqr(a), m2 = fp_mul2(a, b, c, d);
+  for (int k = 0; k < N; k++) { out[(i * 3 + 0) * N + k] = m.l[k]; out[(i * 3 + 1) * N + k] = q.l[k]; out[(i * 3 + 2) * N + k] = m2.l[k]; }
+}
+
+int msm_field_selftest(int field, const uint32_t* in_host, size_t n, uint32_t* out_host, char* errbuf, size_t errlen) {
+  const int N = field == 0 ? FqParams::NL : FrParams::NL;
+  uint32_t *in = nullptr, *out = nullptr;
+  hipError_t e = hipMalloc(&in, n * 4 * N * 4 + 4);
+  if (e == hipSuccess) e = hipMalloc(&out, n * 3 * N * 4 + 4);
+  if (e == hipSuccess) e = hipMemcpy(in, in_host, n * 4 * N * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && n) {
+    if (field == 0) hipLaunchKernelGGL(k_field_selftest<FqParams>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, in, out, n);
+    else hipLaunchKernelGGL(k_field_selftest<FrParams>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, in, out, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out_host, out, n * 3 * N * 4, hipMemcpyDeviceToHost);
+  if (in) (void)hipFree(in);
+  if (out) (void)hipFree(out);
+  if (e != hipSuccess) {
+    if (errbuf) snprintf(errbuf, errlen, "msm_field_selftest: %s", hipGetErrorString(e));
+    return ZKHIP_ERR_HIP;
+  }
+  return ZKHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------

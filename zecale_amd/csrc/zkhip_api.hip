@@ -1484,6 +1484,13 @@ int zkhip_measure_fq_mul_rate(double* fq_mul_per_s) {
   return msm_measure_fqmul_rate(fq_mul_per_s, t_err, sizeof t_err);
 }
 
+int zkhip_internal_field_selftest(int field, const uint32_t* limbs_in, size_t n, uint32_t* limbs_out) {
+  BIND_CUR();
+  if ((field != 0 && field != 1) || (n && (!limbs_in || !limbs_out)) || n > (1u << 20)) return fail(ZKHIP_ERR_ARG, "field 0 (Fq) or 1 (Fr), at most 2^20 cases");
+  std::lock_guard<std::mutex> lk(g.dev[cur_dev()].mu);
+  return msm_field_selftest(field, limbs_in, n, limbs_out, t_err, sizeof t_err);
+}
+
 // pinned host memory for callers without a HIP runtime of their own (source of zkhip_msm_stream_submit_host's asynchronous copies)
 int zkhip_host_alloc(size_t bytes, void** out) {
   BIND_CUR();

@@ -29,7 +29,7 @@ EXPORTS = [
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
     "zkhip_last_accumulate_interval", "zkhip_crs_upload_ex", "zkhip_crs_upload_slice_ex", "zkhip_bases_precompute_ex", "zkhip_crs_table_kind", "zkhip_crs_finite_terms",
-    "zkhip_bases_set_window", "zkhip_reset_time_base", "zkhip_measure_fq_mul_rate", "zkhip_host_alloc", "zkhip_host_free",
+    "zkhip_bases_set_window", "zkhip_reset_time_base", "zkhip_measure_fq_mul_rate", "zkhip_internal_field_selftest", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_msm_stream_new", "zkhip_msm_stream_submit", "zkhip_msm_stream_submit_host", "zkhip_msm_stream_collect", "zkhip_msm_stream_last_accumulate_ms",
     "zkhip_msm_stream_last_accumulate_interval", "zkhip_msm_stream_free", "zkhip_prover_new_slice", "zkhip_prover_prove_partial",
     "zkhip_dispatcher_new", "zkhip_dispatcher_size", "zkhip_dispatcher_submit", "zkhip_dispatcher_wait", "zkhip_dispatcher_stats", "zkhip_dispatcher_free",
@@ -937,6 +937,18 @@ def jac_add(a, b):
 
 def last_accumulate_ms():
     return float(load().zkhip_last_accumulate_ms())
+
+
+def field_selftest(field, limbs_in):
+    """Test hook: the device's multiplier bodies on raw limbs.  field 0 = Fq (27 limbs), 1 = Fr (14); limbs_in: uint32 [n][4][NL] =
+    cases of (a, b, c, d); returns uint32 [n][3][NL] = (a b / R, a^2 / R, (a b + c d) / R)."""
+    nl = 27 if field == 0 else 14
+    x = np.ascontiguousarray(limbs_in, dtype=np.uint32).reshape(-1, 4, nl)
+    out = np.zeros((x.shape[0], 3, nl), dtype=np.uint32)
+    lib = load()
+    lib.zkhip_internal_field_selftest.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    _check(lib.zkhip_internal_field_selftest(int(field), x.ctypes.data, x.shape[0], out.ctypes.data))
+    return out
 
 
 def measure_fq_mul_rate():
