@@ -1,7 +1,24 @@
-// single-accumulator Montgomery product: every column's mads in asm blocks on one register pair
+// The three multiplier bodies of fp29.cuh (fp_mul, fp_sqr, fp_mul2) for the DEVICE, every column's v_mad_u64_u32 as ONE dependent chain
+// on one register pair.  Included by fp29.cuh inside namespace zkhip (device pass only); same arithmetic, same bounds, same results.
+//
+// Why asm.  fp29.cuh's C++ bodies have one accumulator in the source, but hipcc's reassociation pass orders every column sum so that the
+// loop-carried value - the carry of the previous column - is added LAST.  The columns then look independent: the scheduler runs eight
+// of them side by side on eight register pairs and joins each with the carry by a 64-bit addition (v_lshl_add_u64, as dear as a mad):
+// 52 per product.  With two waves per SIMD that parallelism buys nothing - a wave's dependent mads issue back to back - and there is
+// no builtin for a mad with its addend, no switch for the pass, and an empty asm barrier moves with the sum it is attached to.
+//
+// How.  zk_chain.inc (tools/gen_chain_inc.py) holds asm BLOCKS of 1 .. 13 mads on one accumulator: an asm statement takes at most 30
+// operands - the accumulator, the carry-out pair, 13 pairs of factors.  The carry-out pair (unused; the instruction must name one) is
+// an EARLY-CLOBBER output: without "&" the allocator may give it the registers of a modulus limb that a later mad of the block
+// still reads.  Between two blocks the compiler puts one s_nop: a VGPR written by inline asm and read by the next instruction is
+// treated as gfx950's dst_sel forwarding hazard.  That is why the blocks are as long as the operand limit allows (~150 nops per
+// product, free beside a second wave; one statement per mad - 1,458 nops - was measurably slower and 20 KB larger).
+// Shifts, quotient digits (m = acc * PINV mod 2^29) and the dual product's column split stay C++ between the blocks.
+// Checked against big integers on the device: tests/test_field_gpu.py.  -DZK_NO_ASM_CHAIN keeps the C++ bodies.
 template <int CNT> struct ZkMadV;
 template <class PC, int J0, int CNT> struct ZkMadS;
 #include "zk_chain.inc"
+// acc += sum_{i = I0 .. I1} x[i] * y[K - i], in blocks of at most 13 terms
 template <int K, int I0, int I1>
 __device__ __forceinline__ void zk_prod_terms(uint64_t& acc, const uint32_t* a, const uint32_t* b) {
   if constexpr (I0 <= I1) {
@@ -10,6 +27,7 @@ __device__ __forceinline__ void zk_prod_terms(uint64_t& acc, const uint32_t* a, 
     zk_prod_terms<K, I0 + CNT, I1>(acc, a, b);
   }
 }
+// acc += sum_{i = I0 .. I1} m[i] * P[K - i]  (the modulus limbs are SGPR operands)
 template <class PC, int K, int I0, int I1>
 __device__ __forceinline__ void zk_red_terms(uint64_t& acc, const uint32_t* m) {
   if constexpr (I0 <= I1) {
@@ -18,6 +36,7 @@ __device__ __forceinline__ void zk_red_terms(uint64_t& acc, const uint32_t* m) {
     zk_red_terms<PC, K, I0 + CNT, I1>(acc, m);
   }
 }
+// column K of the interleaved Montgomery product, then column K + 1 (compile-time recursion: the block sizes are template arguments)
 template <class PR, int K>
 __device__ __forceinline__ void zk_mul_col(uint64_t& acc, const Fp<PR>& a, const Fp<PR>& b, uint32_t* m, Fp<PR>& r) {
   constexpr int N = PR::NL;
