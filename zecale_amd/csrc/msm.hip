@@ -850,7 +850,10 @@ __global__ void __launch_bounds__(256, 2) k_fixup_fold(const uint32_t* __restric
 // final stitch: the slice in which a cut bucket STARTS owns it: bucket = L[t0] + F[t0+1] (folded).
 __global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ goff,
                                                    uint32_t nb, uint32_t S_host, int tight, uint32_t T, uint32_t* __restrict__ slots, uint32_t stride) {
-  ADD_SCRATCH_DECL(false);
+  // the L piece goes to the CU (X, ZZ, ZZZ in LDS, Y in registers, as in k_accumulate / k_sum_lds), the F piece is added to it
+  // there and the sum is stored once: ten coordinate loads and four stores per cut bucket (a copy into the bucket's slot followed by
+  // an addition in memory - rounds 1-3 - moved fourteen and eight)
+  __shared__ uint32_t lds_zz[27 * ZK_LDS_STRIDE], lds_zzz[27 * ZK_LDS_STRIDE], lds_x[24 * ZK_LDS_STRIDE];
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // throughput-bound (one addition per slice): one lane each
   const uint32_t M = offsets[nb - 1] + counts[nb - 1];
   const uint32_t A = slice_weight(goff[nb], T, S_host, tight);
@@ -862,9 +865,22 @@ __global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ o
   uint32_t b = bucket_of(offsets, nb, pos1 - 1);
   uint32_t bend = offsets[b] + counts[b];
   if (bend <= pos1 || offsets[b] < pos0) return;      // not cut at this slice's end, or started earlier
-  XyzzRef dst = make_ref(slots, stride, b);
-  mem_copy(dst, make_ref(slots, stride, nb + T + t));
-  add_mem_s(dst, make_ref(slots, stride, nb + t + 1), sc.zz, sc.zzz);
+  const XyzzRef dst = make_ref(slots, stride, b), pl = make_ref(slots, stride, nb + T + t), pf = make_ref(slots, stride, nb + t + 1);
+  const bool l_inf = mem_is_inf(pl), f_inf = mem_is_inf(pf);
+  if (l_inf || f_inf) {                                 // (a piece whose points cancelled: rare)
+    if (l_inf && f_inf) mem_set_inf(dst);
+    else mem_copy(dst, l_inf ? pf : pl);
+    return;
+  }
+  uint32_t* zz = lds_zz + threadIdx.x;
+  uint32_t* zzz = lds_zzz + threadIdx.x;
+  uint32_t* xs = lds_x + threadIdx.x;
+  lds_st_packed(xs, mem_ld(pl, CX));                    // X of a stored point is an X3 [10]: below 2^768, packs into 24 words
+  Fq ty = mem_ld(pl, CY);
+  lds_st(zz, mem_ld(pl, CZZ));
+  lds_st(zzz, mem_ld(pl, CZZZ));
+  if (add_lds_regy(dst, xs, zz, zzz, ty, pf) && fp_is_zero_2p(lds_ld(zz))) { mem_set_inf(dst); return; }   // same-x path: L = -F
+  mem_st(dst, CX, lds_ld_packed(xs)); mem_st(dst, CY, ty); mem_st(dst, CZZ, lds_ld(zz)); mem_st(dst, CZZZ, lds_ld(zzz));
 }
 
 // Segment pass of the bucket reduction.  in: n_in items (XYZZ limb-major, stride n_in), grouped in
