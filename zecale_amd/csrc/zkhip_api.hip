@@ -153,6 +153,13 @@ int auto_table_window(size_t n) {
 
 // table_c = 0: plain plan with the automatic window;  > 0: merged plan (bases are a window table built for table_c)
 // total: bound on the terms of all K jobs of a launch together (0: K * n)
+// would ensure_ctx keep this context as it is (same plan, nothing pending)?
+static bool ctx_reusable(const MsmCtx* cx, bool ready, size_t n, int table_c, int K, int naf, size_t total, int plain_c = 0) {
+  const int c = table_c ? table_c : (plain_c ? plain_c : auto_window(n)), merged = table_c ? (naf ? 2 : 1) : 0;
+  if (total == 0 || total > (size_t)K * n) total = (size_t)K * n;
+  return ready && !cx->pending && cx->max_n >= n && cx->total_terms >= total && cx->c == c && cx->merged == merged && cx->K == K &&
+         cx->aff_forced == msm_forced_aff_levels();
+}
 int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1, int naf = 0, size_t total = 0, int plain_c = 0) {
   const int c = table_c ? table_c : (plain_c ? plain_c : auto_window(n)), merged = table_c ? (naf ? 2 : 1) : 0;
   if (total == 0 || total > (size_t)K * n) total = (size_t)K * n;
@@ -701,8 +708,20 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   // adopted - the plain entry point's phase timings are the bench's one-proof-alone figures).  A chained proof's phase timings measure
   // enqueueing, not execution.
   static const int chain_env = getenv("ZKHIP_STREAM_CHAIN") ? atoi(getenv("ZKHIP_STREAM_CHAIN")) : 1;
-  const bool chain = chain_env && (ps.quad_below || chain_env == 2) && crs->A->table_c > 0 && crs->batch_msms && ps.ready[ZK_MSM_SLOTS] && ps.ctx[ZK_MSM_SLOTS].stream &&
-                     !ps.ctx[ZK_MSM_SLOTS].pending;
+  size_t maxlen = a_len > h_len ? a_len : h_len;
+  if (maxlen < 1) maxlen = 1;
+  size_t total_finite = 0;                          // (the rule of msm_launch_multi: a base at infinity never produces an entry)
+  {
+    const zkhip_bases* qs[5] = {crs->A, crs->B2, crs->B1, crs->H, crs->L};
+    const size_t lens[5] = {a_len, a_len, a_len, h_len, l_len};
+    for (int j = 0; j < 5; j++) {
+      const size_t nf = lens[j] == qs[j]->len ? qs[j]->n_finite : 0;
+      total_finite += (nf && nf < lens[j]) ? nf : lens[j];
+    }
+  }
+  // (only when the launch sequence's context will be used as it stands: a context that ensure_ctx is about to rebuild gets a new stream)
+  const bool chain = chain_env && (ps.quad_below || chain_env == 2) && crs->A->table_c > 0 && crs->batch_msms && ps.ctx[ZK_MSM_SLOTS].stream &&
+                     ctx_reusable(&ps.ctx[ZK_MSM_SLOTS], ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf, total_finite ? total_finite : 1);
   hipStream_t qst = chain ? ps.ctx[ZK_MSM_SLOTS].stream : ps.st;
   if (!d_z_ready) {
     API_HIP(hipMemcpyAsync(ps.dz, z, m * 48, hipMemcpyHostToDevice, qst));
@@ -720,8 +739,6 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     API_HIP(zk_event_wait(ps.ev_st));   // the MSM contexts run on their own streams
   }
   ps.ms[1] = ms_since(t0);
-  size_t maxlen = a_len > h_len ? a_len : h_len;
-  if (maxlen < 1) maxlen = 1;
   struct { const zkhip_bases* b; const uint64_t* sc; size_t len; int mode; uint64_t* out; } jobs[5] = {
       {crs->A, dz + a_lo * 6, a_len, 1, sums}, {crs->B2, dz + a_lo * 6, a_len, 1, sums + 36}, {crs->B1, dz + a_lo * 6, a_len, 1, sums + 72},
       {crs->H, (const uint64_t*)rd->bufA + h_lo * 6, h_len, 2, sums + 108}, {crs->L, dz + (l + 1 + l_lo) * 6, l_len, 1, sums + 144}};
@@ -730,11 +747,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     // table-backed key: the five MSMs share ONE launch sequence (one sort, one accumulation launch over all five entry
     // lists, one reduction chain with a bucket window per MSM) - a fifth of the launches, five times the lanes in each.
     // (A plan that does not fit the engine's 32-bit entry positions is refused with ZKHIP_ERR_ARG: one sequence per MSM then.)
-    size_t total = 0;
-    for (int j = 0; j < 5; j++) {                     // (the rule of msm_launch_multi: a base at infinity never produces an entry)
-      const size_t nf = jobs[j].len == jobs[j].b->len ? jobs[j].b->n_finite : 0;
-      total += (nf && nf < jobs[j].len) ? nf : jobs[j].len;
-    }
+    const size_t total = total_finite;
     rc = ensure_ctx(&ps.ctx[ZK_MSM_SLOTS], &ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf, total ? total : 1);
     if (rc == ZKHIP_OK && ps.quad_below) { ps.ctx[ZK_MSM_SLOTS].quad_below = ps.quad_below; ps.ctx[ZK_MSM_SLOTS].one_stream = 1; }
     if (rc == ZKHIP_ERR_ARG) batched = false;
