@@ -73,6 +73,40 @@ def test_prover_instances_match_the_plain_entry_point(zk):
     crs.free(); r1.free(); kp.free(); agg.free()
 
 
+def test_streaming_prover_chains_its_phases_and_survives_a_rebuilt_plan(zk):
+    """A streaming prover (zkhip_prover_set_streaming) enqueues upload, QAP map and the MSMs' launch sequence on ONE stream without
+    host waits from its second proof on.  Same proofs as the plain entry point - also when the launch sequence's plan has to be
+    rebuilt between two proofs (the deprecated process-wide affine-level switch changes what a plan holds: the chained path must
+    not enqueue on the stream of a context that is about to be replaced), and when streaming is switched off and on again."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    crs, r1 = kp.upload_crs(zk.key_opts(table_naf=True)), zk.r1cs_from_desc(desc)
+    zs, rs = [], []
+    for a, b in ((0, 1), (2, 3), (4, 5)):
+        (pa, ia), (pb, ib) = proofs[a], proofs[b]
+        zs.append(agg.witness(nvk_l, np.concatenate([nested_proof_limbs(pa), nested_proof_limbs(pb)]), np.array([fr_limbs(ia[0]), fr_limbs(ib[0])])))
+        rs.append((fr_limbs(0x3333 + a), fr_limbs(0x4444 + b)))
+    expected = [zk.groth16_prove(crs, r1, z, r, s) for z, (r, s) in zip(zs, rs)]
+    p = zk.Prover(crs, desc)
+    p.set_streaming(True)
+    try:
+        for rep in range(3):                                   # the first proof builds the plan, the others are chained
+            for i in range(3):
+                assert (p.prove(zs[i], *rs[i]) == expected[i]).all(), (rep, i)
+        zk.set_affine_levels(1)                                # the next proof rebuilds its plan ...
+        assert (p.prove(zs[0], *rs[0]) == expected[0]).all()
+        assert (p.prove(zs[1], *rs[1]) == expected[1]).all()
+        zk.set_affine_levels(0)                                # ... and the one after it again
+        assert (p.prove(zs[2], *rs[2]) == expected[2]).all()
+        p.set_streaming(False)
+        assert (p.prove(zs[0], *rs[0]) == expected[0]).all()
+        p.set_streaming(True)
+        assert (p.prove(zs[1], *rs[1]) == expected[1]).all()
+        assert (p.prove(zs[2], *rs[2]) == expected[2]).all()
+    finally:
+        zk.set_affine_levels(0)
+    p.free(); crs.free(); r1.free(); kp.free(); agg.free()
+
+
 def test_naf_table_key_proves_the_same(zk):
     """The proving key's window tables with every bit position and the scalars in non-adjacent form (zkhip_key_opts.table_naf): the five
     MSMs of a wrapping proof - real witness scalars, a B query with points at infinity, the H coefficients - give the same proof
