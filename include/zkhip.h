@@ -244,7 +244,10 @@ int zkhip_last_prove_timings(double out_ms[8]);
 typedef struct zkhip_prover zkhip_prover;
 int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prover** out);   /* crs must outlive the prover */
 /* on != 0: this prover shares the GPU with others (a server's slots): the latency-bound launches of the bucket reduction then use
-   one lane per point addition instead of four - less total work, a longer single proof.  The streaming pipeline sets it on its provers. */
+   one lane per point addition instead of four - less total work, a longer single proof -, slices of the bucket accumulation are twice
+   as long, and from its second proof on the instance enqueues the upload of the assignment and the QAP map on the stream of its MSM
+   launch sequence: the calling thread waits once, for the MSM results (zkhip_prover_timings then reports enqueueing times for the
+   first two phases; ZKHIP_STREAM_CHAIN=0 in the environment keeps the waits).  The streaming pipeline sets it on its provers. */
 int zkhip_prover_set_streaming(zkhip_prover* p, int on);
 int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r[6], const uint64_t s[6], uint64_t proof_affine[72]);
 /* the same with the assignment already in device memory (n_vars x 6 limbs, e.g. from zkhip_gpu_witness_run; must be complete) */
