@@ -84,6 +84,8 @@ class keypair {                            // wsnarkT::keypair: pk (HBM-resident
   keypair& operator=(const keypair&) = delete;
   ~keypair() { zkhip_crs_free(crs_); zkhip_keypair_free(kp_); }
   const zkhip_crs* pk() const { return crs_; }
+  // points of the evaluation domain the key was generated on (its H query has one fewer): a prover follows the key
+  size_t domain_size() const { zkhip_crs_desc d; zk_check(zkhip_keypair_crs_desc(kp_, &d), "zkhip_keypair_crs_desc"); return d.domain_size; }
   const zkhip_keypair* host() const { return kp_; }      // the key in host memory (what a multi-GPU stream uploads to every GPU)
   // vk: alpha (G1), beta, delta (G2), ABC; `vk_abc_size() == num_primary_inputs() + 1` is the server's sanity check (aggregator_server.cpp:490)
   size_t vk_abc_size() const { uint64_t a[24], b[24], d[24]; const uint64_t* abc; return zkhip_keypair_vk(kp_, a, b, d, &abc); }
@@ -131,12 +133,14 @@ class aggregator_circuit {
   size_t num_primary_inputs() const { return zkhip_aggregator_num_primary_inputs(agg_); }
   const zkhip_r1cs_desc& get_constraint_system() const { return cs_; }
 
-  // needs a device (the batch exponentiations run on the GPU); fresh toxic waste, uniform in Fr, from the OS, discarded on return
-  std::unique_ptr<keypair> generate_trusted_setup() const {
+  // needs a device (the batch exponentiations run on the GPU); fresh toxic waste, uniform in Fr, from the OS, discarded on return.
+  // domain_size: ZKHIP_DOMAIN_DEFAULT = the power of two libzeth's generate_setup forces (the reference: tcc:108; 65,536 points for
+  // batch 2); ZKHIP_DOMAIN_STEP = libfqfft's unforced step domain (49,152: an option of this library, not a reference key).
+  std::unique_ptr<keypair> generate_trusted_setup(size_t domain_size = ZKHIP_DOMAIN_DEFAULT) const {
     uint64_t t[4][6];
     for (auto& s : t) zk_check(zkhip_fr_random(s), "zkhip_fr_random");
     zkhip_keypair* kp = nullptr;
-    zk_check(zkhip_groth16_setup(&cs_, t[0], t[1], t[2], t[3], &kp), "zkhip_groth16_setup");
+    zk_check(zkhip_groth16_setup_ex(&cs_, t[0], t[1], t[2], t[3], domain_size, &kp), "zkhip_groth16_setup_ex");
     return std::unique_ptr<keypair>(new keypair(kp));
   }
 
@@ -243,7 +247,7 @@ class aggregator_circuit {
     zk_check(zkhip_aggregator_check_inputs(agg_, vk.data(), proofs.data(), &well_formed), "zkhip_aggregator_check_inputs");
     if (!well_formed) throw std::runtime_error("nested proof or verification key has a point that is not on its curve");
     zk_check(zkhip_aggregator_witness(agg_, vk.data(), proofs.data(), inputs.data(), z.data()), "zkhip_aggregator_witness");
-    if (!r1cs_) zk_check(zkhip_r1cs_upload(&cs_, &r1cs_), "zkhip_r1cs_upload");
+    if (!r1cs_) zk_check(zkhip_r1cs_upload_ex(&cs_, kp.domain_size(), &r1cs_), "zkhip_r1cs_upload_ex");   // (zkhip_groth16_prove follows the key from then on)
     uint64_t r[6], s[6];
     random_scalars(r, s);
     uint64_t out[72];

@@ -46,8 +46,11 @@ struct csr_matrix {
 class hip_proving_key {
  public:
   // opts: this key's own table / launch options (zkhip_key_opts travel with the handle; nullptr = the defaults)
+  // The KEY names the QAP's evaluation domain (crs.domain_size): a key from the reference's generate_setup - libzeth forces a power
+  // of two, 65,536 points for the wrapping circuit (aggregator_circuit.tcc:108) - proves as it is; so does a key generated here on
+  // libfqfft's unforced step domain.  The constraint system is uploaded on the key's domain.
   hip_proving_key(const zkhip_crs_desc& crs, const zkhip_r1cs_desc& cs, const zkhip_key_opts* opts = nullptr) {
-    zk_check(zkhip_r1cs_upload(&cs, &r1cs_), "zkhip_r1cs_upload");
+    zk_check(zkhip_r1cs_upload_ex(&cs, crs.domain_size, &r1cs_), "zkhip_r1cs_upload_ex");
     int rc = zkhip_crs_upload_ex(&crs, opts, &crs_);
     if (rc != ZKHIP_OK) { zkhip_r1cs_free(r1cs_); zk_check(rc, "zkhip_crs_upload_ex"); }
     n_vars_ = cs.n_vars;
@@ -59,8 +62,8 @@ class hip_proving_key {
     if (devices.empty()) throw std::runtime_error("hip_proving_key: empty device list");
     zk_check(zkhip_multi_prover_new(&crs, &cs, opts, devices.data(), (int)devices.size(), &multi_), "zkhip_multi_prover_new");
     int rc = zkhip_set_device(devices[0]);                       // (is_satisfied runs on the first GPU of the list)
-    if (rc == ZKHIP_OK) rc = zkhip_r1cs_upload(&cs, &r1cs_);
-    if (rc != ZKHIP_OK) { zkhip_multi_prover_free(multi_); zk_check(rc, "zkhip_r1cs_upload"); }
+    if (rc == ZKHIP_OK) rc = zkhip_r1cs_upload_ex(&cs, crs.domain_size, &r1cs_);
+    if (rc != ZKHIP_OK) { zkhip_multi_prover_free(multi_); zk_check(rc, "zkhip_r1cs_upload_ex"); }
     n_vars_ = cs.n_vars;
   }
   hip_proving_key(const hip_proving_key&) = delete;
@@ -69,7 +72,8 @@ class hip_proving_key {
   size_t num_devices() const { return multi_ ? (size_t)zkhip_multi_prover_size(multi_) : 1; }
 
   size_t num_variables() const { return n_vars_; }
-  unsigned log_domain_size() const { return zkhip_r1cs_log_domain(r1cs_); }
+  size_t domain_size() const { return zkhip_r1cs_domain_size(r1cs_); }          // the key's: 2^k (a reference key), or 2^k + 2^r
+  unsigned log_domain_size() const { return zkhip_r1cs_log_domain(r1cs_); }      // ceil(log2 domain_size())
 
   // full assignment z = (1, primary, auxiliary), n_vars x 6 limbs
   bool is_satisfied(const uint64_t* z) const {

@@ -39,6 +39,8 @@ extern "C" {
 #define ZKHIP_ERR_NO_DEVICE (-2)  /* no gfx950 device / HIP runtime unavailable */
 #define ZKHIP_ERR_HIP (-3)        /* a HIP call failed; see zkhip_last_error() */
 #define ZKHIP_ERR_STATE (-4)      /* library not initialised / handle invalid */
+#define ZKHIP_ERR_NO_TICKET (-5)  /* pipeline / dispatcher wait: this ticket was never issued or has been collected already
+                                     (ZKHIP_ERR_ARG from a wait means the BATCH failed: malformed or degenerate nested proofs) */
 
 typedef struct zkhip_bases zkhip_bases; /* opaque: a base-point set resident in HBM */
 
@@ -173,21 +175,40 @@ typedef struct {
   const uint32_t *c_row_ptr, *c_col; const uint64_t* c_val;
 } zkhip_r1cs_desc;
 typedef struct zkhip_r1cs zkhip_r1cs;
-int zkhip_r1cs_upload(const zkhip_r1cs_desc* d, zkhip_r1cs** out);
+/* THE EVALUATION DOMAIN of the QAP (a7).  A system of n constraints and l primary inputs interpolates n + l + 1 points.
+ *   - The reference reaches libsnark through libzeth's groth16_snark, whose generate_setup / generate_proof
+ *     (libzecale/circuits/aggregator_circuit.tcc:108, :168) pass force_pow_2_domain = true: the domain is libfqfft's
+ *     basic_radix2_domain of 2^ceil(log2(n + l + 1)) points.  That is the DEFAULT of every entry
+ *     point here: the wrapping circuit (44,183 constraints + 5) lives on 65,536 points and its key's H query has 65,535 entries.
+ *   - ZKHIP_DOMAIN_STEP asks for what libfqfft's get_evaluation_domain picks when NOT forced: a power of two if n + l + 1 is one,
+ *     else step_radix2_domain of 2^k + 2^r points (49,152 for the wrapping circuit: a quarter fewer H terms).  An explicit option -
+ *     NOT what a reference deployment uses, and unpinnable here (libfqfft and the reference's keys are absent from its tree).
+ *   - Any other value must be a size one of those two rules can return (zkhip_domain_is_valid) and at least n + l + 1.
+ * THE PROVING KEY IS AUTHORITATIVE: zkhip_crs_desc.domain_size says which domain a key was generated on, and every prover
+ * (zkhip_groth16_prove, zkhip_prover_new[_slice], zkhip_multi_prover_new, the pipelines) works on the key's domain - a 65,536-point
+ * key from a reference-style setup and a 49,152-point key from zkhip_groth16_setup_ex(.., ZKHIP_DOMAIN_STEP, ..) both prove.  A
+ * zkhip_r1cs handle handed to zkhip_groth16_prove with a key of another domain is moved to it (zkhip_r1cs_set_domain; the matrices
+ * stay in HBM, the domain's work buffers are rebuilt once).  A key whose domain cannot hold the system is refused (ZKHIP_ERR_ARG). */
+#define ZKHIP_DOMAIN_DEFAULT ((size_t)0)       /* the reference's forced power of two */
+#define ZKHIP_DOMAIN_STEP (~(size_t)0)         /* libfqfft's unforced get_evaluation_domain: a power of two or 2^k + 2^r */
+int zkhip_r1cs_upload(const zkhip_r1cs_desc* d, zkhip_r1cs** out);                        /* = _ex(d, ZKHIP_DOMAIN_DEFAULT, out) */
+int zkhip_r1cs_upload_ex(const zkhip_r1cs_desc* d, size_t domain_size, zkhip_r1cs** out);
+int zkhip_r1cs_set_domain(zkhip_r1cs* r, size_t domain_size);   /* no proof may be in flight on the handle */
 void zkhip_r1cs_free(zkhip_r1cs* r);
-unsigned zkhip_r1cs_log_domain(const zkhip_r1cs* r);   /* ceil(log2) of the QAP domain size d */
-/* The QAP's evaluation domain is the one libfqfft's get_evaluation_domain picks for n_constraints + n_primary + 1 points (reached from
- * r1cs_gg_ppzksnark_generator / _prover through aggregator_circuit.tcc:108, :168; libfqfft is an absent sub-submodule: the rule is
- * restated from its published source): a power of two (basic_radix2_domain), else 2^k + 2^r points (step_radix2_domain) - the
- * wrapping circuit's 44,188 points get 32,768 + 16,384 = 49,152, not 65,536.  d is also the proving key's domain_size (H query: d - 1). */
-size_t zkhip_r1cs_domain_size(const zkhip_r1cs* r);
-size_t zkhip_domain_size(size_t min_size);              /* host code: the domain size for min_size points */
+size_t zkhip_r1cs_domain_size(const zkhip_r1cs* r);     /* d: the points of the handle's current domain (a key's H query: d - 1) */
+/* ceil(log2 d): log2 d exactly for a radix-2 domain (the default); for a step domain 2^k + 2^r it is k + 1 - use
+ * zkhip_r1cs_domain_size where the number of points matters */
+unsigned zkhip_r1cs_log_domain(const zkhip_r1cs* r);
+/* host code, no device: the domain size for min_size = n + l + 1 points under each rule, and whether a size is a domain at all */
+size_t zkhip_domain_size(size_t min_size);              /* forced power of two (the reference, the default) */
+size_t zkhip_step_domain_size(size_t min_size);         /* libfqfft unforced: 2^k, or 2^k + 2^r */
+int zkhip_domain_is_valid(size_t domain_size);          /* 1 / 0 */
 
 /* replaces: protoboard::is_satisfied() under DEBUG (aggregator_circuit.tcc:159-164); *ok = 1/0 */
 int zkhip_r1cs_is_satisfied(zkhip_r1cs* r, const uint64_t* z, int* ok);
 
-/* replaces: libsnark::r1cs_to_qap_witness_map(cs, primary, auxiliary, 0, 0, 0, force_pow_2) -
- * coefficients_for_H.  h_out: d x 6 limbs (h_{d-1} = 0). */
+/* replaces: libsnark::r1cs_to_qap_witness_map(cs, primary, auxiliary, 0, 0, 0, force_pow_2 = true) -
+ * coefficients_for_H, over the handle's domain (above).  h_out: d x 6 limbs (h_{d-1} = 0). */
 int zkhip_qap_h(zkhip_r1cs* r, const uint64_t* z, uint64_t* h_out);
 
 /* The proving key (replaces r1cs_gg_ppzksnark_proving_key<bw6_761_pp> held by the server,
@@ -363,6 +384,10 @@ void zkhip_aggregator_pipeline_free(zkhip_pipeline* p);
 typedef struct zkhip_keypair zkhip_keypair;
 int zkhip_groth16_setup(const zkhip_r1cs_desc* cs, const uint64_t tau[6], const uint64_t alpha[6], const uint64_t beta[6],
                         const uint64_t delta[6], zkhip_keypair** out);
+/* the same with the evaluation domain as an argument (see zkhip_r1cs_upload_ex): ZKHIP_DOMAIN_DEFAULT = the forced power of two that
+ * libzeth's generate_setup uses (what zkhip_groth16_setup does), ZKHIP_DOMAIN_STEP = libfqfft's unforced choice, else a valid size */
+int zkhip_groth16_setup_ex(const zkhip_r1cs_desc* cs, const uint64_t tau[6], const uint64_t alpha[6], const uint64_t beta[6],
+                           const uint64_t delta[6], size_t domain_size, zkhip_keypair** out);
 /* proving half: pointers into the keypair (valid while it lives) */
 int zkhip_keypair_crs_desc(const zkhip_keypair* kp, zkhip_crs_desc* out);
 /* verification half: alpha (G1), beta, delta (G2), abc = (n_primary + 1) x 24 limbs; returns n_primary + 1 */
@@ -421,6 +446,7 @@ int zkhip_dispatcher_submit(zkhip_dispatcher* d, const uint64_t* nested_vk, cons
                             const uint64_t r[6], const uint64_t s[6], uint64_t* ticket);
 int zkhip_dispatcher_wait(zkhip_dispatcher* d, uint64_t ticket, uint64_t* primary_inputs, uint64_t proof_affine[72]);
 int zkhip_dispatcher_stats(const zkhip_dispatcher* d, size_t* submitted_per_entry);   /* batches given to each entry so far */
+int zkhip_dispatcher_outstanding(const zkhip_dispatcher* d, size_t* per_entry);        /* submitted and not yet collected, per entry */
 void zkhip_dispatcher_free(zkhip_dispatcher* d);
 /* One proof over a key PARTITIONED across the list (BASELINE configs[3]): entry k holds the k-th contiguous slice of
  * the A / B, H and L queries (sizes differ by at most one, the partition of zecale_amd/dist.py) and a prover instance on it; prove

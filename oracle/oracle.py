@@ -120,35 +120,58 @@ def qap_log_d(n, n_primary):
     return int(load().oracle_qap_log_d(ctypes.c_size_t(n), ctypes.c_size_t(n_primary)))
 
 
+STEP = -1          # `domain` argument: libfqfft's unforced get_evaluation_domain (None / 0 = the reference's forced power of two)
+
+
+def _dom_arg(domain):
+    return ctypes.c_size_t(0 if not domain else (2 ** (8 * ctypes.sizeof(ctypes.c_size_t)) - 1 if domain == STEP else int(domain)))
+
+
 def domain_size(min_size):
-    """Size of the evaluation domain libfqfft picks for min_size points (a power of two, or 2^k + 2^r: step_radix2_domain)."""
-    fn = load().oracle_domain_size
+    """The reference's evaluation domain for min_size points: libzeth's groth16_snark forces a power of two."""
+    fn = load().oracle_forced_domain_size
     fn.restype = ctypes.c_size_t
     return int(fn(ctypes.c_size_t(min_size)))
 
 
-def qap_domain_size(n, n_primary):
-    return domain_size(n + n_primary + 1)
+def step_domain_size(min_size):
+    """Size of the domain libfqfft picks for min_size points when NOT forced (a power of two, or 2^k + 2^r: step_radix2_domain)."""
+    fn = load().oracle_step_domain_size
+    fn.restype = ctypes.c_size_t
+    return int(fn(ctypes.c_size_t(min_size)))
+
+
+def qap_domain_size(n, n_primary, domain=None):
+    """domain: None = forced power of two (the reference), STEP = libfqfft unforced, else an explicit valid size."""
+    fn = load().oracle_qap_domain_size_ex
+    fn.restype = ctypes.c_size_t
+    d = int(fn(ctypes.c_size_t(n), ctypes.c_size_t(n_primary), _dom_arg(domain)))
+    assert d, "not a usable evaluation domain for this system: %r" % (domain,)
+    return d
 
 
 def domain_fft(a, inverse=False, coset=False):
-    """FFT / iFFT / cosetFFT / icosetFFT over the domain of len(a) points (len(a) must be a size domain_size returns)."""
+    """FFT / iFFT / cosetFFT / icosetFFT over the domain of len(a) points (a power of two or 2^k + 2^r)."""
     x = np.array(a, dtype=np.uint64).reshape(-1, 6).copy()
-    assert domain_size(x.shape[0]) == x.shape[0]
+    assert step_domain_size(x.shape[0]) == x.shape[0]
     load().oracle_domain_fft(_p(x), ctypes.c_size_t(x.shape[0]), int(inverse), int(coset))
     return x
 
 
-def qap_h(A, B, C, z, n, n_primary):
-    """A, B, C: (row_ptr u32[n+1], col u32[nnz], val u64[nnz,6]) CSR triples; z: [m,6]."""
-    d = qap_domain_size(n, n_primary)
+def qap_h(A, B, C, z, n, n_primary, domain=None):
+    """A, B, C: (row_ptr u32[n+1], col u32[nnz], val u64[nnz,6]) CSR triples; z: [m,6].  domain: as qap_domain_size - the proving
+    key's domain_size when a key is at hand."""
+    d = qap_domain_size(n, n_primary, domain)
     h = np.zeros((d, 6), dtype=np.uint64)
     args = []
     for (rp, col, val) in (A, B, C):
         args += [_p32(np.ascontiguousarray(rp, dtype=np.uint32)), _p32(np.ascontiguousarray(col, dtype=np.uint32)),
                  _p(np.ascontiguousarray(val, dtype=np.uint64))]
     zz = np.ascontiguousarray(z, dtype=np.uint64)
-    load().oracle_qap_h(*args, _p(zz), ctypes.c_size_t(n), ctypes.c_size_t(n_primary), _p(h))
+    fn = load().oracle_qap_h_ex
+    fn.restype = ctypes.c_size_t
+    got = int(fn(*args, _p(zz), ctypes.c_size_t(n), ctypes.c_size_t(n_primary), ctypes.c_size_t(d), _p(h)))
+    assert got == d
     return h
 
 

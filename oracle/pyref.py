@@ -266,13 +266,31 @@ def evaluation_domain_size(min_size):
     return big + (1 << _ceil_log2(small))
 
 
-def qap_domain_size(n_constraints, n_primary):
-    return evaluation_domain_size(n_constraints + n_primary + 1)
+def forced_domain_size(min_size):
+    """The power of two at or above min_size: the domain the REFERENCE uses - libzeth's groth16_snark::generate_setup / generate_proof
+    (reached from libzecale/circuits/aggregator_circuit.tcc:108, :168) pass force_pow_2_domain = true to libsnark (SURVEY 8 row a7,
+    App. B.1, B.2).  The wrapping circuit's 44,188 points live on 65,536."""
+    return 1 << _ceil_log2(max(1, min_size))
 
 
-def qap_domain_log(n_constraints, n_primary):
-    """ceil(log2) of the domain size (the size itself for power-of-two domains)."""
-    return _ceil_log2(qap_domain_size(n_constraints, n_primary))
+STEP = -1          # `domain` argument below: libfqfft's unforced choice (evaluation_domain_size)
+
+
+def qap_domain_size(n_constraints, n_primary, domain=None):
+    """domain None / 0: the reference's forced power of two (default);  STEP: libfqfft's unforced get_evaluation_domain;  else an
+    explicit size - what a proving key says - which must be a domain (a power of two or 2^k + 2^r) of at least n + l + 1 points."""
+    points = n_constraints + n_primary + 1
+    if not domain:
+        return forced_domain_size(points)
+    if domain == STEP:
+        return evaluation_domain_size(points)
+    assert evaluation_domain_size(domain) == domain and domain >= points, (domain, points)
+    return domain
+
+
+def qap_domain_log(n_constraints, n_primary, domain=None):
+    """ceil(log2) of the domain size (log2 itself for power-of-two domains)."""
+    return _ceil_log2(qap_domain_size(n_constraints, n_primary, domain))
 
 
 class EvalDomain:
@@ -375,11 +393,12 @@ class EvalDomain:
         return out
 
 
-def qap_witness_map(A, B, C, z, n_primary):
-    """Coefficients h_0..h_{d-2} (returned with length d; h_{d-1} = 0) of H = (A(X)B(X) - C(X)) / Z(X) over the domain libfqfft picks
-    for n + l + 1 points (evaluation_domain_size); extra rows aA[n+k] = z_k, k = 0..l (input consistency).  Returns (h, d)."""
+def qap_witness_map(A, B, C, z, n_primary, domain=None):
+    """Coefficients h_0..h_{d-2} (returned with length d; h_{d-1} = 0) of H = (A(X)B(X) - C(X)) / Z(X) over the evaluation domain
+    (qap_domain_size: the reference's forced power of two unless `domain` says otherwise); extra rows aA[n+k] = z_k, k = 0..l
+    (input consistency).  Returns (h, d)."""
     n = len(A)
-    d = qap_domain_size(n, n_primary)
+    d = qap_domain_size(n, n_primary, domain)
     dom = EvalDomain(d)
     aA = [0] * d
     aB = [0] * d
@@ -410,11 +429,12 @@ def lagrange_evals_at(d, tau):
     return EvalDomain(d).lagrange_at(tau)
 
 
-def groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
+def groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta, domain=None):
     """Trapdoor-side QAP evaluation: returns dict with At[i], Bt[i], Ct[i] (i < n_vars),
-    Zt, d (domain size), log_d (its ceil log2).  n_vars counts the constant ONE (so z has length n_vars)."""
+    Zt, d (domain size), log_d (its ceil log2).  n_vars counts the constant ONE (so z has length n_vars).
+    domain: as qap_domain_size (default: the reference's forced power of two)."""
     n = len(A)
-    d = qap_domain_size(n, n_primary)
+    d = qap_domain_size(n, n_primary, domain)
     dom = EvalDomain(d)
     L = dom.lagrange_at(tau)
     At = [0] * n_vars
@@ -432,9 +452,9 @@ def groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
     return dict(At=At, Bt=Bt, Ct=Ct, Zt=dom.vanishing(tau), d=d, log_d=_ceil_log2(d))
 
 
-def groth16_generate_keypair(A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
+def groth16_generate_keypair(A, B, C, n_vars, n_primary, tau, alpha, beta, delta, domain=None):
     """CRS in affine big-int points (tiny circuits only)."""
-    s = groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta)
+    s = groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta, domain)
     d = s["d"]
     delta_inv = inv_mod(delta, R_MOD)
     pk = dict(
@@ -460,7 +480,7 @@ def groth16_generate_keypair(A, B, C, n_vars, n_primary, tau, alpha, beta, delta
 def groth16_prove(pk, A, B, C, z, r, s):
     """Proof (A in G1, B in G2, C in G1) per SURVEY App. B.1 with injected (r, s)."""
     l = pk["n_primary"]
-    h, d = qap_witness_map(A, B, C, z, l)
+    h, d = qap_witness_map(A, B, C, z, l, pk["d"])             # the key says which domain it was generated on
     assert d == pk["d"]
     assert h[d - 1] == 0
     evA = msm_naive(z, pk["A_query"])
@@ -478,12 +498,12 @@ def groth16_prove(pk, A, B, C, z, r, s):
     return gA, gB2, gC
 
 
-def groth16_expected_proof_from_trapdoor(A, B, C, z, n_primary, tau, alpha, beta, delta, r, s):
+def groth16_expected_proof_from_trapdoor(A, B, C, z, n_primary, tau, alpha, beta, delta, r, s, domain=None):
     """Pairing-free check: with the toxic waste known, the proof elements are
     single scalar multiples of the generators."""
     n_vars = len(z)
-    st = groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta)
-    h, d = qap_witness_map(A, B, C, z, n_primary)
+    st = groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta, domain)
+    h, d = qap_witness_map(A, B, C, z, n_primary, domain)
     a_t = sum(zi * x for zi, x in zip(z, st["At"])) % R_MOD
     b_t = sum(zi * x for zi, x in zip(z, st["Bt"])) % R_MOD
     delta_inv = inv_mod(delta, R_MOD)

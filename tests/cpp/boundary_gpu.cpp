@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
     aggregator_circuit<2> agg(1);
     auto kp = agg.generate_trusted_setup();
     std::printf("ABC %zu PRIMARY %zu\n", kp->vk_abc_size(), agg.num_primary_inputs());      // aggregator_server.cpp:490
+    std::printf("DOMAIN %zu\n", kp->domain_size());                                          // the reference's forced power of two
     std::printf("VK %s\n", kp->verification_key_to_json().c_str());
     std::array<const nested_extended_proof*, 2> batch = {&np[0], &np[1]};
     extended_proof ep = agg.prove(nvk, batch, *kp);
@@ -66,6 +67,40 @@ int main(int argc, char** argv) {
     extended_proof eg = st2->wait(tg);
     std::printf("GPUWITNESS VERIFY %d INPUTS_EQUAL %d\n", kp->verify(eg) ? 1 : 0,
                 (int)(eg.primary_inputs[2] == np[1].primary_inputs[0] && eg.primary_inputs[3] == np[0].primary_inputs[0]));
+    // THE KEY IS AUTHORITATIVE FOR THE DOMAIN.  (a) A key handed over as raw arrays - what the bridge of INTEGRATION.md section 2 builds
+    // from a reference-generated r1cs_gg_ppzksnark_proving_key, domain_size 65,536 - proves through hip_proving_key; (b) the same
+    // circuit object proves with a key generated on libfqfft's unforced step domain (49,152 points) and then again with the first
+    // key: its constraint-system handle follows the key; (c) a key whose domain cannot hold the system is refused.
+    {
+      zkhip_crs_desc d;
+      zk_check(zkhip_keypair_crs_desc(kp->host(), &d), "zkhip_keypair_crs_desc");
+      std::vector<uint64_t> vkf = nvk.flat(), prf, inf, z(agg.get_constraint_system().n_vars * 6);
+      for (int p = 0; p < 2; p++) {
+        prf.insert(prf.end(), np[p].proof.a.begin(), np[p].proof.a.end()); prf.insert(prf.end(), np[p].proof.b.begin(), np[p].proof.b.end());
+        prf.insert(prf.end(), np[p].proof.c.begin(), np[p].proof.c.end());
+        inf.insert(inf.end(), np[p].primary_inputs[0].begin(), np[p].primary_inputs[0].end());
+      }
+      zkhip_aggregator* raw = nullptr;
+      zk_check(zkhip_aggregator_new(2, 1, &raw), "zkhip_aggregator_new");
+      zk_check(zkhip_aggregator_witness(raw, vkf.data(), prf.data(), inf.data(), z.data()), "zkhip_aggregator_witness");
+      zkhip_aggregator_free(raw);
+      uint64_t r[6], s[6];
+      zk_check(zkhip_fr_random(r), "zkhip_fr_random"); zk_check(zkhip_fr_random(s), "zkhip_fr_random");
+      hip_proving_key imported(d, agg.get_constraint_system());
+      groth16_proof gp = imported.generate_proof(z.data(), r, s);
+      extended_proof ei;
+      ei.proof = gp;
+      for (size_t i = 0; i < agg.num_primary_inputs(); i++) { std::array<uint64_t, 6> x; std::memcpy(x.data(), &z[(i + 1) * 6], 48); ei.primary_inputs.push_back(x); }
+      std::printf("IMPORTED_KEY domain=%zu key_domain=%zu VERIFY %d\n", imported.domain_size(), (size_t)d.domain_size, kp->verify(ei) ? 1 : 0);
+      zkhip_crs_desc small = d;
+      small.domain_size = 32768;                                       // a power of two, but below the circuit's 44,188 points
+      try { hip_proving_key bad_key(small, agg.get_constraint_system()); std::printf("SMALL_DOMAIN accepted\n"); }
+      catch (const std::runtime_error& e) { std::printf("SMALL_DOMAIN refused\n"); }
+    }
+    auto kps = agg.generate_trusted_setup(ZKHIP_DOMAIN_STEP);
+    extended_proof es = agg.prove(nvk, batch, *kps);
+    extended_proof eb = agg.prove(nvk, batch, *kp);                    // back on the 65,536-point key
+    std::printf("STEP_KEY domain=%zu VERIFY %d CROSS %d BACK %d\n", kps->domain_size(), kps->verify(es) ? 1 : 0, kp->verify(es) ? 1 : 0, kp->verify(eb) ? 1 : 0);
     std::printf("DONE\n");
   } catch (const std::exception& e) {
     std::printf("EXCEPTION %s\n", e.what());

@@ -111,23 +111,33 @@ def small_r1cs(rng, n_constraints, n_primary, n_aux):
     return A, B, C, z
 
 
-def gen_groth16(rng, n_constraints=5):
+def gen_groth16(rng, n_constraints=5, domain=None, also=()):
+    """domain: the QAP's evaluation domain (oracle/pyref.py qap_domain_size): None = the reference's forced power of two, R.STEP =
+    libfqfft's unforced choice.  also: further domains for the SAME system, trapdoor and (r, s), returned under "other_domains"."""
     n_primary = 2
     A, B, C, z = small_r1cs(rng, n_constraints, n_primary, 4)
     tau, alpha, beta, delta = (rng.randrange(1, R.R_MOD) for _ in range(4))
     r, s = rng.randrange(R.R_MOD), rng.randrange(R.R_MOD)
-    pk, vk = R.groth16_generate_keypair(A, B, C, len(z), n_primary, tau, alpha, beta, delta)
+    out = _groth16_on(A, B, C, z, n_primary, tau, alpha, beta, delta, r, s, domain)
+    if also:
+        out["other_domains"] = [_groth16_on(A, B, C, z, n_primary, tau, alpha, beta, delta, r, s, dm, key_only=True) for dm in also]
+    return out
+
+
+def _groth16_on(A, B, C, z, n_primary, tau, alpha, beta, delta, r, s, domain, key_only=False):
+    pk, vk = R.groth16_generate_keypair(A, B, C, len(z), n_primary, tau, alpha, beta, delta, domain)
     proof = R.groth16_prove(pk, A, B, C, z, r, s)
-    expect = R.groth16_expected_proof_from_trapdoor(A, B, C, z, n_primary, tau, alpha, beta, delta, r, s)
+    expect = R.groth16_expected_proof_from_trapdoor(A, B, C, z, n_primary, tau, alpha, beta, delta, r, s, domain)
     assert proof == expect
-    h, d = R.qap_witness_map(A, B, C, z, n_primary)
-    log_d = R.qap_domain_log(len(A), n_primary)
+    h, d = R.qap_witness_map(A, B, C, z, n_primary, domain)
+    log_d = R.qap_domain_log(len(A), n_primary, domain)
     # pairing check of the proof under the vk with the reference's verification equation
     assert R.bw6_groth16_verify(dict(alpha=vk["alpha_g1"], beta=vk["beta_g2"], delta=vk["delta_g2"], ABC=vk["ABC_g1"]),
                                 dict(a=proof[0], b=proof[1], c=proof[2]), z[1:1 + n_primary])
     rows = lambda M: [[[i, hx(c)] for i, c in row] for row in M]
-    return dict(n_primary=n_primary, A=rows(A), B=rows(B), C=rows(C), z=[hx(x) for x in z],
-                trapdoor=dict(tau=hx(tau), alpha=hx(alpha), beta=hx(beta), delta=hx(delta)), r=hx(r), s=hx(s),
+    system = dict() if key_only else dict(n_primary=n_primary, A=rows(A), B=rows(B), C=rows(C), z=[hx(x) for x in z],
+                                          trapdoor=dict(tau=hx(tau), alpha=hx(alpha), beta=hx(beta), delta=hx(delta)), r=hx(r), s=hx(s))
+    return dict(**system,
                 log_d=log_d, d=d, h=[hx(x) for x in h],
                 pk=dict(alpha_g1=pt(pk["alpha_g1"]), beta_g1=pt(pk["beta_g1"]), beta_g2=pt(pk["beta_g2"]),
                         delta_g1=pt(pk["delta_g1"]), delta_g2=pt(pk["delta_g2"]),
@@ -154,13 +164,15 @@ def gen_step_domain(rng):
         vecs.append(dict(d=d, input=[hx(x) for x in a], fft=[hx(x) for x in dom.fft(a)], ifft=[hx(x) for x in dom.ifft(a)],
                          coset_fft=[hx(x) for x in dom.coset_fft(a)], icoset_fft=[hx(x) for x in dom.icoset_fft(a)]))
     sizes = {str(m): R.evaluation_domain_size(m) for m in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 13, 17, 33, 100, 1025, 44188, 92060, 1048573, 4194301)}
-    g = gen_groth16(rng, n_constraints=7)
-    assert g["d"] == 10
-    return dict(domain_sizes=sizes, fft_vectors=vecs, groth16=g)
+    # the SAME system and toxic waste on both domains: "groth16" = libfqfft's unforced step domain (10 = 8 + 2 points; the library's
+    # option), "other_domains"[0] = the reference's forced power of two (16 points; the default) - key, h and proof of each
+    g = gen_groth16(rng, n_constraints=7, domain=R.STEP, also=(None,))
+    assert g["d"] == 10 and g["other_domains"][0]["d"] == 16
+    return dict(domain_sizes=sizes, forced_domain_sizes={m: R.forced_domain_size(int(m)) for m in sizes}, fft_vectors=vecs, groth16=g)
 
 
 def main():
-    if "--step-only" in sys.argv:          # (the other files are unchanged by round 4: their domains are powers of two)
+    if "--step-only" in sys.argv:          # (the other files are unchanged by rounds 4-5: their domains are powers of two under both rules)
         with open(os.path.join(HERE, "step_domain.json"), "w") as f:
             json.dump(gen_step_domain(random.Random(0x57E9)), f, indent=0)
         print("wrote step_domain")

@@ -133,11 +133,12 @@ def csr_from_rows(rows):
     return (np.array(rp, dtype=np.uint32), np.array(col, dtype=np.uint32), fr_array(val))
 
 
-def crs_from_trapdoor(zk, A, B, C, n_vars, n_primary, tau, alpha, beta, delta):
+def crs_from_trapdoor(zk, A, B, C, n_vars, n_primary, tau, alpha, beta, delta, domain=None):
     """Proving key with known toxic waste: exponents from oracle/pyref (big ints), group elements by the
-    product's fixed-base kernel (checked against the oracle in test_msm_gpu)."""
-    st = R.groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta)
-    d = st["d"]               # the domain libfqfft picks: a power of two or 2^k + 2^r (oracle/pyref.py evaluation_domain_size)
+    product's fixed-base kernel (checked against the oracle in test_msm_gpu).  domain: None = the reference's forced power of two,
+    R.STEP = libfqfft's unforced step domain, an int = that size (oracle/pyref.py qap_domain_size)."""
+    st = R.groth16_setup_scalars(A, B, C, n_vars, n_primary, tau, alpha, beta, delta, domain)
+    d = st["d"]
     dinv = pow(delta, -1, R.R_MOD)
     g1, g2 = aff_limbs(R.G1_GEN), aff_limbs(R.G2_GEN)
     can = lambda xs: np.array([R.int_to_limbs(x % R.R_MOD, 6) for x in xs], dtype=np.uint64).reshape(-1, 6)

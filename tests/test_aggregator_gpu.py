@@ -41,10 +41,13 @@ def test_aggregate_two_dummy_app_proofs(zk, oracle_lib):
     crs.free(); r1.free(); kp.free(); agg.free()
 
 
-def _setup(zk):
+def _setup(zk, domain=None):
+    """domain None: the trusted setup's default - the reference's forced power-of-two domain (65,536 points for batch 2);
+    "step": the library's option, libfqfft's unforced step domain (49,152)."""
     agg = zk.AggregatorCircuit(2, 1)
     desc = zk.r1cs_desc_from_aggregator(agg)
-    kp = zk.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
+    kp = zk.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a), domain=domain)
+    assert kp.domain_size == (49152 if domain == "step" else 65536)
     nvk, proofs = load_nested_fixtures()
     return agg, desc, kp, nested_vk_limbs(nvk), proofs
 
@@ -119,8 +122,8 @@ def test_naf_table_key_proves_the_same(zk):
     expected = zk.groth16_prove(crs, r1, z, r, s_)
     crs.free()
     crs2 = kp.upload_crs(zk.key_opts(table_naf=True))
-    # such a key picks its window from its finite bases (log2(176,280) - 2.45 -> 15; the default tables keep 16 for this size) ...
-    assert crs2.table_kind == 2 and crs2.table_window == 15 and sum(crs2.finite_terms()) == 176280
+    # such a key picks its window from its finite bases (log2(192,664) - 2.45 -> 15: 65,535 H terms on the reference's domain; the default tables keep 16 for this size) ...
+    assert crs2.table_kind == 2 and crs2.table_window == 15 and sum(crs2.finite_terms()) == 192664
     assert (zk.groth16_prove(crs2, r1, z, r, s_) == expected).all()
     # ... and an explicit window still wins
     crs3 = kp.upload_crs(zk.key_opts(table_naf=True, window=13))
@@ -242,8 +245,10 @@ def test_sixteen_batches_of_a_32_proof_round(zk):
     crs.free(); kp.free(); agg.free()
 
 
-def test_nine_inputs_per_nested_proof_on_the_gpu(zk):
-    """The Zeth-shaped workload of libzecale/tests/aggregator/aggregator_test.cpp:222-254 (9 primary inputs per nested proof):
+@pytest.mark.parametrize("domain", [None, "step"], ids=["forced-pow2-domain", "step-domain"])
+def test_nine_inputs_per_nested_proof_on_the_gpu(zk, domain):
+    """(Both evaluation domains: the reference's forced 131,072 points - the default - and the optional 98,304-point step domain.)
+    The Zeth-shaped workload of libzecale/tests/aggregator/aggregator_test.cpp:222-254 (9 primary inputs per nested proof):
     circuit, trusted setup on the GPU, witness, wrapping proof, wsnark::verify.  No Zeth proofs are in the tree: the nested key is
     padded with further G1 points of the fixtures, so the nested proofs are INVALID for it and the wrapping proof must carry result
     bits 0 (aggregator_circuit.hpp:51-54) together with the 18 nested inputs."""
@@ -251,10 +256,11 @@ def test_nine_inputs_per_nested_proof_on_the_gpu(zk):
     agg = zk.AggregatorCircuit(2, k)
     assert agg.num_primary_inputs() == 2 + 2 * k
     desc = zk.r1cs_desc_from_aggregator(agg)
-    kp = zk.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
+    kp = zk.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a), domain=domain)
+    assert kp.domain_size == (98304 if domain == "step" else 131072)
     vk = kp.vk()
     assert vk["ABC"].shape[0] == 2 + 2 * k + 1
-    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
+    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)          # (the handle starts on the default domain and follows the key)
     nvk, proofs = load_nested_fixtures()
     nvk9 = dict(nvk)
     nvk9["ABC"] = list(nvk["ABC"]) + [proofs[i][0]["a"] for i in range(6)] + [proofs[0][0]["c"], proofs[1][0]["c"]]
@@ -329,16 +335,19 @@ def test_entry_points_bind_their_device_on_any_thread(zk):
     crs.free(); r1.free(); kp.free(); agg.free()
 
 
+@pytest.mark.parametrize("domain", [None, "step"], ids=["forced-pow2-domain", "step-domain"])
 @pytest.mark.parametrize("naf", [False, True], ids=["window-tables", "naf-tables"])
 @pytest.mark.parametrize("gpu_witness", [False, True], ids=["host-witness", "gpu-witness"])
-def test_wrapping_proof_equals_oracle(zk, oracle_lib, naf, gpu_witness):
+def test_wrapping_proof_equals_oracle(zk, oracle_lib, naf, gpu_witness, domain):
     """The checks of aggregator_dummy_test.cpp:61-96 with the ORACLE as the judge of the proof itself: the assignment of the real
     batch-2 circuit (reference fixtures) goes through the C restatement of r1cs_to_qap_witness_map + r1cs_gg_ppzksnark_prover and
     through the GPU prover with the same (r, s) uniform in Fr - the three proof elements must agree limb for limb, for both kinds
-    of window table and for the assignment generated on the host and on the GPU.  (Rounds 1-2 held this comparison in bench.py only.)"""
+    of window table and for the assignment generated on the host and on the GPU.  (Rounds 1-2 held this comparison in bench.py only.)
+    On BOTH evaluation domains: 65,536 points - what libzeth's groth16_snark forces, the reference's and the default
+    - and the optional 49,152-point step domain; the oracle takes the domain from the key, like the product."""
     from tests.helpers import random_fr_uniform
     O = oracle_lib
-    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    agg, desc, kp, nvk_l, proofs = _setup(zk, domain)
     crs = kp.upload_crs(zk.key_opts(table_naf=naf))
     assert crs.table_kind == (2 if naf else 1)
     r1 = zk.r1cs_from_desc(desc)
@@ -346,19 +355,22 @@ def test_wrapping_proof_equals_oracle(zk, oracle_lib, naf, gpu_witness):
     npr = np.concatenate([nested_proof_limbs(p1), nested_proof_limbs(p2)])
     l = agg.num_primary_inputs()
     pk, m, l_pk, dom = kp.pk_arrays()
-    assert l_pk == l
+    assert l_pk == l and dom == (49152 if domain == "step" else 65536) == O.qap_domain_size(agg.num_constraints, l, O.STEP if domain == "step" else None)
+    assert r1.domain_size == 65536                        # the handle's default; the step key moves it
     A, B, C = agg.get_constraint_system()
     rs = random_fr_uniform(1234, 2)                       # canonical limbs below r are valid Montgomery residues: uniform in Fr
     # (the invalid-nested-proof batch for the default combination only: the CPU oracle needs ~4 s per proof)
-    for bump, bits in (((0, 3), (1, 1)) if not (naf or gpu_witness) else ((0, 3),)):
+    for bump, bits in (((0, 3), (1, 1)) if not (naf or gpu_witness or domain) else ((0, 3),)):
         nin = np.array([fr_limbs(in1[0]), fr_limbs(in2[0] + bump)])
         z = agg.witness_gpu(nvk_l, npr, nin) if gpu_witness else agg.witness(nvk_l, npr, nin)
         assert O.r1cs_first_unsatisfied(A, B, C, z) == -1
-        h = O.qap_h(A, B, C, z, agg.num_constraints, l)
+        h = O.qap_h(A, B, C, z, agg.num_constraints, l, dom)
+        r1.set_domain(dom)
         assert (r1.qap_h(z) == h).all()                   # coefficients_for_H, limb for limb
+        r1.set_domain(None)                               # ... and the proof below follows the KEY from the default domain
         expect = O.groth16_prove(pk, z, l, h, rs[0], rs[1])
         got = zk.groth16_prove(crs, r1, z, rs[0], rs[1])
-        assert (got == expect).all()
+        assert (got == expect).all() and r1.domain_size == dom
         assert zk.groth16_verify(kp.vk(), z[1:1 + l], got) and fr_int(z[2]) == bits
     crs.free(); r1.free(); kp.free(); agg.free()
 

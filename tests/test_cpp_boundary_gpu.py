@@ -46,6 +46,13 @@ def test_cpp_mirror_setup_prove_verify_and_stream(zk, tmp_path):
     assert lines["THROW"] == "attempt to aggregate proof with invalid number of inputs"     # aggregator_circuit.tcc:138-141
     assert lines["OFFCURVE"].startswith("nested proof or verification key has a point that is not on its curve")
     assert lines["GPUWITNESS"] == "VERIFY 1 INPUTS_EQUAL 1"
+    # the reference's domain is the default, and the key decides: generate_trusted_setup gives the forced power of
+    # two; a 65,536-point key handed over as raw arrays proves; a step-domain key (49,152) proves on the same
+    # circuit object, and the first key again after it; a key whose domain cannot hold the 44,188 points is refused
+    assert lines["DOMAIN"] == "65536"
+    assert lines["IMPORTED_KEY"] == "domain=65536 key_domain=65536 VERIFY 1"
+    assert lines["SMALL_DOMAIN"] == "refused"
+    assert lines["STEP_KEY"] == "domain=49152 VERIFY 1 CROSS 0 BACK 1"
     assert "DONE" in out.stdout
     # the printed JSON is the reference's encoding: decode it here and verify with the host pairing check
     vk = E.verification_key_from_json(json.loads(lines["VK"]))

@@ -114,8 +114,27 @@ def test_dispatcher_spreads_batches_over_two_contexts(zk, wrapping):
     assert len(firsts) == 2                                       # same (r, s): one proof per order of the nested proofs
     st = disp.stats()
     assert sum(st) == 12 and min(st) >= 3, st
-    with pytest.raises(zk.ZkhipError):
+    assert disp.outstanding() == [0, 0]
+    with pytest.raises(zk.ZkhipError) as e:
         disp.wait(12345)                                          # no such ticket
+    assert e.value.code == -5                                     # ZKHIP_ERR_NO_TICKET, not the ERR_ARG of a failed batch
+    # a batch that FAILS (an off-curve nested proof: witness generation refuses it with ZKHIP_ERR_ARG) is a known
+    # ticket - collecting it must take it off its entry's count, or least-loaded routing steers away from that GPU for good
+    bad = w["npr"].copy(); bad[48 + 6] ^= np.uint64(1)            # y of the second proof's A
+    bad_tickets = [disp.submit(w["nvk"], bad, w["nin"], rr, ss) for _ in range(4)]
+    assert sum(disp.outstanding()) == 4
+    for t in bad_tickets:
+        with pytest.raises(zk.ZkhipError) as e:
+            disp.wait(t)
+        assert e.value.code == -1                                 # ZKHIP_ERR_ARG: the batch itself
+    assert disp.outstanding() == [0, 0]
+    before = disp.stats()
+    good = [disp.submit(w["nvk"], w["npr"], w["nin"], rr, ss) for _ in range(6)]
+    for t in good:
+        prim, proof = disp.wait(t)
+        assert zk.groth16_verify(vk, prim, proof)
+    after = disp.stats()
+    assert [a - b for a, b in zip(after, before)] == [3, 3]       # both entries still take their share
     disp.free()
     with pytest.raises(zk.ZkhipError):
         zk.AggregatorDispatcher(w["agg"], w["kp"], [0, 99])       # no such GPU: refused, nothing leaked

@@ -192,14 +192,20 @@ def test_c_oracle_qap_and_groth16(oracle_lib):
     assert aff_point(proof[48:]) == pt_from_json(g["proof"]["c"])
 
 
-def test_c_oracle_step_domains(oracle_lib):
-    """Round 4: the evaluation domains libfqfft picks for sizes that are not powers of two (step_radix2_domain, 2^k + 2^r points;
-    tests/golden/step_domain.json comes from oracle/pyref.py, where every transform is checked against naive evaluation at the
-    domain's points): domain sizes, the four transforms, the QAP map and the Groth16 proof of a 10-point instance."""
+def test_c_oracle_evaluation_domains(oracle_lib):
+    """The two rules for the QAP's evaluation domain (tests/golden/step_domain.json comes from oracle/pyref.py, where every transform
+    is checked against naive evaluation at the domain's points): the reference's FORCED power of two - libzeth's groth16_snark passes
+    force_pow_2_domain = true; the oracle's and the product's default - and libfqfft's unforced choice
+    (step_radix2_domain, 2^k + 2^r points; an option).  Domain sizes under both rules, the four transforms, and ONE 10-point system
+    with one trapdoor on both domains: the QAP map and the Groth16 proof of each, C oracle against pyref."""
     O = oracle_lib
     g = golden("step_domain.json")
     for m, d in g["domain_sizes"].items():
-        assert O.domain_size(int(m)) == d == R.evaluation_domain_size(int(m))
+        assert O.step_domain_size(int(m)) == d == R.evaluation_domain_size(int(m))
+        assert O.domain_size(int(m)) == g["forced_domain_sizes"][m] == R.forced_domain_size(int(m)) == 1 << (int(m) - 1).bit_length()
+    assert O.qap_domain_size(44183, 4) == 65536 == R.qap_domain_size(44183, 4)                  # the wrapping circuit, batch 2: the reference's domain
+    assert O.qap_domain_size(44183, 4, O.STEP) == 49152 == R.qap_domain_size(44183, 4, R.STEP)  # ... and the optional one
+    assert O.qap_domain_size(44183, 4, 65536) == 65536 and R.qap_domain_size(44183, 4, 98304) == 98304
     for v in g["fft_vectors"]:
         a = fr_array([h2i(x) for x in v["input"]])
         assert fr_ints(O.domain_fft(a)) == [h2i(x) for x in v["fft"]], v["d"]
@@ -208,15 +214,17 @@ def test_c_oracle_step_domains(oracle_lib):
         assert fr_ints(O.domain_fft(a, inverse=True, coset=True)) == [h2i(x) for x in v["icoset_fft"]], v["d"]
     q = g["groth16"]
     pts = lambda L: np.array([aff_limbs(pt_from_json(p)) for p in L]).reshape(-1, 24)
-    pk = {k: (aff_limbs(pt_from_json(v)) if k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2") else pts(v))
-          for k, v in q["pk"].items()}
     A, B, C = (csr_from_rows(q[k]) for k in "ABC")
     z = fr_array([h2i(x) for x in q["z"]])
     n = len(q["A"])
-    assert O.qap_domain_size(n, q["n_primary"]) == q["d"] == 10
-    h = O.qap_h(A, B, C, z, n, q["n_primary"])
-    assert fr_ints(h) == [h2i(x) for x in q["h"]] and h.shape[0] == 10
-    proof = O.groth16_prove(pk, z, q["n_primary"], h, fr_limbs(h2i(q["r"])), fr_limbs(h2i(q["s"])), chunks=2)
-    assert aff_point(proof[:24]) == pt_from_json(q["proof"]["a"])
-    assert aff_point(proof[24:48]) == pt_from_json(q["proof"]["b"])
-    assert aff_point(proof[48:]) == pt_from_json(q["proof"]["c"])
+    assert O.qap_domain_size(n, q["n_primary"], O.STEP) == q["d"] == 10 and O.qap_domain_size(n, q["n_primary"]) == 16
+    for case, dom in ((q, O.STEP), (q["other_domains"][0], None), (q["other_domains"][0], 16)):
+        pk = {k: (aff_limbs(pt_from_json(v)) if k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2") else pts(v))
+              for k, v in case["pk"].items()}
+        h = O.qap_h(A, B, C, z, n, q["n_primary"], dom)
+        assert fr_ints(h) == [h2i(x) for x in case["h"]] and h.shape[0] == case["d"] == len(case["pk"]["H"]) + 1
+        proof = O.groth16_prove(pk, z, q["n_primary"], h, fr_limbs(h2i(q["r"])), fr_limbs(h2i(q["s"])), chunks=2)
+        assert aff_point(proof[:24]) == pt_from_json(case["proof"]["a"])
+        assert aff_point(proof[24:48]) == pt_from_json(case["proof"]["b"])
+        assert aff_point(proof[48:]) == pt_from_json(case["proof"]["c"])
+    assert q["proof"] != q["other_domains"][0]["proof"]          # another domain: other Lagrange bases, another key, another proof

@@ -54,30 +54,42 @@ def test_golden_small_circuit(zk, key_mode):
     crs.free(); r1.free()
 
 
-@pytest.mark.parametrize("n,bool_frac", [(3000, 0.0), (4000, 0.6)])
-def test_synthetic_circuit_vs_oracle_and_trapdoor(zk, oracle_lib, key_mode, n, bool_frac):
+@pytest.mark.parametrize("n,bool_frac,domain", [(3000, 0.0, None), (3000, 0.0, "step"), (4000, 0.6, None)])
+def test_synthetic_circuit_vs_oracle_and_trapdoor(zk, oracle_lib, key_mode, n, bool_frac, domain):
+    """domain None: the reference's forced power of two (libzeth passes force_pow_2_domain) - the default of every
+    entry point; "step": libfqfft's unforced step_radix2_domain, the library's explicit option.  The constraint-system handle is
+    created on the DEFAULT domain in both cases: zkhip_groth16_prove moves it to the key's."""
     O = oracle_lib
     n_primary, n_aux = 4, n                # the wrapping circuit has 4 primary inputs (aggregator_circuit.tcc:172-180)
     A, B, C, z = make_r1cs(11 + n, n, n_primary, n_aux, bool_frac)
     m = len(z)
     rng = random.Random(5)
     tau, alpha, beta, delta, r, s = (rng.randrange(1, R.R_MOD) for _ in range(6))
-    pk, d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta)
+    dom = R.STEP if domain == "step" else None
+    pk, d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta, dom)
     Ac, Bc, Cc = csr_from_rows(A), csr_from_rows(B), csr_from_rows(C)
     zl = fr_array(z)
     r1 = zk.R1cs(Ac, Bc, Cc, m, n_primary)
-    # n = 3000: 3,005 points -> 2,048 + 1,024 (libfqfft's step_radix2_domain); n = 4000: 4,005 -> 4,096 (basic_radix2_domain)
-    assert r1.domain_size == d == O.qap_domain_size(n, n_primary) == {3000: 3072, 4000: 4096}[n] and r1.is_satisfied(zl)
+    # n = 3000: 3,005 points -> 4,096 forced, 2,048 + 1,024 unforced (step_radix2_domain); n = 4000: 4,005 -> 4,096 either way
+    assert r1.domain_size == 4096 == O.qap_domain_size(n, n_primary) == zk.domain_size(n + n_primary + 1)
+    assert d == O.qap_domain_size(n, n_primary, O.STEP if domain == "step" else None) == {(3000, None): 4096, (3000, "step"): 3072, (4000, None): 4096}[(n, domain)]
+    assert zk.step_domain_size(n + n_primary + 1) == {3000: 3072, 4000: 4096}[n]
+    assert r1.is_satisfied(zl)
+    if d != r1.domain_size:
+        r1.set_domain(d)
+        assert r1.domain_size == d and r1.is_satisfied(zl)
     h = r1.qap_h(zl)
-    h_or = O.qap_h(Ac, Bc, Cc, zl, n, n_primary)
+    h_or = O.qap_h(Ac, Bc, Cc, zl, n, n_primary, d)
+    r1.set_domain(None)                    # back on the default: the proof below must follow the KEY
     assert (h == h_or).all()
     assert (h[-1] == 0).all()
     crs = zk.Crs(pk, m, n_primary, d, opts=_opts(zk, key_mode))
     proof = zk.groth16_prove(crs, r1, zl, fr_limbs(r), fr_limbs(s))
+    assert r1.domain_size == d
     proof_or = O.groth16_prove(pk, zl, n_primary, h_or, fr_limbs(r), fr_limbs(s))
     assert (proof == proof_or).all()
     # trapdoor closed form: A = (alpha + a(tau) + r delta) G1 etc. with h from the oracle
-    st = R.groth16_setup_scalars(A, B, C, m, n_primary, tau, alpha, beta, delta)
+    st = R.groth16_setup_scalars(A, B, C, m, n_primary, tau, alpha, beta, delta, dom)
     hi = fr_ints(h_or)
     a_t = sum(zi * x for zi, x in zip(z, st["At"])) % R.R_MOD
     b_t = sum(zi * x for zi, x in zip(z, st["Bt"])) % R.R_MOD
@@ -111,6 +123,50 @@ def test_bad_arguments(zk):
     r1.free()
 
 
+def test_key_names_the_domain(zk):
+    """a prover works on the domain its KEY was generated on.  One 2,505-point system, three keys from the same
+    toxic waste: the reference's forced 4,096 points, libfqfft's unforced 2,048 + 512, and 8,192 (a larger valid domain).  Every key
+    proves through the shared handle and through a prover instance; the proofs differ (other Lagrange bases, other H) and each verifies
+    under ITS key only; a key whose domain is too small (2,048), or not a domain (3,000), is refused."""
+    n, n_primary = 2500, 4
+    A, B, C, z = make_r1cs(78, n, n_primary, n, 0.3)
+    m = len(z)
+    rng = random.Random(10)
+    tau, alpha, beta, delta, r, s = (rng.randrange(1, R.R_MOD) for _ in range(6))
+    csr = (csr_from_rows(A), csr_from_rows(B), csr_from_rows(C))
+    desc, keep = zk.make_r1cs_desc(*csr, m, n_primary)
+    zl = fr_array(z)
+    r1 = zk.R1cs(*csr, m, n_primary)
+    assert r1.domain_size == 4096
+    proofs = {}
+    for dom, want in ((None, 4096), (R.STEP, 2560), (8192, 8192)):
+        pk, d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta, dom)
+        assert d == want
+        crs = zk.Crs(pk, m, n_primary, d)
+        proof = zk.groth16_prove(crs, r1, zl, fr_limbs(r), fr_limbs(s))
+        assert r1.domain_size == d
+        pr = zk.Prover(crs, desc)
+        assert (pr.prove(zl, fr_limbs(r), fr_limbs(s)) == proof).all()
+        pr.free()
+        assert zk.groth16_verify(pk["vk"], zl[1:1 + n_primary], proof)
+        proofs[want] = (proof, pk["vk"])
+        crs.free()
+    assert not zk.groth16_verify(proofs[4096][1], zl[1:1 + n_primary], proofs[2560][0])
+    assert not (proofs[4096][0][48:] == proofs[8192][0][48:]).all()
+    pk, d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta, None)
+    for bad_d in (2048, 3000):
+        with pytest.raises(zk.ZkhipError):
+            bad = dict(pk); bad["H"] = pk["H"][:bad_d - 1]
+            crs = zk.Crs(bad, m, n_primary, bad_d)
+            try:
+                zk.groth16_prove(crs, r1, zl, fr_limbs(r), fr_limbs(s))
+            finally:
+                crs.free()
+    with pytest.raises(zk.ZkhipError):
+        zk.R1cs(*csr, m, n_primary, domain=2048)
+    r1.free()
+
+
 def test_key_partitioned_prover_matches_whole_key(zk):
     """SURVEY 8e on one device: the proving key cut into 3 uneven slices (as 3 ranks would hold it), partial sums
     added, tail run once == the single-GPU proof, limb for limb."""
@@ -120,9 +176,9 @@ def test_key_partitioned_prover_matches_whole_key(zk):
     m = len(z)
     rng = random.Random(9)
     tau, alpha, beta, delta, r, s = (rng.randrange(1, R.R_MOD) for _ in range(6))
-    pk, d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta)
-    assert d == 2048 + 512                               # 2,505 points: a step domain with four rows per column
-    r1 = zk.R1cs(csr_from_rows(A), csr_from_rows(B), csr_from_rows(C), m, n_primary)
+    pk, d = crs_from_trapdoor(zk, A, B, C, m, n_primary, tau, alpha, beta, delta, R.STEP)
+    assert d == 2048 + 512                               # 2,505 points: the OPTIONAL step domain with four rows per column (slices of a non-power-of-two H query)
+    r1 = zk.R1cs(csr_from_rows(A), csr_from_rows(B), csr_from_rows(C), m, n_primary, domain="step")
     zl = fr_array(z)
     whole = zk.Crs(pk, m, n_primary, d)
     expect = zk.groth16_prove(whole, r1, zl, fr_limbs(r), fr_limbs(s))
@@ -236,30 +292,35 @@ def test_full_size_2_22_proof_verifies(zk):
     _full_size_proof_verifies(zk, 22)
 
 
-def test_step_domain_golden_instance(zk):
-    """tests/golden/step_domain.json: 7 constraints + 2 inputs + 1 = 10 = 8 + 2 points (libfqfft's step_radix2_domain) - the
-    coefficients of H and the proof that oracle/pyref.py computed (its transforms checked against naive evaluation, the proof
-    against the pinned pairing check), limb for limb."""
+def test_both_domains_golden_instance(zk):
+    """tests/golden/step_domain.json: ONE system (7 constraints + 2 inputs + 1 = 10 points) and trapdoor on both evaluation domains -
+    16 points (the reference's forced power of two: the default) and 10 = 8 + 2 points (libfqfft's unforced step_radix2_domain: the
+    option) - the coefficients of H and the proof that oracle/pyref.py computed for each (its transforms checked against naive
+    evaluation, the proofs against the pinned pairing check), limb for limb.  One handle serves both keys."""
     g = golden("step_domain.json")["groth16"]
     pts = lambda L: np.array([aff_limbs(pt_from_json(p)) for p in L]).reshape(-1, 24)
-    pk = {k: (aff_limbs(pt_from_json(v)) if k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2") else pts(v)) for k, v in g["pk"].items()}
     A, B, C = (csr_from_rows(g[k]) for k in "ABC")
     z = fr_array([h2i(x) for x in g["z"]])
     r1 = zk.R1cs(A, B, C, len(g["z"]), g["n_primary"])
-    assert r1.domain_size == 10 == zk.domain_size(10) and r1.log_d == 4 and r1.is_satisfied(z)
-    assert fr_ints(r1.qap_h(z)) == [h2i(x) for x in g["h"]]
-    crs = zk.Crs(pk, len(g["z"]), g["n_primary"], 10)
-    proof = zk.groth16_prove(crs, r1, z, fr_limbs(h2i(g["r"])), fr_limbs(h2i(g["s"])))
-    assert aff_point(proof[:24]) == pt_from_json(g["proof"]["a"])
-    assert aff_point(proof[24:48]) == pt_from_json(g["proof"]["b"])
-    assert aff_point(proof[48:]) == pt_from_json(g["proof"]["c"])
-    crs.free(); r1.free()
+    assert r1.domain_size == 16 == zk.domain_size(10) and zk.step_domain_size(10) == 10 and r1.is_satisfied(z)
+    for case in (g["other_domains"][0], g, g["other_domains"][0]):
+        pk = {k: (aff_limbs(pt_from_json(v)) if k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2") else pts(v)) for k, v in case["pk"].items()}
+        crs = zk.Crs(pk, len(g["z"]), g["n_primary"], case["d"])
+        proof = zk.groth16_prove(crs, r1, z, fr_limbs(h2i(g["r"])), fr_limbs(h2i(g["s"])))
+        assert r1.domain_size == case["d"] and r1.log_d == 4 and r1.is_satisfied(z)
+        assert fr_ints(r1.qap_h(z)) == [h2i(x) for x in case["h"]]
+        assert aff_point(proof[:24]) == pt_from_json(case["proof"]["a"])
+        assert aff_point(proof[24:48]) == pt_from_json(case["proof"]["b"])
+        assert aff_point(proof[48:]) == pt_from_json(case["proof"]["c"])
+        crs.free()
+    r1.free()
 
 
 @pytest.mark.parametrize("points,domain", [(3, 3), (6, 6), (11, 12), (1025, 1025), (1030, 1032), (2500, 2560), (4100, 4100), (6000, 6144), (20000, 20480),
                                            (33000, 33024)])
 def test_step_domains_qap_against_the_oracle(zk, oracle_lib, points, domain):
-    """The QAP map over the domains libfqfft picks for sizes that are not powers of two (2^k + 2^r points), against the C oracle:
+    """The library's OPTION (ZKHIP_DOMAIN_STEP; the default is the reference's forced power of two, checked beside it here).
+    The QAP map over the domains libfqfft picks, unforced, for sizes that are not powers of two (2^k + 2^r points), against the C oracle:
     one row per column up to a thousand (1,025 = 1,024 + 1: the whole big part folds into ONE point), parts below and above the
     2^12 points from which a transform's input order is transposed, the two parts in different orders (4,100 = 4,096 + 4)."""
     O = oracle_lib
@@ -274,7 +335,12 @@ def test_step_domains_qap_against_the_oracle(zk, oracle_lib, points, domain):
         return rp, cols, bench.random_fr_canonical(int(rng.integers(1 << 30)), n * terms)
     csr = (rand_csr(2), rand_csr(1), rand_csr(2))
     z = bench.random_fr_canonical(7 + points, m)
-    r1 = zk.R1cs(*csr, m, l)
-    assert r1.domain_size == domain == O.qap_domain_size(n, l) == zk.domain_size(points)
-    assert (r1.qap_h(z) == O.qap_h(*csr, z, n, l)).all()          # (an unsatisfied system: H is then a quotient with a remainder - the same one)
+    r1 = zk.R1cs(*csr, m, l, domain="step")
+    assert r1.domain_size == domain == O.qap_domain_size(n, l, O.STEP) == zk.step_domain_size(points)
+    assert (r1.qap_h(z) == O.qap_h(*csr, z, n, l, O.STEP)).all()          # (an unsatisfied system: H is then a quotient with a remainder - the same one)
+    # the same handle on the reference's domain: the forced power of two
+    r1.set_domain(None)
+    forced = 1 << (points - 1).bit_length()
+    assert r1.domain_size == forced == O.qap_domain_size(n, l) == zk.domain_size(points)
+    assert (r1.qap_h(z) == O.qap_h(*csr, z, n, l)).all()
     r1.free()

@@ -1,14 +1,20 @@
-// Evaluation domains of the QAP (host side): which domain libfqfft's get_evaluation_domain picks for `min_size` points over Fr of
-// BW6-761 (2-adicity 46), its points, its vanishing polynomial and the Lagrange basis at a point.  [UPSTREAM-RECALL: libfqfft is an
-// absent sub-submodule of the reference; libfqfft/evaluation_domain/get_evaluation_domain.tcc and
-// domains/{basic,step}_radix2_domain.tcc.]  Reached in the reference from r1cs_gg_ppzksnark_generator / _prover through
-// aggregator_circuit.tcc:108 and :168.
-//   min_size a power of two: basic_radix2_domain, points w^i.
-//   otherwise: step_radix2_domain of m = big + small points, big = the largest power of two below min_size, small = min_size - big
-//   rounded up to a power of two (if that makes m = 2 big, the basic domain of that size): points big_w^i (i < big), then
-//   w small_w^i (i < small) with w of order 2 big, big_w = w^2, small_w of order small; Z(x) = (x^big - 1)(x^small - w^small).
-// The wrapping circuit (44,183 constraints + 5) gets 32,768 + 16,384 = 49,152 points where a power of two would be 65,536: a
-// quarter fewer H-query terms and transform points.  Rounds 1-3 always rounded up to a power of two.
+// Evaluation domains of the QAP (host side): the domains libfqfft offers over Fr of BW6-761 (2-adicity 46), their points, their
+// vanishing polynomial and the Lagrange basis at a point.  [UPSTREAM-RECALL: libfqfft is an absent sub-submodule of the reference
+// (SURVEY 0.1); libfqfft/evaluation_domain/get_evaluation_domain.tcc and domains/{basic,step}_radix2_domain.tcc.]  Reached in the
+// reference from r1cs_gg_ppzksnark_generator / _prover through aggregator_circuit.tcc:108 and :168.
+//
+// WHICH domain a system of n constraints and l inputs gets (n + l + 1 points):
+//   * the reference: libzeth's groth16_snark passes force_pow_2_domain = true to the generator and to the prover (SURVEY App. B.1,
+//     B.2, row a7): basic_radix2_domain of 2^ceil(log2(n + l + 1)) points.  This is the DEFAULT here (forced_domain_size): the
+//     wrapping circuit (44,183 constraints + 5) lives on 65,536 points and a reference key's H query has 65,535 entries.
+//   * libfqfft's unforced get_evaluation_domain (eval_domain_size), an explicit OPTION (ZKHIP_DOMAIN_STEP): a power of two gets the
+//     basic domain; anything else step_radix2_domain of m = big + small points, big = the largest power of two below min_size, small =
+//     min_size - big rounded up to a power of two (if that makes m = 2 big, the basic domain of that size): points big_w^i (i < big),
+//     then w small_w^i (i < small) with w of order 2 big, big_w = w^2, small_w of order small; Z(x) = (x^big - 1)(x^small - w^small).
+//     The wrapping circuit would get 32,768 + 16,384 = 49,152 points: a quarter fewer H-query terms - but NOT the domain of a key
+//     the reference generates, and nothing in the reference's tree can pin it.
+// A proving key is authoritative: a prover works on the domain its key was generated for (zkhip_crs_desc.domain_size), whichever
+// of the two it is (is_valid_domain).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -21,11 +27,24 @@ namespace host {
 
 inline int ceil_log2(size_t n) { int k = 0; while (((size_t)1 << k) < n) k++; return k; }
 
+// the reference's choice (force_pow_2_domain): the power of two at or above min_size
+inline size_t forced_domain_size(size_t min_size) { return (size_t)1 << ceil_log2(min_size < 1 ? 1 : min_size); }
+// libfqfft's unforced choice
 inline size_t eval_domain_size(size_t min_size) {
   if (min_size <= 1) return 1;
   if ((min_size & (min_size - 1)) == 0) return min_size;
   const size_t big = (size_t)1 << (ceil_log2(min_size) - 1), small = min_size - big;
   return big + ((size_t)1 << ceil_log2(small));
+}
+
+// a size get_evaluation_domain can return: a power of two, or 2^k + 2^r with r < k (a fixed point of eval_domain_size)
+inline bool is_valid_domain(size_t d) { return d >= 1 && eval_domain_size(d) == d; }
+// the domain of a system with `points` = n + l + 1 interpolation points: requested == 0: the forced power of two (default);
+// requested == (size_t)-1: libfqfft's unforced choice; else `requested` itself if it is valid and large enough; 0 = refused
+inline size_t resolve_domain(size_t points, size_t requested) {
+  if (requested == 0) return forced_domain_size(points);
+  if (requested == (size_t)-1) return eval_domain_size(points);
+  return (is_valid_domain(requested) && requested >= points) ? requested : 0;
 }
 
 inline HFr fr_pow_u64(const HFr& b, uint64_t e) { uint64_t ee[1] = {e}; return b.pow_limbs(ee, 1); }

@@ -117,9 +117,12 @@ int zkhip_dispatcher_submit(zkhip_dispatcher* d, const uint64_t* nested_vk, cons
 int zkhip_dispatcher_wait(zkhip_dispatcher* d, uint64_t ticket, uint64_t* primary_inputs, uint64_t proof_affine[72]) {
   if (!d || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
   const size_t idx = (size_t)(ticket >> 56);
-  if (idx < 1 || idx > d->pipes.size()) return fail(ZKHIP_ERR_ARG, "no such ticket");
+  if (idx < 1 || idx > d->pipes.size()) return fail(ZKHIP_ERR_NO_TICKET, "no such ticket");
   const int rc = zkhip_aggregator_pipeline_wait(d->pipes[idx - 1], ticket & (((uint64_t)1 << 56) - 1), primary_inputs, proof_affine);
-  if (rc != ZKHIP_ERR_ARG) d->outstanding[idx - 1]--;        // (ZKHIP_ERR_ARG: the pipeline never knew the ticket)
+  // a known ticket is consumed whatever its batch's result was (ZKHIP_ERR_ARG = the batch itself failed: a degenerate or malformed
+  // nested proof); only a ticket the pipeline never issued, or one whose pipeline is shutting down, leaves the count alone
+  if (rc == ZKHIP_ERR_NO_TICKET) return fail(rc, "no such ticket");
+  if (rc != ZKHIP_ERR_STATE) d->outstanding[idx - 1]--;
   return rc;
 }
 
@@ -127,6 +130,13 @@ int zkhip_dispatcher_wait(zkhip_dispatcher* d, uint64_t ticket, uint64_t* primar
 int zkhip_dispatcher_stats(const zkhip_dispatcher* d, size_t* submitted_per_entry) {
   if (!d || !submitted_per_entry) return fail(ZKHIP_ERR_ARG, "null pointer");
   for (size_t i = 0; i < d->pipes.size(); i++) submitted_per_entry[i] = d->submitted[i].load();
+  return ZKHIP_OK;
+}
+
+// batches each entry still owes a collector (what submit's least-loaded routing looks at)
+int zkhip_dispatcher_outstanding(const zkhip_dispatcher* d, size_t* per_entry) {
+  if (!d || !per_entry) return fail(ZKHIP_ERR_ARG, "null pointer");
+  for (size_t i = 0; i < d->pipes.size(); i++) per_entry[i] = d->outstanding[i].load();
   return ZKHIP_OK;
 }
 
@@ -159,6 +169,9 @@ int zkhip_multi_prover_new(const zkhip_crs_desc* key, const zkhip_r1cs_desc* cs,
   if (rc != ZKHIP_OK) return rc;
   if (key->n_vars != cs->n_vars || key->n_primary != cs->n_primary || key->n_vars < key->n_primary + 1 || key->domain_size < 1)
     return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+  // the key names the evaluation domain (zkhip.h): it must be one, and hold the system's n + l + 1 interpolation points
+  if (!zkhip_domain_is_valid(key->domain_size) || key->domain_size < cs->n_constraints + cs->n_primary + 1)
+    return fail(ZKHIP_ERR_ARG, "proving key: its evaluation domain is not a power of two or 2^k + 2^r, or too small for the constraint system");
   DeviceGuard guard;
   zkhip_multi_prover* mp = new zkhip_multi_prover();
   mp->n_vars = key->n_vars;

@@ -327,7 +327,7 @@ int zkhip_aggregator_pipeline_wait(zkhip_pipeline* p, uint64_t ticket, uint64_t*
   if (!p || !proof_affine) return ZKHIP_ERR_ARG;
   std::unique_lock<std::mutex> lk(p->mu);
   auto it = p->jobs.find(ticket);
-  if (it == p->jobs.end()) return ZKHIP_ERR_ARG;
+  if (it == p->jobs.end()) return ZKHIP_ERR_NO_TICKET;     // (not ZKHIP_ERR_ARG: that is what a batch's own failure returns)
   std::shared_ptr<Job> j = it->second;
   p->cv_done.wait(lk, [&] { return p->stop || j->done; });
   if (!j->done) return ZKHIP_ERR_STATE;

@@ -19,8 +19,8 @@ struct R1csDev {
   int spmv_log_lanes = 4;      // lanes per row of the sparse products: 2^4 (a proof alone), 2^2 (a prover that shares the chip), 2^0 (short rows)
   int spmv_log_lanes_alone = 4;   // what r1cs_upload chose for a proof alone (by the average row length)
   size_t n_constraints = 0, n_vars = 0, n_primary = 0;   // n_vars counts the constant ONE
-  // The evaluation domain (domain.hpp): d points - a power of two (small == 0, big == d), or big + small with both powers of two
-  // (libfqfft's step_radix2_domain).  log_d = ceil(log2 d).
+  // The evaluation domain (domain.hpp): d points - a power of two (small == 0, big == d; the reference's forced choice and the
+  // default), or big + small with both powers of two (libfqfft's step_radix2_domain, by option or by the key).  log_d = ceil(log2 d).
   size_t d = 0, big = 0, small = 0;
   int log_d = 0, log_big = 0, log_small = 0;
   CsrDev A, B, C;
@@ -32,7 +32,11 @@ struct R1csDev {
   uint32_t *pw_w = nullptr, *pw_winv = nullptr, *pw_g = nullptr, *pw_ginv = nullptr, *half = nullptr;
 };
 
-int r1cs_upload(const zkhip_r1cs_desc* d, R1csDev** out, char* err, size_t errlen);
+// domain_size: 0 = the reference's forced power of two for n + l + 1 points (default); (size_t)-1 = libfqfft's unforced choice
+// (ZKHIP_DOMAIN_STEP); else a valid domain size >= n + l + 1 (what a proving key was generated on) - domain.hpp
+int r1cs_upload(const zkhip_r1cs_desc* d, size_t domain_size, R1csDev** out, char* err, size_t errlen);
+// moves the handle to another domain (no-op if it is there already); nothing may be in flight on it
+int r1cs_set_domain(R1csDev* r, size_t domain_size, char* err, size_t errlen);
 void r1cs_free(R1csDev* r);
 // z: device pointer, ABI form (n_vars x 6 u64).  Leaves h (packed device form, d elements) in r->bufA.
 int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, size_t errlen);

@@ -260,8 +260,8 @@ static int csr_upload(const uint32_t* row_ptr, const uint32_t* col, const uint64
   return ZKHIP_OK;
 }
 
-static int r1cs_upload_impl(const zkhip_r1cs_desc* d, R1csDev* r, char* err, size_t errlen);
-int r1cs_upload(const zkhip_r1cs_desc* d, R1csDev** out, char* err, size_t errlen) {
+static int r1cs_upload_impl(const zkhip_r1cs_desc* d, size_t domain_size, R1csDev* r, char* err, size_t errlen);
+int r1cs_upload(const zkhip_r1cs_desc* d, size_t domain_size, R1csDev** out, char* err, size_t errlen) {
   if (!d || !out || d->n_vars < d->n_primary + 1) { snprintf(err, errlen, "r1cs_upload: bad descriptor"); return ZKHIP_ERR_ARG; }
   for (size_t k = 0; k < 3; k++) {
     const uint32_t* rp = k == 0 ? d->a_row_ptr : k == 1 ? d->b_row_ptr : d->c_row_ptr;
@@ -273,34 +273,38 @@ int r1cs_upload(const zkhip_r1cs_desc* d, R1csDev** out, char* err, size_t errle
       if (cl[j] >= d->n_vars) { snprintf(err, errlen, "r1cs_upload: column index out of range"); return ZKHIP_ERR_ARG; }
   }
   R1csDev* r = new R1csDev();
-  int rc = r1cs_upload_impl(d, r, err, errlen);
+  int rc = r1cs_upload_impl(d, domain_size, r, err, errlen);
   if (rc != ZKHIP_OK) { r1cs_free(r); return rc; }        // frees what was uploaded before the failure
   *out = r;
   return ZKHIP_OK;
 }
 
-static int r1cs_upload_impl(const zkhip_r1cs_desc* d, R1csDev* r, char* err, size_t errlen) {
+static void free_domain_buffers(R1csDev* r) {
+  void** ptrs[] = {(void**)&r->bufA, (void**)&r->bufB, (void**)&r->bufC, (void**)&r->zinv, (void**)&r->pw_w, (void**)&r->pw_winv,
+                   (void**)&r->pw_g, (void**)&r->pw_ginv, (void**)&r->half};
+  for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+// Everything of a constraint system that depends on its evaluation domain: the three work vectors, 1 / Z on the coset and, for a
+// step domain, the powers of its element-wise halves.  The matrices do not.  A handle can be moved to another domain (the proving
+// key decides: zkhip_groth16_prove with a key of another valid domain size); the caller makes sure nothing is in flight on it.
+int r1cs_set_domain(R1csDev* r, size_t domain_size, char* err, size_t errlen) {
   using host::HFr;
-  r->n_constraints = d->n_constraints; r->n_vars = d->n_vars; r->n_primary = d->n_primary;
-  // the evaluation domain libfqfft picks for n + l + 1 points: a power of two, or 2^k + 2^r (step_radix2_domain; domain.hpp)
-  const host::EvalDomain dom(host::eval_domain_size(d->n_constraints + d->n_primary + 1));
-  if (dom.m > ((size_t)1 << 22)) { snprintf(err, errlen, "r1cs_upload: domain larger than 2^22"); return ZKHIP_ERR_ARG; }
-  // lanes per row of the sparse products: sixteen for a proof alone (a wrapping circuit has rows of 47 and 253 terms and fewer rows than the
-  // chip has lanes), ONE where the rows are short (a system of two-term rows, 2^20 of them: sixteen lanes a row made 1.7 ms of folding)
-  {
-    const size_t nnz = (size_t)d->a_row_ptr[d->n_constraints] + d->b_row_ptr[d->n_constraints] + d->c_row_ptr[d->n_constraints];
-    r->spmv_log_lanes_alone = (d->n_constraints && nnz <= 9 * d->n_constraints) ? 0 : 4;
-    r->spmv_log_lanes = r->spmv_log_lanes_alone;
+  const size_t points = r->n_constraints + r->n_primary + 1;
+  const size_t want = host::resolve_domain(points, domain_size);
+  if (!want) {
+    snprintf(err, errlen, "evaluation domain of %zu points: not a power of two or 2^k + 2^r, or smaller than the system's %zu points", domain_size, points);
+    return ZKHIP_ERR_ARG;
   }
+  if (want > ((size_t)1 << 22)) { snprintf(err, errlen, "r1cs: domain larger than 2^22"); return ZKHIP_ERR_ARG; }
+  if (want == r->d && r->bufA) return ZKHIP_OK;
+  free_domain_buffers(r);
+  const host::EvalDomain dom(want);
   r->d = dom.m; r->big = dom.big; r->small = dom.small;
   r->log_d = host::ceil_log2(dom.m); r->log_big = dom.log_big; r->log_small = dom.log_small;
-  size_t dd = dom.m;
+  const size_t dd = dom.m;
   int rc;
-  if ((rc = csr_upload(d->a_row_ptr, d->a_col, d->a_val, d->n_constraints, &r->A, err, errlen)) != ZKHIP_OK) return rc;
-  if ((rc = csr_upload(d->b_row_ptr, d->b_col, d->b_val, d->n_constraints, &r->B, err, errlen)) != ZKHIP_OK) return rc;
-  if ((rc = csr_upload(d->c_row_ptr, d->c_col, d->c_val, d->n_constraints, &r->C, err, errlen)) != ZKHIP_OK) return rc;
   Q_HIP(hipMalloc(&r->bufA, dd * 48)); Q_HIP(hipMalloc(&r->bufB, dd * 48)); Q_HIP(hipMalloc(&r->bufC, dd * 48));
-  Q_HIP(hipMalloc(&r->tmp, 256)); Q_HIP(hipMalloc(&r->z, d->n_vars * 48));     // tmp: the satisfiability flag
   // 1 / Z on the coset g x, per class (see qap.h)
   const HFr g = HFr::from_limbs(FrParams::GEN64);
   const size_t classes = dom.is_step() ? dom.compr() + 1 : 1;
@@ -350,6 +354,25 @@ static int r1cs_upload_impl(const zkhip_r1cs_desc* d, R1csDev* r, char* err, siz
     Q_HIP(hipMalloc(&r->half, 14 * 4));
     Q_HIP(hipMemcpy(r->half, hd.l, 14 * 4, hipMemcpyHostToDevice));
   }
+  return ZKHIP_OK;
+}
+
+static int r1cs_upload_impl(const zkhip_r1cs_desc* d, size_t domain_size, R1csDev* r, char* err, size_t errlen) {
+  r->n_constraints = d->n_constraints; r->n_vars = d->n_vars; r->n_primary = d->n_primary;
+  // lanes per row of the sparse products: sixteen for a proof alone (a wrapping circuit has rows of 47 and 253 terms and fewer rows than the
+  // chip has lanes), ONE where the rows are short (a system of two-term rows, 2^20 of them: sixteen lanes a row made 1.7 ms of folding)
+  {
+    const size_t nnz = (size_t)d->a_row_ptr[d->n_constraints] + d->b_row_ptr[d->n_constraints] + d->c_row_ptr[d->n_constraints];
+    r->spmv_log_lanes_alone = (d->n_constraints && nnz <= 9 * d->n_constraints) ? 0 : 4;
+    r->spmv_log_lanes = r->spmv_log_lanes_alone;
+  }
+  // the evaluation domain: the reference's forced power of two unless the caller (a proving key) names another one (domain.hpp)
+  int rc;
+  if ((rc = r1cs_set_domain(r, domain_size, err, errlen)) != ZKHIP_OK) return rc;
+  if ((rc = csr_upload(d->a_row_ptr, d->a_col, d->a_val, d->n_constraints, &r->A, err, errlen)) != ZKHIP_OK) return rc;
+  if ((rc = csr_upload(d->b_row_ptr, d->b_col, d->b_val, d->n_constraints, &r->B, err, errlen)) != ZKHIP_OK) return rc;
+  if ((rc = csr_upload(d->c_row_ptr, d->c_col, d->c_val, d->n_constraints, &r->C, err, errlen)) != ZKHIP_OK) return rc;
+  Q_HIP(hipMalloc(&r->tmp, 256)); Q_HIP(hipMalloc(&r->z, d->n_vars * 48));     // tmp: the satisfiability flag
   return ZKHIP_OK;
 }
 

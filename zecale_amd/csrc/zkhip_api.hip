@@ -224,6 +224,7 @@ const char* zkhip_strerror(int code) {
     case ZKHIP_ERR_NO_DEVICE: return "no gfx950 device";
     case ZKHIP_ERR_HIP: return "HIP runtime error";
     case ZKHIP_ERR_STATE: return "library not initialised";
+    case ZKHIP_ERR_NO_TICKET: return "no such ticket";
     default: return "unknown error";
   }
 }
@@ -503,15 +504,23 @@ int zkhip_ntt(uint64_t* data, unsigned log_d, int dir, int coset) {
   return rc;
 }
 
-int zkhip_r1cs_upload(const zkhip_r1cs_desc* d, zkhip_r1cs** out) {
+int zkhip_r1cs_upload_ex(const zkhip_r1cs_desc* d, size_t domain_size, zkhip_r1cs** out) {
   BIND_CUR();
   std::lock_guard<std::mutex> lk(g.dev[cur_dev()].mu);
   if (!d || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
   R1csDev* dev = nullptr;
-  int rc = r1cs_upload(d, &dev, t_err, sizeof t_err);
+  int rc = r1cs_upload(d, domain_size, &dev, t_err, sizeof t_err);
   if (rc != ZKHIP_OK) return rc;
   *out = new zkhip_r1cs{dev, cur_dev()};
   return ZKHIP_OK;
+}
+int zkhip_r1cs_upload(const zkhip_r1cs_desc* d, zkhip_r1cs** out) { return zkhip_r1cs_upload_ex(d, 0, out); }   // the reference's forced power of two
+
+int zkhip_r1cs_set_domain(zkhip_r1cs* r, size_t domain_size) {
+  if (!r) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(r);
+  std::lock_guard<std::mutex> lk(g.dev[r->device].mu);
+  return r1cs_set_domain(r->dev, domain_size, t_err, sizeof t_err);
 }
 
 void zkhip_r1cs_free(zkhip_r1cs* r) {
@@ -523,7 +532,9 @@ void zkhip_r1cs_free(zkhip_r1cs* r) {
 
 unsigned zkhip_r1cs_log_domain(const zkhip_r1cs* r) { return r ? (unsigned)r->dev->log_d : 0; }
 size_t zkhip_r1cs_domain_size(const zkhip_r1cs* r) { return r ? r->dev->d : 0; }
-size_t zkhip_domain_size(size_t min_size) { return host::eval_domain_size(min_size); }
+size_t zkhip_domain_size(size_t min_size) { return host::forced_domain_size(min_size); }
+size_t zkhip_step_domain_size(size_t min_size) { return host::eval_domain_size(min_size); }
+int zkhip_domain_is_valid(size_t domain_size) { return host::is_valid_domain(domain_size) ? 1 : 0; }
 
 int zkhip_r1cs_is_satisfied(zkhip_r1cs* r, const uint64_t* z, int* ok) {
   if (!r || !z || !ok) return fail(ZKHIP_ERR_ARG, "null pointer");
@@ -620,6 +631,7 @@ int zkhip_crs_upload_ex(const zkhip_crs_desc* d, const zkhip_key_opts* opts, zkh
   if (!d || !out || !d->alpha_g1 || !d->beta_g1 || !d->beta_g2 || !d->delta_g1 || !d->delta_g2)
     return fail(ZKHIP_ERR_ARG, "null pointer");
   if (d->n_vars < d->n_primary + 1 || d->domain_size < 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
+  if (!host::is_valid_domain(d->domain_size)) return fail(ZKHIP_ERR_ARG, "proving key: domain_size is neither a power of two nor 2^k + 2^r");
   return crs_upload_impl(d, 0, d->n_vars, 0, d->domain_size - 1, 0, d->n_vars - d->n_primary - 1, opts, out);
 }
 int zkhip_crs_upload(const zkhip_crs_desc* d, zkhip_crs** out) { return zkhip_crs_upload_ex(d, nullptr, out); }
@@ -629,6 +641,7 @@ int zkhip_crs_upload_slice_ex(const zkhip_crs_desc* d, size_t a_lo, size_t a_len
   BIND_CUR();
   if (!d || !out || !d->alpha_g1 || !d->beta_g1 || !d->beta_g2 || !d->delta_g1 || !d->delta_g2) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (d->n_vars < d->n_primary + 1 || d->domain_size < 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
+  if (!host::is_valid_domain(d->domain_size)) return fail(ZKHIP_ERR_ARG, "proving key: domain_size is neither a power of two nor 2^k + 2^r");
   if (a_lo + a_len > d->n_vars || h_lo + h_len > d->domain_size - 1 || l_lo + l_len > d->n_vars - d->n_primary - 1)
     return fail(ZKHIP_ERR_ARG, "slice out of range");
   return crs_upload_impl(d, a_lo, a_len, h_lo, h_len, l_lo, l_len, opts, out);
@@ -670,10 +683,22 @@ int zkhip_last_prove_timings(double out_ms[8]) {
 // z: host assignment (uploaded here) - or d_z_ready: the assignment already in device memory, ABI form, complete (GPU witness)
 // the cheap argument and size checks of a proof, before anything is started for it (the tail's scalar multiplications used to
 // be spawned before them)
+// The proving key is authoritative for the evaluation domain (a reference key of the wrapping circuit says 65,536, a key generated
+// here with ZKHIP_DOMAIN_STEP says 49,152): a shared constraint-system handle that sits on another domain is moved to the key's -
+// its matrices stay, the domain's buffers are rebuilt (once: the next proof with this key finds it there).  A key whose domain is
+// too small for the system, or not a domain at all, is refused.  Caller holds the device's mutex.
+static int follow_key_domain(const zkhip_crs* crs, R1csDev* rd) {
+  if (crs->n_vars != rd->n_vars || crs->n_primary != rd->n_primary) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+  if (crs->domain_size == rd->d) return ZKHIP_OK;
+  if (crs->domain_size == 0 || crs->domain_size == (size_t)-1) return fail(ZKHIP_ERR_ARG, "proving key without a domain size");
+  return r1cs_set_domain(rd, crs->domain_size, t_err, sizeof t_err);
+}
+
 static int prove_check(const zkhip_crs* crs, const R1csDev* rd, size_t a_lo, size_t h_lo, size_t l_lo) {
   const size_t m = rd->n_vars, l = rd->n_primary, d = rd->d;
   const size_t a_len = crs->A->len, h_len = crs->H->len, l_len = crs->L->len;
-  if (crs->n_vars != m || crs->n_primary != l || crs->domain_size != d) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+  if (crs->n_vars != m || crs->n_primary != l) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+  if (crs->domain_size != d) return fail(ZKHIP_ERR_ARG, "the constraint system handle is not on the proving key's evaluation domain");
   if (crs->B2->len != a_len || crs->B1->len != a_len || a_lo + a_len > m || h_lo + h_len > d - 1 || l_lo + l_len > m - l - 1)
     return fail(ZKHIP_ERR_ARG, "key slice out of range");
   const int tc = crs->A->table_c;
@@ -803,6 +828,7 @@ int zkhip_groth16_prove_partial(const zkhip_crs* crs_slice, zkhip_r1cs* r1cs, co
   if (crs_slice->device != r1cs->device) return fail(ZKHIP_ERR_ARG, "proving key and constraint system live on different devices");
   BIND(crs_slice);
   std::lock_guard<std::mutex> lk(g.dev[crs_slice->device].mu);
+  { int rc_ = follow_key_domain(crs_slice, r1cs->dev); if (rc_ != ZKHIP_OK) return rc_; }
   return prove_partial(g.dev[crs_slice->device].ps, crs_slice, r1cs->dev, z, a_lo, h_lo, l_lo, sums_jac);
 }
 
@@ -875,6 +901,7 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
   TailPre pre;
   {
     std::lock_guard<std::mutex> lk(g.dev[crs->device].mu);
+    { int rc_ = follow_key_domain(crs, r1cs->dev); if (rc_ != ZKHIP_OK) return rc_; }
     const size_t m = r1cs->dev->n_vars, l = r1cs->dev->n_primary, d = r1cs->dev->d;
     if (crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
     { int rc_ = prove_check(crs, r1cs->dev, 0, 0, 0); if (rc_ != ZKHIP_OK) return rc_; }
@@ -906,7 +933,8 @@ static int prover_new_impl(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, bool
   R1csDev* rd = nullptr;
   {
     std::lock_guard<std::mutex> lk(g.dev[crs->device].mu);
-    int rc = r1cs_upload(cs, &rd, t_err, sizeof t_err);
+    if (crs->n_vars != cs->n_vars || crs->n_primary != cs->n_primary) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
+    int rc = r1cs_upload(cs, crs->domain_size, &rd, t_err, sizeof t_err);     // the key's domain, whichever kind (domain.hpp)
     if (rc != ZKHIP_OK) return rc;
   }
   const size_t m = rd->n_vars, l = rd->n_primary, d = rd->d;
@@ -1038,13 +1066,20 @@ int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_
 
 int zkhip_groth16_setup(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], const uint64_t alpha_m[6], const uint64_t beta_m[6],
                         const uint64_t delta_m[6], zkhip_keypair** out) {
+  return zkhip_groth16_setup_ex(cs, tau_m, alpha_m, beta_m, delta_m, 0, out);     // the reference's forced power-of-two domain
+}
+
+int zkhip_groth16_setup_ex(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], const uint64_t alpha_m[6], const uint64_t beta_m[6],
+                           const uint64_t delta_m[6], size_t domain_size, zkhip_keypair** out) {
   using namespace host;
   BIND_CUR();
   if (!cs || !tau_m || !alpha_m || !beta_m || !delta_m || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
   const size_t n = cs->n_constraints, m = cs->n_vars, l = cs->n_primary;
   if (m < l + 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
-  // the evaluation domain libfqfft picks for n + l + 1 points (domain.hpp): a power of two or 2^k + 2^r (step_radix2_domain)
-  const size_t d = eval_domain_size(n + l + 1);
+  // the evaluation domain (domain.hpp): 0 = the power of two libzeth's groth16_snark forces (the reference's keys), ZKHIP_DOMAIN_STEP =
+  // libfqfft's unforced choice (a power of two or 2^k + 2^r), else a valid size at least n + l + 1
+  const size_t d = resolve_domain(n + l + 1, domain_size);
+  if (!d) return fail(ZKHIP_ERR_ARG, "setup: the evaluation domain is not a power of two or 2^k + 2^r, or smaller than n + l + 1");
   if (d > ((size_t)1 << 22)) return fail(ZKHIP_ERR_ARG, "domain larger than 2^22");
   HFr tau = HFr::from_limbs(tau_m), alpha = HFr::from_limbs(alpha_m), beta = HFr::from_limbs(beta_m), delta = HFr::from_limbs(delta_m);
   if (delta.is_zero()) return fail(ZKHIP_ERR_ARG, "delta must be invertible");

@@ -17,7 +17,8 @@ EXPORTS = [
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_msm_submit", "zkhip_msm_collect",
     "zkhip_device_alloc", "zkhip_device_free", "zkhip_device_copy_in", "zkhip_last_accumulate_ms",
     "zkhip_prover_set_streaming", "zkhip_set_table_naf", "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
-    "zkhip_r1cs_upload", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_domain_size", "zkhip_domain_size", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
+    "zkhip_r1cs_upload", "zkhip_r1cs_upload_ex", "zkhip_r1cs_set_domain", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_domain_size",
+    "zkhip_domain_size", "zkhip_step_domain_size", "zkhip_domain_is_valid", "zkhip_groth16_setup_ex", "zkhip_dispatcher_outstanding", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
     "zkhip_crs_upload", "zkhip_crs_free", "zkhip_groth16_prove", "zkhip_last_prove_timings", "zkhip_groth16_verify",
     "zkhip_crs_upload_slice", "zkhip_groth16_prove_partial", "zkhip_groth16_finish",
     "zkhip_bls12_377_groth16_verify", "zkhip_aggregator_new", "zkhip_aggregator_free", "zkhip_aggregator_num_constraints",
@@ -113,6 +114,11 @@ def load():
     lib.zkhip_ntt.argtypes = [c_u64p, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
     lib.zkhip_ntt_dev.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
     lib.zkhip_r1cs_upload.argtypes = [ctypes.POINTER(R1csDesc), ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_r1cs_upload_ex.argtypes = [ctypes.POINTER(R1csDesc), ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_r1cs_set_domain.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    lib.zkhip_step_domain_size.argtypes = [ctypes.c_size_t]
+    lib.zkhip_step_domain_size.restype = ctypes.c_size_t
+    lib.zkhip_domain_is_valid.argtypes = [ctypes.c_size_t]
     lib.zkhip_r1cs_free.argtypes = [ctypes.c_void_p]
     lib.zkhip_r1cs_log_domain.argtypes = [ctypes.c_void_p]
     lib.zkhip_r1cs_log_domain.restype = ctypes.c_uint
@@ -429,10 +435,20 @@ def make_r1cs_desc(A, B, C, n_vars, n_primary):
     return d, keep
 
 
-class R1cs:
-    """A constraint system resident in HBM.  A, B, C: CSR triples (row_ptr u32[n+1], col u32[nnz], val u64[nnz, 6])."""
+DOMAIN_DEFAULT = 0                # ZKHIP_DOMAIN_DEFAULT: the reference's forced power of two (libzeth passes force_pow_2_domain = true)
+DOMAIN_STEP = (1 << (8 * ctypes.sizeof(ctypes.c_size_t))) - 1     # ZKHIP_DOMAIN_STEP: libfqfft's unforced choice (2^k or 2^k + 2^r)
 
-    def __init__(self, A, B, C, n_vars, n_primary):
+
+def _domain_arg(domain):
+    return ctypes.c_size_t(DOMAIN_DEFAULT if not domain else (DOMAIN_STEP if domain in ("step", -1, DOMAIN_STEP) else int(domain)))
+
+
+class R1cs:
+    """A constraint system resident in HBM.  A, B, C: CSR triples (row_ptr u32[n+1], col u32[nnz], val u64[nnz, 6]).
+    domain: None = the reference's forced power-of-two evaluation domain; "step" = libfqfft's unforced choice; an int = that many
+    points (what a proving key says).  zkhip_groth16_prove moves the handle to its key's domain by itself."""
+
+    def __init__(self, A, B, C, n_vars, n_primary, domain=None):
         self._keep = []
         d = R1csDesc()
         d.n_constraints = len(A[0]) - 1
@@ -448,11 +464,21 @@ class R1cs:
             setattr(d, name + "_val", val.ctypes.data if len(val) else None)
         self.n_vars, self.n_primary, self.n_constraints = n_vars, n_primary, d.n_constraints
         h = ctypes.c_void_p()
-        _check(load().zkhip_r1cs_upload(ctypes.byref(d), ctypes.byref(h)))
+        _check(load().zkhip_r1cs_upload_ex(ctypes.byref(d), _domain_arg(domain), ctypes.byref(h)))
         self.handle = h
         self._keep = []
-        self.log_d = int(load().zkhip_r1cs_log_domain(h))
-        self.domain_size = int(load().zkhip_r1cs_domain_size(h))     # a power of two, or 2^k + 2^r (libfqfft's step_radix2_domain)
+
+    @property
+    def log_d(self):
+        return int(load().zkhip_r1cs_log_domain(self.handle))
+
+    @property
+    def domain_size(self):
+        """Points of the handle's CURRENT domain: a power of two (default), or 2^k + 2^r (libfqfft's step_radix2_domain)."""
+        return int(load().zkhip_r1cs_domain_size(self.handle))
+
+    def set_domain(self, domain):
+        _check(load().zkhip_r1cs_set_domain(self.handle, _domain_arg(domain)))
 
     def is_satisfied(self, z):
         zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(self.n_vars, 6)
@@ -789,6 +815,12 @@ class AggregatorDispatcher:
         _check(load().zkhip_dispatcher_stats(self.handle, out))
         return list(out)
 
+    def outstanding(self):
+        """Batches each entry still owes a collector (what submit's least-loaded routing looks at)."""
+        out = (ctypes.c_size_t * self.size)()
+        _check(load().zkhip_dispatcher_outstanding(self.handle, out))
+        return list(out)
+
     def free(self):
         if self.handle:
             load().zkhip_dispatcher_free(self.handle)
@@ -828,11 +860,21 @@ class MultiProver:
 class Keypair:
     """Groth16 keypair from a trusted setup on the GPU (mirror of wsnark::generate_setup / keypair)."""
 
-    def __init__(self, r1cs_desc, tau, alpha, beta, delta):
+    def __init__(self, r1cs_desc, tau, alpha, beta, delta, domain=None):
+        """domain: None = the forced power of two the reference's generate_setup uses; "step" = libfqfft's unforced choice (an
+        option; not a reference deployment's key); an int = that many points."""
         h = ctypes.c_void_p()
         c = lambda a: _p(np.ascontiguousarray(a, dtype=np.uint64))
-        _check(load().zkhip_groth16_setup(ctypes.byref(r1cs_desc), c(tau), c(alpha), c(beta), c(delta), ctypes.byref(h)))
+        lib = load()
+        lib.zkhip_groth16_setup_ex.argtypes = [ctypes.POINTER(R1csDesc), c_u64p_t, c_u64p_t, c_u64p_t, c_u64p_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        _check(lib.zkhip_groth16_setup_ex(ctypes.byref(r1cs_desc), c(tau), c(alpha), c(beta), c(delta), _domain_arg(domain), ctypes.byref(h)))
         self.handle = h
+
+    @property
+    def domain_size(self):
+        d = CrsDesc()
+        _check(load().zkhip_keypair_crs_desc(self.handle, ctypes.byref(d)))
+        return int(d.domain_size)
 
     def write(self, path):
         """Mirror of wsnark::keypair_write_bytes (aggregator_server.cpp:88-94); the library's own container format."""
@@ -892,15 +934,13 @@ def r1cs_desc_from_aggregator(agg):
     return d
 
 
-def r1cs_from_desc(desc):
-    """Upload a constraint system described by a zkhip_r1cs_desc (e.g. the aggregator circuit's)."""
+def r1cs_from_desc(desc, domain=None):
+    """Upload a constraint system described by a zkhip_r1cs_desc (e.g. the aggregator circuit's).  domain: as R1cs."""
     r = R1cs.__new__(R1cs)
     h = ctypes.c_void_p()
-    _check(load().zkhip_r1cs_upload(ctypes.byref(desc), ctypes.byref(h)))
+    _check(load().zkhip_r1cs_upload_ex(ctypes.byref(desc), _domain_arg(domain), ctypes.byref(h)))
     r.handle, r._keep = h, []
     r.n_vars, r.n_primary, r.n_constraints = desc.n_vars, desc.n_primary, desc.n_constraints
-    r.log_d = int(load().zkhip_r1cs_log_domain(h))
-    r.domain_size = int(load().zkhip_r1cs_domain_size(h))
     return r
 
 
@@ -912,8 +952,17 @@ def aggregator_vk_hash(nested_vk, inputs_per_nested_proof=1):
 
 
 def domain_size(min_size):
-    """Points of the evaluation domain libfqfft picks for min_size points (host code)."""
+    """Points of the reference's evaluation domain for min_size points: the forced power of two (host code)."""
     return int(load().zkhip_domain_size(min_size))
+
+
+def step_domain_size(min_size):
+    """Points of the domain libfqfft picks for min_size points when not forced: 2^k, or 2^k + 2^r (host code)."""
+    return int(load().zkhip_step_domain_size(min_size))
+
+
+def domain_is_valid(d):
+    return bool(load().zkhip_domain_is_valid(d))
 
 
 def last_prove_timings():
