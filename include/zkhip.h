@@ -117,6 +117,7 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
 int zkhip_device_alloc(size_t bytes, void** out);
 int zkhip_device_free(void* p);
 int zkhip_device_copy_in(void* dst, const void* src, size_t bytes);
+int zkhip_device_copy_out(void* dst_host, const void* src_device, size_t bytes);
 
 /* Asynchronous form of zkhip_msm_dev for a stream of MSMs on resident bases: submit enqueues the MSM on one of EIGHT
  * slots (0 .. 7) and returns, collect waits for it.  d_scalars must stay valid until collect.  With several slots in flight the
@@ -354,6 +355,47 @@ void zkhip_gpu_witness_free(zkhip_gpu_witness* w);
  * [3] multiplications, [4] inversions, [5] distinct constants */
 int zkhip_gpu_witness_stats(zkhip_aggregator* a, size_t out[6]);
 
+/* ---- PER-APPLICATION CONSTANTS -----------------------------------------------------------------------------------------------
+ * The reference registers an application - a nested verification key - once (RegisterApplication, aggregator_server.cpp:170-235)
+ * and then aggregates batch after batch of ITS proofs (GenerateAggregatedTransaction, :279-348).  Everything the wrapping circuit
+ * derives from the nested key alone is the same in every one of those batches: the key's variables, the MiMC chain of its hash
+ * (verification_key_hash_gadget.tcc:36-40), the lines of -beta and -delta (aggregator_gadget.tcc:93) and the doubling chains
+ * 2^j ABC_i of the input accumulators - 9,038 of the 44,206 variables at batch 2 with one input per nested proof.  Their share of
+ * the A, B-G2, B-G1 and L sums of a proof, sum z_i Base_i over those positions, is FOUR CONSTANT POINTS per (application, proving
+ * key).  A zkhip_aggregator_app computes both once:
+ *   - the constant positions (auxiliary variables only: the constant ONE and the primary inputs - the key's hash among them - stay
+ *     ordinary entries) and their values, by recording the circuit with the key as constants (witness_tape.cpp): what the
+ *     recorder folds does not depend on the proofs;
+ *   - the four points, by one masked MSM per query over the resident key.
+ * Per batch, the generators then produce a MASKED assignment - zero at the constant positions: a zero scalar produces no bucket
+ * entry, so the five MSMs lose a sixth of their entries - the QAP map runs on (masked | constants), H is untouched, and the tail adds
+ * the four points.  The proof is the same group elements as without the handle: bit-identical (tests/test_app_cache_gpu.py).
+ * The handle belongs to ONE proving key (its GPU) and ONE circuit; crs and a must outlive it. */
+typedef struct zkhip_aggregator_app zkhip_aggregator_app;
+int zkhip_aggregator_app_new(zkhip_aggregator* a, const zkhip_crs* crs, const uint64_t* nested_vk, zkhip_aggregator_app** out);
+void zkhip_aggregator_app_free(zkhip_aggregator_app* app);
+size_t zkhip_aggregator_app_num_constants(const zkhip_aggregator_app* app);
+/* positions (num_constants, ascending), their values (x 6 limbs), the key's hash (primary input 0) and the four cached points
+ * (A, B-G2, B-G1, L: 4 x 36 limbs, Jacobian); any pointer may be null */
+int zkhip_aggregator_app_constants(const zkhip_aggregator_app* app, uint32_t* positions, uint64_t* values, uint64_t vk_hash[6], uint64_t points_jac[144]);
+/* a FULL assignment generated under the application's key -> masked in place (ZKHIP_ERR_ARG if a constant position holds another value) */
+int zkhip_aggregator_app_mask(const zkhip_aggregator_app* app, uint64_t* z);
+/* replaces: the generate_r1cs_witness calls of aggregator_circuit::prove (aggregator_circuit.tcc:136-157) for a batch of the
+ * registered application: the proof sections only (the key's hash and lines are not recomputed), masked assignment out */
+int zkhip_aggregator_witness_app(const zkhip_aggregator_app* app, const uint64_t* nested_proofs, const uint64_t* nested_inputs, uint64_t* z_out);
+/* replaces: wsnarkT::generate_proof (aggregator_circuit.tcc:168) for a masked assignment: same proof as zkhip_groth16_prove /
+ * zkhip_prover_prove[_dev] on the full one.  A host assignment that is not masked is refused (ZKHIP_ERR_ARG). */
+int zkhip_groth16_prove_app(const zkhip_crs* crs, zkhip_r1cs* r1cs, const zkhip_aggregator_app* app, const uint64_t* z_masked, const uint64_t r[6],
+                            const uint64_t s[6], uint64_t proof_affine[72]);
+int zkhip_prover_prove_app(zkhip_prover* p, const zkhip_aggregator_app* app, const uint64_t* z_masked, const uint64_t r[6], const uint64_t s[6],
+                           uint64_t proof_affine[72]);
+int zkhip_prover_prove_app_dev(zkhip_prover* p, const zkhip_aggregator_app* app, const void* d_z_masked, const uint64_t r[6], const uint64_t s[6],
+                               uint64_t proof_affine[72]);
+/* zkhip_gpu_witness_run_batched for n batches of ONE application, by the application's own device program (the key folded in: no
+ * key-hash launch, an eighth fewer multiplications): masked assignments in device memory, ready for zkhip_prover_prove_app_dev */
+int zkhip_gpu_witness_run_batched_app(zkhip_gpu_witness* w, zkhip_aggregator_app* app, size_t n, const uint64_t* const* nested_proofs,
+                                      const uint64_t* const* nested_inputs, void* d_z_out, uint64_t* primary_inputs, int* degenerate);
+
 /* Streaming form of aggregator_circuit::prove for a server that wraps batch after batch (the reference's
  * GenerateAggregatedTransaction loop, aggregator_server.cpp:300-420, handles one batch at a time on the CPU):
  * `witness_workers` host threads generate witnesses (zkhip_aggregator_witness) while `gpu_slots` prover instances
@@ -370,7 +412,15 @@ int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int
  * a host thread that waits on its batch's kernel; the assignment never leaves the device) and fall back to the host generator for a
  * degenerate batch.  Results are the same proofs. */
 #define ZKHIP_PIPELINE_GPU_WITNESS 1u
+/* ZKHIP_PIPELINE_NO_APP_CACHE - a pipeline keeps a zkhip_aggregator_app per nested key it has seen (at most 32; built by the first
+ * batch of a key or by zkhip_aggregator_pipeline_register_app) and proves that key's batches from masked assignments; this flag (or
+ * ZKHIP_NO_APP_CACHE in the environment) turns that off.  The proofs are the same either way. */
+#define ZKHIP_PIPELINE_NO_APP_CACHE 2u
 int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, unsigned flags, zkhip_pipeline** out);
+/* replaces: RegisterApplication's part in the prover (aggregator_server.cpp:170-235 stores the key; here its constants are computed,
+ * ~0.2 s, so that the application's first batch does not pay for them).  ZKHIP_ERR_ARG: a key with a point off its curve. */
+int zkhip_aggregator_pipeline_register_app(zkhip_pipeline* p, const uint64_t* nested_vk);
+size_t zkhip_aggregator_pipeline_app_hits(const zkhip_pipeline* p);     /* batches proved from an application's constants so far */
 int zkhip_aggregator_pipeline_submit(zkhip_pipeline* p, const uint64_t* nested_vk, const uint64_t* nested_proofs,
                                      const uint64_t* nested_inputs, const uint64_t r[6], const uint64_t s[6], uint64_t* ticket);
 int zkhip_aggregator_pipeline_wait(zkhip_pipeline* p, uint64_t ticket, uint64_t* primary_inputs, uint64_t proof_affine[72]);
@@ -445,6 +495,7 @@ int zkhip_dispatcher_size(const zkhip_dispatcher* d);                          /
 int zkhip_dispatcher_submit(zkhip_dispatcher* d, const uint64_t* nested_vk, const uint64_t* nested_proofs, const uint64_t* nested_inputs,
                             const uint64_t r[6], const uint64_t s[6], uint64_t* ticket);
 int zkhip_dispatcher_wait(zkhip_dispatcher* d, uint64_t ticket, uint64_t* primary_inputs, uint64_t proof_affine[72]);
+int zkhip_dispatcher_register_app(zkhip_dispatcher* d, const uint64_t* nested_vk);    /* zkhip_aggregator_pipeline_register_app on every entry */
 int zkhip_dispatcher_stats(const zkhip_dispatcher* d, size_t* submitted_per_entry);   /* batches given to each entry so far */
 int zkhip_dispatcher_outstanding(const zkhip_dispatcher* d, size_t* per_entry);        /* submitted and not yet collected, per entry */
 void zkhip_dispatcher_free(zkhip_dispatcher* d);

@@ -96,6 +96,44 @@ void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const Ne
   z[2] = packed;
 }
 
+// Proof sections only, for a batch under a REGISTERED key (zk_app_host_witness): the key's variables are allocated as always (the
+// numbering must not move), its hash and its lines are not recomputed - `vk` carries the lines - and their slices stay zero.
+void witness_proofs_only(std::vector<HFr>& z, const zkhip_aggregator* a, const NestedVk<WV>& vk, const NestedData* data) {
+  const size_t num_proofs = a->num_proofs, k = a->inputs_per_proof;
+  Builder b0;
+  current_builder() = &b0;
+  Inputs<WV> in;
+  alloc_inputs(in, num_proofs, k, data);
+  current_builder() = nullptr;
+  in.vk.neg_beta_lines = vk.neg_beta_lines;
+  in.vk.neg_delta_lines = vk.neg_delta_lines;
+  std::vector<std::vector<HFr>> parts(num_proofs);
+  std::vector<HFr> results(num_proofs);
+  std::vector<std::exception_ptr> errs(num_proofs);
+  auto run = [&](size_t p) {
+    try {
+      Builder bs;
+      bs.z.clear();
+      current_builder() = &bs;
+      results[p] = section_proof(in, p, k).value();
+      current_builder() = nullptr;
+      parts[p] = std::move(bs.z);
+    } catch (...) { errs[p] = std::current_exception(); current_builder() = nullptr; }
+  };
+  std::vector<std::thread> th;
+  for (size_t p = 1; p < num_proofs; p++) th.emplace_back(run, p);
+  run(0);
+  for (auto& t : th) t.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+  z = std::move(b0.z);
+  if (z.size() != a->sec_hash) throw std::runtime_error("assignment layout changed");
+  z.resize(a->sec_proofs, HFr::zero());                 // the hash and key sections: the application's constants, left at zero
+  for (auto& p : parts) z.insert(z.end(), p.begin(), p.end());
+  HFr packed = HFr::zero(), pow2 = HFr::one();
+  for (size_t p = 0; p < num_proofs; p++) { packed = packed + results[p] * pow2; pow2 = pow2 + pow2; }
+  z[2] = packed;
+}
+
 void to_csr(const std::vector<LC>& M, std::vector<uint32_t>& rp, std::vector<uint32_t>& col, std::vector<uint64_t>& val) {
   rp.assign(1, 0);
   for (const LC& row : M) {
@@ -119,7 +157,12 @@ int zkhip_aggregator_new(size_t num_proofs, size_t inputs_per_proof, zkhip_aggre
   a->num_proofs = num_proofs; a->inputs_per_proof = inputs_per_proof;
   Builder b;
   b.record = true;
+  static thread_local size_t marks[3];
+  static thread_local Builder* marking;
+  marking = &b;
+  b.on_section = [](int which) { if (which >= 0 && which < 3) marks[which] = marking->z.size(); };
   synthesize<CV>(b, num_proofs, inputs_per_proof, nullptr);
+  a->sec_hash = marks[0]; a->sec_key = marks[1]; a->sec_proofs = marks[2];
   a->n_vars = b.z.size();
   a->n_primary = 2 + num_proofs * inputs_per_proof;       // aggregator_circuit.tcc:172-180
   a->n_constraints = b.num_constraints();
@@ -163,6 +206,54 @@ int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, con
   }
   if (z.size() != a->n_vars) return ZKHIP_ERR_STATE;
   for (size_t i = 0; i < z.size(); i++) z[i].to_limbs(z_out + i * 6);
+  return ZKHIP_OK;
+}
+
+struct AppHost { NestedVk<WV> vk; };
+
+int zk_app_host_new(const zkhip_aggregator* a, const uint64_t* nested_vk, void** state) {
+  if (!a || !nested_vk || !state) return ZKHIP_ERR_ARG;
+  AppHost* st = new AppHost();
+  try {
+    Builder b;                                     // scratch: only the VALUES of the key's lines are kept
+    b.record = false;
+    current_builder() = &b;
+    NestedData d{nested_vk, nullptr, nullptr};
+    st->vk.alpha = g1_from<WV>(d.vk, true);
+    st->vk.beta = g2_from<WV>(d.vk + 12, true);
+    st->vk.delta = g2_from<WV>(d.vk + 36, true);
+    for (size_t i = 0; i <= a->inputs_per_proof; i++) st->vk.abc.push_back(g1_from<WV>(d.vk + 60 + i * 12, true));
+    vk_precompute(st->vk);
+    current_builder() = nullptr;
+  } catch (const std::exception&) {
+    current_builder() = nullptr;
+    delete st;
+    return ZKHIP_ERR_ARG;
+  }
+  *state = st;
+  return ZKHIP_OK;
+}
+
+void zk_app_host_free(void* state) { delete (AppHost*)state; }
+
+int zk_app_host_witness(const zkhip_aggregator* a, const void* state, const uint64_t* nested_vk, const uint64_t* nested_proofs,
+                        const uint64_t* nested_inputs, const uint32_t* s_idx, size_t n_s, const uint64_t vk_hash[6], uint64_t* z_out) {
+  if (!a || !state || !nested_vk || !nested_proofs || !nested_inputs || !vk_hash || !z_out || (n_s && !s_idx)) return ZKHIP_ERR_ARG;
+  std::vector<HFr> z;
+  NestedData d{nested_vk, nested_proofs, nested_inputs};
+  try {
+    witness_proofs_only(z, a, ((const AppHost*)state)->vk, &d);
+  } catch (const std::exception&) {
+    current_builder() = nullptr;
+    return ZKHIP_ERR_ARG;
+  }
+  if (z.size() != a->n_vars) return ZKHIP_ERR_STATE;
+  for (size_t i = 0; i < z.size(); i++) z[i].to_limbs(z_out + i * 6);
+  memcpy(z_out + 6, vk_hash, 48);                              // primary input 0 (not a masked position: the caller gets it back)
+  for (size_t j = 0; j < n_s; j++) {
+    if (s_idx[j] <= a->n_primary || s_idx[j] >= a->n_vars) return ZKHIP_ERR_ARG;
+    memset(z_out + (size_t)s_idx[j] * 6, 0, 48);
+  }
   return ZKHIP_OK;
 }
 

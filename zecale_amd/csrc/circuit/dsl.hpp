@@ -72,7 +72,7 @@ struct Builder {
   std::vector<HFr> z;       // full assignment, z[0] = 1
   std::vector<LC> A, B, C;  // constraints (recorded when `record`)
   bool record = true;
-  void (*on_section)(int) = nullptr;      // told where the key-hash section begins (0) and ends (1): the recording build splits its program there
+  void (*on_section)(int) = nullptr;      // told where the key-hash section begins (0) and ends (1) - the recording build splits its program there - and where the key's lines end (2)
   Builder() { z.push_back(HFr::one()); }
   uint32_t alloc(const HFr& value) { z.push_back(value); return (uint32_t)(z.size() - 1); }
   void enforce(LC a, LC b, LC c) {

@@ -110,6 +110,7 @@ void synthesize(Builder& b, size_t num_proofs, size_t k, const NestedData* data)
   if (b.on_section) b.on_section(1);
   b.z[1] = h.value();
   vk_precompute(in.vk);
+  if (b.on_section) b.on_section(2);
   V packed_lc;
   HFr pow2 = HFr::one();
   for (size_t p = 0; p < num_proofs; p++) {

@@ -126,6 +126,15 @@ int zkhip_dispatcher_wait(zkhip_dispatcher* d, uint64_t ticket, uint64_t* primar
   return rc;
 }
 
+int zkhip_dispatcher_register_app(zkhip_dispatcher* d, const uint64_t* nested_vk) {
+  if (!d || !nested_vk) return fail(ZKHIP_ERR_ARG, "null pointer");
+  for (zkhip_pipeline* p : d->pipes) {
+    const int rc = zkhip_aggregator_pipeline_register_app(p, nested_vk);
+    if (rc != ZKHIP_OK) return rc;
+  }
+  return ZKHIP_OK;
+}
+
 // batches each entry of the device list has been given so far (n = zkhip_dispatcher_size values)
 int zkhip_dispatcher_stats(const zkhip_dispatcher* d, size_t* submitted_per_entry) {
   if (!d || !submitted_per_entry) return fail(ZKHIP_ERR_ARG, "null pointer");

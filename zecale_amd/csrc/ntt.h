@@ -16,5 +16,6 @@ int ntt_dev_packed_batch(uint32_t* const* d_bufs, int nbuf, int log_d, int inver
 int ntt_layout_logk(int log_d);
 int ntt_dev_abi(uint64_t* d_data, int log_d, int inverse, int coset, char* err, size_t errlen);
 void fr_abi_to_dev(const uint64_t* d_in, uint32_t* d_out, size_t n, hipStream_t st);
+void fr_abi_to_dev_merge(const uint64_t* d_in, const uint64_t* d_in2, uint32_t* d_out, size_t n, hipStream_t st);   // limb-wise OR of two disjoint parts
 void fr_dev_to_abi(const uint32_t* d_in, uint64_t* d_out, size_t n, hipStream_t st);
 }  // namespace zkhip

@@ -73,6 +73,16 @@ __global__ void __launch_bounds__(256) k_fr_abi_to_dev(const uint64_t* __restric
   for (int k = 0; k < 6; k++) x[k] = in[i * 6 + k];
   fr_store12(out + i * 12, fp_from_abi<FrParams>(x));
 }
+// the same for an assignment in two parts (per-application constants: zkhip_aggregator_app): `in` holds zeros where `in2` holds the
+// application's constants and the other way round, so the whole assignment is their limb-wise OR
+__global__ void __launch_bounds__(256) k_fr_abi_to_dev_merge(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t x[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) x[k] = in[i * 6 + k] | in2[i * 6 + k];
+  fr_store12(out + i * 12, fp_from_abi<FrParams>(x));
+}
 // (log_k != 0: `in` is in transposed order, element i at (i mod 2^log_k) * 2^log_n2 + (i >> log_k))
 __global__ void __launch_bounds__(256) k_fr_dev_to_abi(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, size_t n, int log_k, int log_n2) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -467,6 +477,9 @@ int ntt_dev_packed_batch(uint32_t* const* d_bufs, int nbuf, int log_d, int inver
 
 void fr_abi_to_dev(const uint64_t* d_in, uint32_t* d_out, size_t n, hipStream_t st) {
   if (n) hipLaunchKernelGGL(k_fr_abi_to_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, d_out, n);
+}
+void fr_abi_to_dev_merge(const uint64_t* d_in, const uint64_t* d_in2, uint32_t* d_out, size_t n, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_fr_abi_to_dev_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, d_in2, d_out, n);
 }
 void fr_dev_to_abi(const uint32_t* d_in, uint64_t* d_out, size_t n, hipStream_t st) {
   if (n) hipLaunchKernelGGL(k_fr_dev_to_abi, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, d_out, n, 0, 0);

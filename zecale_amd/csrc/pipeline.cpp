@@ -29,7 +29,15 @@
 #include "../../include/zkhip.h"
 
 namespace {
+// One registered application of the pipeline (zkhip_aggregator_app: the constants of its nested key on this pipeline's proving key).
+// Built by the first worker that meets the key (or by zkhip_aggregator_pipeline_register_app); batches that arrive while it is being
+// built take the plain path.
+struct AppEntry {
+  zkhip_aggregator_app* app = nullptr;
+  int state = 0;                  // 0: being built, 1: ready, 2: could not be built (its batches take the plain path and report their own errors)
+};
 struct Job {
+  std::shared_ptr<AppEntry> app;  // set: the assignment is MASKED and the proof goes through zkhip_prover_prove_app[_dev]
   uint64_t id = 0;
   std::vector<uint64_t> vk, proofs, inputs, z;
   void* d_z = nullptr;            // GPU witness: the assignment in device memory (z then holds the primary inputs only)
@@ -43,6 +51,11 @@ struct Job {
 struct zkhip_pipeline {
   std::atomic<uint64_t> st_wit_ns{0}, st_wit_n{0}, st_slot_wait_ns{0}, st_prove_ns{0}, st_prove_n{0};   // ZKHIP_PIPELINE_STATS: printed when the pipeline is freed
   zkhip_aggregator* agg = nullptr;
+  const zkhip_crs* crs = nullptr;
+  bool app_cache = true;                         // per-application constants (off: ZKHIP_PIPELINE_NO_APP_CACHE)
+  std::mutex mu_apps;
+  std::map<std::vector<uint64_t>, std::shared_ptr<AppEntry>> apps;      // by nested key
+  std::atomic<uint64_t> st_app_hits{0};
   size_t n_vars = 0, n_primary = 0, vk_words = 0, proofs_words = 0, inputs_words = 0;
   std::vector<zkhip_prover*> provers;
   std::vector<std::thread> threads;
@@ -82,6 +95,43 @@ void lower_priority() {
   if (nice_by) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nice_by);
 }
 
+constexpr size_t MAX_APPS = 32;          // per pipeline: each holds ~15 MB on the host and ~13 MB on the device
+
+// The application of a batch's nested key, built on first sight.  Null: no cache, the table is full, the handle is still being
+// built by another thread, or it could not be built - the batch then takes the plain path.
+std::shared_ptr<AppEntry> find_app(zkhip_pipeline* p, const std::vector<uint64_t>& vk, bool wait_for_build = false) {
+  if (!p->app_cache) return nullptr;
+  std::shared_ptr<AppEntry> e;
+  {
+    std::lock_guard<std::mutex> lk(p->mu_apps);
+    auto it = p->apps.find(vk);
+    if (it != p->apps.end()) {
+      if (it->second->state == 1) return it->second;
+      if (!wait_for_build || it->second->state == 2) return nullptr;
+      e = it->second;
+    } else {
+      if (p->apps.size() >= MAX_APPS) return nullptr;
+      e = std::make_shared<AppEntry>();
+      p->apps[vk] = e;
+      wait_for_build = false;
+    }
+  }
+  if (wait_for_build) {                         // (registration of a key a worker is already building: poll, it takes ~0.2 s)
+    for (int i = 0; i < 2000; i++) {
+      { std::lock_guard<std::mutex> lk(p->mu_apps); if (e->state) break; }
+      usleep(1000);
+    }
+    std::lock_guard<std::mutex> lk(p->mu_apps);
+    return e->state == 1 ? e : nullptr;
+  }
+  zkhip_aggregator_app* app = nullptr;
+  const int rc = (zkhip_set_device(p->device) == ZKHIP_OK) ? zkhip_aggregator_app_new(p->agg, p->crs, vk.data(), &app) : ZKHIP_ERR_STATE;
+  std::lock_guard<std::mutex> lk(p->mu_apps);
+  e->app = app;
+  e->state = rc == ZKHIP_OK ? 1 : 2;
+  return rc == ZKHIP_OK ? e : nullptr;
+}
+
 void witness_loop(zkhip_pipeline* p) {
   pthread_setname_np(pthread_self(), "zk-witness");
   lower_priority();
@@ -99,8 +149,12 @@ void witness_loop(zkhip_pipeline* p) {
     if (rc == ZKHIP_OK && !wf) rc = ZKHIP_ERR_ARG;
     if (rc == ZKHIP_OK) {
       j->z.resize(p->n_vars * 6);
+      j->app = find_app(p, j->vk);
       const auto t0 = std::chrono::steady_clock::now();
-      rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
+      // a registered application: the proof sections only, MASKED assignment (the key's hash, lines and doubling chains are its constants)
+      rc = j->app ? zkhip_aggregator_witness_app(j->app->app, j->proofs.data(), j->inputs.data(), j->z.data())
+                  : zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
+      if (j->app) p->st_app_hits++;
       p->st_wit_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
       p->st_wit_n++;
     }
@@ -133,10 +187,19 @@ void gpu_witness_loop(zkhip_pipeline* p) {
       if (p->stop) break;
       p->cv_buf.wait(lk, [&] { return p->stop || !p->slab_free.empty(); });
       if (p->stop) break;
-      while (!p->q_wit.empty() && jobs.size() < p->wit_batch) { jobs.push_back(p->q_wit.front()); p->q_wit.pop_front(); }
+      // one launch = batches of ONE nested key (an application's program has its key folded in): the oldest batch decides, the
+      // others of its key follow from anywhere in the queue, the rest wait for the next launch
+      if (!p->q_wit.empty()) {
+        const std::vector<uint64_t> key = p->q_wit.front()->vk;
+        for (auto it = p->q_wit.begin(); it != p->q_wit.end() && jobs.size() < p->wit_batch;) {
+          if (!p->app_cache || (*it)->vk == key) { jobs.push_back(*it); it = p->q_wit.erase(it); }
+          else ++it;
+        }
+      }
       if (jobs.empty()) continue;                     // another batcher took them while this one waited for a slab
       slab = p->slab_free.back(); p->slab_free.pop_back();
     }
+    std::shared_ptr<AppEntry> app = find_app(p, jobs[0]->vk);
     for (auto& j : jobs) {
       int wf = 0;
       int rc = zkhip_aggregator_check_inputs(p->agg, j->vk.data(), j->proofs.data(), &wf);
@@ -148,7 +211,9 @@ void gpu_witness_loop(zkhip_pipeline* p) {
     if (!good.empty()) {
       vks.clear(); prs.clear(); ins.clear();
       for (auto& j : good) { vks.push_back(j->vk.data()); prs.push_back(j->proofs.data()); ins.push_back(j->inputs.data()); }
-      rc = zkhip_gpu_witness_run_batched(gw, good.size(), vks.data(), prs.data(), ins.data(), p->slabs[slab].base, prim.data(), deg.data());
+      rc = app ? zkhip_gpu_witness_run_batched_app(gw, app->app, good.size(), prs.data(), ins.data(), p->slabs[slab].base, prim.data(), deg.data())
+               : zkhip_gpu_witness_run_batched(gw, good.size(), vks.data(), prs.data(), ins.data(), p->slabs[slab].base, prim.data(), deg.data());
+      if (app) p->st_app_hits += good.size();
     }
     int on_device = 0;
     for (size_t i = 0; i < good.size(); i++) {
@@ -157,6 +222,7 @@ void gpu_witness_loop(zkhip_pipeline* p) {
         j->z.assign(prim.begin() + i * p->n_primary * 6, prim.begin() + (i + 1) * p->n_primary * 6);
         j->d_z = (char*)p->slabs[slab].base + i * p->n_vars * 48;
         j->slab = slab;
+        j->app = app;
         on_device++;
       }
     }
@@ -186,6 +252,7 @@ void host_fallback_loop(zkhip_pipeline* p) {
       p->q_host.pop_front();
     }
     j->z.resize(p->n_vars * 6);
+    j->app = nullptr;                                  // (the full assignment, the plain proof)
     const int rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
     std::lock_guard<std::mutex> lk(p->mu);
     if (rc != ZKHIP_OK) finish_failed(p, j, rc);
@@ -206,7 +273,9 @@ void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
       p->q_gpu.pop_front();
     }
     const auto t1 = std::chrono::steady_clock::now();
-    int rc = j->d_z ? zkhip_prover_prove_dev(pr, j->d_z, j->r, j->s, j->proof) : zkhip_prover_prove(pr, j->z.data(), j->r, j->s, j->proof);
+    int rc;
+    if (j->app) rc = j->d_z ? zkhip_prover_prove_app_dev(pr, j->app->app, j->d_z, j->r, j->s, j->proof) : zkhip_prover_prove_app(pr, j->app->app, j->z.data(), j->r, j->s, j->proof);
+    else rc = j->d_z ? zkhip_prover_prove_dev(pr, j->d_z, j->r, j->s, j->proof) : zkhip_prover_prove(pr, j->z.data(), j->r, j->s, j->proof);
     p->st_slot_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
     p->st_prove_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
     p->st_prove_n++;
@@ -239,7 +308,8 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
   int rc = zkhip_aggregator_get_r1cs(a, &desc);
   if (rc != ZKHIP_OK) return rc;
   zkhip_pipeline* p = new zkhip_pipeline();
-  p->agg = a;
+  p->agg = a; p->crs = crs;
+  p->app_cache = (flags & ZKHIP_PIPELINE_NO_APP_CACHE) == 0 && !getenv("ZKHIP_NO_APP_CACHE");
   p->n_vars = desc.n_vars; p->n_primary = desc.n_primary;
   const size_t np = zkhip_aggregator_num_proofs(a), k = zkhip_aggregator_inputs_per_proof(a);
   p->vk_words = 60 + 12 * (k + 1); p->proofs_words = 48 * np; p->inputs_words = 6 * k * np;
@@ -295,13 +365,24 @@ void zkhip_aggregator_pipeline_free(zkhip_pipeline* p) {
   p->cv_wit.notify_all(); p->cv_gpu.notify_all(); p->cv_done.notify_all(); p->cv_room.notify_all(); p->cv_buf.notify_all(); p->cv_host.notify_all();
   for (auto& t : p->threads) t.join();
   if (getenv("ZKHIP_PIPELINE_STATS") && p->st_prove_n)
-    fprintf(stderr, "zkhip pipeline: %llu proofs, %.2f ms in a prover each, provers waited %.2f ms per proof for an assignment; %llu host witnesses of %.2f ms\n",
+    fprintf(stderr, "zkhip pipeline: %llu proofs, %.2f ms in a prover each, provers waited %.2f ms per proof for an assignment; %llu host witnesses of %.2f ms; "
+                    "%llu batches used an application's constants (%zu applications)\n",
             (unsigned long long)p->st_prove_n.load(), p->st_prove_ns / 1e6 / p->st_prove_n, p->st_slot_wait_ns / 1e6 / p->st_prove_n,
-            (unsigned long long)p->st_wit_n.load(), p->st_wit_n ? p->st_wit_ns / 1e6 / p->st_wit_n : 0.0);
+            (unsigned long long)p->st_wit_n.load(), p->st_wit_n ? p->st_wit_ns / 1e6 / p->st_wit_n : 0.0, (unsigned long long)p->st_app_hits.load(), p->apps.size());
   for (zkhip_prover* q : p->provers) zkhip_prover_free(q);
+  for (auto& kv : p->apps) zkhip_aggregator_app_free(kv.second->app);
   for (auto& q : p->slabs) zkhip_device_free(q.base);
   delete p;
 }
+
+// RegisterApplication (aggregator_server.cpp:170-235): the application's constants are computed NOW instead of by the first batch
+int zkhip_aggregator_pipeline_register_app(zkhip_pipeline* p, const uint64_t* nested_vk) {
+  if (!p || !nested_vk) return ZKHIP_ERR_ARG;
+  if (!p->app_cache) return ZKHIP_OK;
+  std::vector<uint64_t> vk(nested_vk, nested_vk + p->vk_words);
+  return find_app(p, vk, true) ? ZKHIP_OK : ZKHIP_ERR_ARG;
+}
+size_t zkhip_aggregator_pipeline_app_hits(const zkhip_pipeline* p) { return p ? (size_t)p->st_app_hits.load() : 0; }
 
 int zkhip_aggregator_pipeline_submit(zkhip_pipeline* p, const uint64_t* nested_vk, const uint64_t* nested_proofs, const uint64_t* nested_inputs,
                                      const uint64_t r[6], const uint64_t s[6], uint64_t* ticket) {

@@ -39,7 +39,9 @@ int r1cs_upload(const zkhip_r1cs_desc* d, size_t domain_size, R1csDev** out, cha
 int r1cs_set_domain(R1csDev* r, size_t domain_size, char* err, size_t errlen);
 void r1cs_free(R1csDev* r);
 // z: device pointer, ABI form (n_vars x 6 u64).  Leaves h (packed device form, d elements) in r->bufA.
-int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, size_t errlen);
+// d_z_app != null: d_z_abi is MASKED (zeros at an application's constant positions) and d_z_app (n_vars x 6, zeros everywhere else)
+// holds those constants: the map runs on their union
+int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, size_t errlen, const uint64_t* d_z_app = nullptr);
 // satisfiability check <A_i,z><B_i,z> = <C_i,z> for all i (reference: _pb.is_satisfied(), aggregator_circuit.tcc:159-164)
 int r1cs_is_satisfied_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, int* ok, char* err, size_t errlen);
 

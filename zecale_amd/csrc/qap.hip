@@ -418,10 +418,11 @@ static int step_ntts(R1csDev* r, uint32_t* const* bufs, int nbuf, int inverse, i
   return ntt_dev_packed_batch(small_bufs, nbuf, r->log_small, inverse, 0, in_transposed, st, err, errlen);
 }
 
-int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, size_t errlen) {
+int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, size_t errlen, const uint64_t* d_z_app) {
   const int lg = r->log_d;
   const uint32_t d = (uint32_t)r->d;
-  fr_abi_to_dev(d_z_abi, r->z, r->n_vars, st);
+  if (d_z_app) fr_abi_to_dev_merge(d_z_abi, d_z_app, r->z, r->n_vars, st);       // masked assignment | the application's constants
+  else fr_abi_to_dev(d_z_abi, r->z, r->n_vars, st);
   spmv3(r, st);
   int rc;
   uint32_t* bufs[3] = {r->bufA, r->bufB, r->bufC};

@@ -20,6 +20,14 @@ struct WitnessProg {
   const uint32_t* subk;            // WT_SUBK_LEVELS value slots: 2^k r in subtraction-safe limbs
   uint32_t mu;                     // floor(2^390 / r) or one less (w_reduce)
 };
+// a program's device copy (seven buffers) and the argument block the kernels take
+struct WitnessProgDev {
+  WitnessProg prog;
+  void* bufs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+// uploads a recorded program to the calling thread's current device / frees it (the device must be current)
+int witness_prog_upload(const WitnessTape& T, WitnessProgDev* out, char* err, size_t errlen);
+void witness_prog_free(WitnessProgDev* pd);
 // the program of `a` on the calling thread's current device (recorded and uploaded on first use)
 int witness_prog(zkhip_aggregator* a, WitnessProg* out, const WitnessTape** tape, char* err, size_t errlen);
 // one workgroup per batch; inputs: batches x n_inputs x 6 u64 (ABI form: nested key | proofs | inputs); values: batches x n_pos x 16 u32 (witness_value_bytes);

@@ -265,25 +265,79 @@ __global__ void __launch_bounds__(256) k_witness_out(WitnessProg P, const uint32
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-struct ProgDev {
-  WitnessProg prog;
-  void* bufs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-};
 struct GpuWitnessState {
   WitnessTape tape;
   bool built = false;
-  std::map<int, ProgDev> dev;        // per device
+  std::map<int, WitnessProgDev> dev;        // per device
 };
+
+void witness_prog_free(WitnessProgDev* pd) {
+  for (void*& p : pd->bufs) if (p) { (void)hipFree(p); p = nullptr; }
+}
 
 static void gpu_release(zkhip_aggregator* a) {
   GpuWitnessState* st = (GpuWitnessState*)a->gpu_state;
   if (!st) return;
   for (auto& kv : st->dev) {
     if (hipSetDevice(kv.first) != hipSuccess) continue;
-    for (void* p : kv.second.bufs) if (p) (void)hipFree(p);
+    witness_prog_free(&kv.second);
   }
   delete st;
   a->gpu_state = nullptr;
+}
+
+// a recorded program on the calling thread's current device
+int witness_prog_upload(const WitnessTape& T, WitnessProgDev* out, char* err, size_t errlen) {
+  WitnessProgDev pd;
+  const size_t n = T.code.size(), nc = T.consts.size() / 6;
+  uint64_t* d_c64 = nullptr;
+  hipError_t e = hipSuccess;
+  auto up = [&](int slot, const void* src, size_t bytes) {
+    if (e != hipSuccess) return;
+    e = hipMalloc(&pd.bufs[slot], bytes ? bytes : 4);
+    if (e == hipSuccess && bytes) e = hipMemcpy(pd.bufs[slot], src, bytes, hipMemcpyHostToDevice);
+  };
+  up(0, T.code.data(), n); up(1, T.a.data(), n * 4); up(2, T.b.data(), n * 4);
+  up(3, T.level_start.data(), T.level_start.size() * 4); up(4, T.out_ref.data(), T.out_ref.size() * 4);
+  if (e == hipSuccess) e = hipMalloc(&pd.bufs[5], nc * 64 + 64);
+  // K r (K = 2^k, k < WT_SUBK_LEVELS) in subtraction-safe limbs: every limb but the top raised by 2^29 at its upper neighbour's expense
+  uint32_t subk[WT_SUBK_LEVELS][16];
+  memset(subk, 0, sizeof subk);
+  for (int k = 0; k < WT_SUBK_LEVELS; k++) {
+    uint64_t c = 0;
+    for (int i = 0; i < 14; i++) {
+      c += (uint64_t)FrParams::P[i] << k;
+      subk[k][i] = (i < 13) ? (uint32_t)(c & M29) : (uint32_t)c;
+      c >>= 29;
+    }
+    for (int i = 0; i < 13; i++) { subk[k][i] += 1u << 29; subk[k][i + 1] -= 1u; }
+  }
+  up(6, subk, sizeof subk);
+  // mu <= floor(2^390 / r), from the top 64 bits of r (bits 313 .. 376)
+  uint32_t mu = 0;
+  {
+    unsigned __int128 top = 0;                 // r >> 290 (limbs 10 .. 13), then >> 23
+    for (int i = 13; i >= 10; i--) top = (top << 29) | FrParams::P[i];
+    const uint64_t p_hi = (uint64_t)(top >> 23);
+    mu = (uint32_t)((((unsigned __int128)1) << 77) / ((unsigned __int128)p_hi + 1));
+  }
+  if (e == hipSuccess) e = hipMalloc(&d_c64, nc * 48 + 48);
+  if (e == hipSuccess) e = hipMemcpy(d_c64, T.consts.data(), nc * 48, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_witness_consts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, 0, d_c64, (uint32_t*)pd.bufs[5], (uint32_t)nc);
+    e = hipDeviceSynchronize();
+  }
+  if (d_c64) (void)hipFree(d_c64);
+  if (e != hipSuccess) {
+    witness_prog_free(&pd);
+    snprintf(err, errlen, "witness program upload: %s", hipGetErrorString(e));
+    return ZKHIP_ERR_HIP;
+  }
+  pd.prog = WitnessProg{(const uint8_t*)pd.bufs[0], (const int32_t*)pd.bufs[1], (const int32_t*)pd.bufs[2], (const uint32_t*)pd.bufs[3],
+                        (const int32_t*)pd.bufs[4], (const uint32_t*)pd.bufs[5], (uint32_t)(T.level_start.size() - 1), (uint32_t)n,
+                        (uint32_t)T.n_vars, (uint32_t)T.n_inputs, T.chain_start, (const uint32_t*)pd.bufs[6], mu};
+  *out = pd;
+  return ZKHIP_OK;
 }
 
 // the program of `a` on the calling thread's current device (built and uploaded on first use)
@@ -301,55 +355,9 @@ int witness_prog(zkhip_aggregator* a, WitnessProg* out, const WitnessTape** tape
   if (hipGetDevice(&device) != hipSuccess) { snprintf(err, errlen, "hipGetDevice failed"); return ZKHIP_ERR_HIP; }
   auto it = st->dev.find(device);
   if (it == st->dev.end()) {
-    const WitnessTape& T = st->tape;
-    ProgDev pd;
-    const size_t n = T.code.size(), nc = T.consts.size() / 6;
-    uint64_t* d_c64 = nullptr;
-    hipError_t e = hipSuccess;
-    auto up = [&](int slot, const void* src, size_t bytes) {
-      if (e != hipSuccess) return;
-      e = hipMalloc(&pd.bufs[slot], bytes ? bytes : 4);
-      if (e == hipSuccess && bytes) e = hipMemcpy(pd.bufs[slot], src, bytes, hipMemcpyHostToDevice);
-    };
-    up(0, T.code.data(), n); up(1, T.a.data(), n * 4); up(2, T.b.data(), n * 4);
-    up(3, T.level_start.data(), T.level_start.size() * 4); up(4, T.out_ref.data(), T.out_ref.size() * 4);
-    if (e == hipSuccess) e = hipMalloc(&pd.bufs[5], nc * 64 + 64);
-    // K r (K = 2^k, k < WT_SUBK_LEVELS) in subtraction-safe limbs: every limb but the top raised by 2^29 at its upper neighbour's expense
-    uint32_t subk[WT_SUBK_LEVELS][16];
-    memset(subk, 0, sizeof subk);
-    for (int k = 0; k < WT_SUBK_LEVELS; k++) {
-      uint64_t c = 0;
-      for (int i = 0; i < 14; i++) {
-        c += (uint64_t)FrParams::P[i] << k;
-        subk[k][i] = (i < 13) ? (uint32_t)(c & M29) : (uint32_t)c;
-        c >>= 29;
-      }
-      for (int i = 0; i < 13; i++) { subk[k][i] += 1u << 29; subk[k][i + 1] -= 1u; }
-    }
-    up(6, subk, sizeof subk);
-    // mu <= floor(2^390 / r), from the top 64 bits of r (bits 313 .. 376)
-    uint32_t mu = 0;
-    {
-      unsigned __int128 top = 0;                 // r >> 290 (limbs 10 .. 13), then >> 23
-      for (int i = 13; i >= 10; i--) top = (top << 29) | FrParams::P[i];
-      const uint64_t p_hi = (uint64_t)(top >> 23);
-      mu = (uint32_t)((((unsigned __int128)1) << 77) / ((unsigned __int128)p_hi + 1));
-    }
-    if (e == hipSuccess) e = hipMalloc(&d_c64, nc * 48 + 48);
-    if (e == hipSuccess) e = hipMemcpy(d_c64, T.consts.data(), nc * 48, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_witness_consts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, 0, d_c64, (uint32_t*)pd.bufs[5], (uint32_t)nc);
-      e = hipDeviceSynchronize();
-    }
-    if (d_c64) (void)hipFree(d_c64);
-    if (e != hipSuccess) {
-      for (void* p : pd.bufs) if (p) (void)hipFree(p);
-      snprintf(err, errlen, "witness program upload: %s", hipGetErrorString(e));
-      return ZKHIP_ERR_HIP;
-    }
-    pd.prog = WitnessProg{(const uint8_t*)pd.bufs[0], (const int32_t*)pd.bufs[1], (const int32_t*)pd.bufs[2], (const uint32_t*)pd.bufs[3],
-                          (const int32_t*)pd.bufs[4], (const uint32_t*)pd.bufs[5], (uint32_t)(T.level_start.size() - 1), (uint32_t)n,
-                          (uint32_t)T.n_vars, (uint32_t)T.n_inputs, T.chain_start, (const uint32_t*)pd.bufs[6], mu};
+    WitnessProgDev pd;
+    int rc = witness_prog_upload(st->tape, &pd, err, errlen);
+    if (rc != ZKHIP_OK) return rc;
     it = st->dev.emplace(device, pd).first;
   }
   *out = it->second.prog;

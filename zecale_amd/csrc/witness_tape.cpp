@@ -38,7 +38,7 @@ struct Recorder {
   std::vector<Op> ops;                           // instruction i defines value i
   std::vector<HV> consts;
   std::map<std::string, int32_t> const_index;
-  const uint64_t *arena_lo = nullptr, *arena_hi = nullptr;
+  const uint64_t *arena_base = nullptr, *arena_lo = nullptr, *arena_hi = nullptr;   // inputs live at arena_base; [arena_lo, arena_hi) of them are VARIABLES
   int32_t intern(const HV& c) {
     std::string k((const char*)c.v, sizeof c.v);
     auto it = const_index.find(k);
@@ -50,8 +50,8 @@ struct Recorder {
   }
 };
 static thread_local Recorder* g_rec = nullptr;
-static thread_local size_t g_mark[2] = {0, 0};       // the key-hash section: instructions [g_mark[0], g_mark[1])
-static void on_section(int which) { g_mark[which] = g_rec->ops.size(); }
+static thread_local size_t g_mark[3] = {0, 0, 0};    // the key-hash section: instructions [g_mark[0], g_mark[1]); [2]: end of the key's lines
+static void on_section(int which) { if (which >= 0 && which < 3) g_mark[which] = g_rec->ops.size(); }
 
 // The recording scalar.  id < 0: a constant (its value in `val`); id >= 0: the value defined by instruction id.
 struct RecFr {
@@ -72,7 +72,7 @@ struct RecFr {
   static RecFr one() { return RecFr(HV::one()); }
   static RecFr from_u64(uint64_t x) { return RecFr(HV::from_u64(x)); }
   static RecFr from_limbs(const uint64_t* p) {
-    if (g_rec && p >= g_rec->arena_lo && p < g_rec->arena_hi) return emit(WT_INPUT, (int32_t)((p - g_rec->arena_lo) / 6), 0);
+    if (g_rec && p >= g_rec->arena_lo && p < g_rec->arena_hi) return emit(WT_INPUT, (int32_t)((p - g_rec->arena_base) / 6), 0);
     return RecFr(HV::from_limbs(p));
   }
   void to_limbs(uint64_t* p) const { need_const("to_limbs"); val.to_limbs(p); }
@@ -104,7 +104,12 @@ struct RecFr {
   RecFr neg() const { return zero() - *this; }
   RecFr dbl() const { return *this + *this; }
   RecFr sqr() const { return *this * *this; }
-  RecFr inv() const { return is_const() ? RecFr(val.inv()) : emit(WT_INV, ref(), 0); }
+  RecFr inv() const {
+    // (a constant that must not be zero IS zero: only possible with an application's key folded in - a degenerate key, where the
+    //  host generator branches; the application then gets no program of its own and its batches take the generic one)
+    if (is_const() && val.is_zero()) throw std::runtime_error("inversion of a constant zero (degenerate nested key)");
+    return is_const() ? RecFr(val.inv()) : emit(WT_INV, ref(), 0);
+  }
   RecFr pow_limbs(const uint64_t* e, int nlimbs) const {
     RecFr acc = one();
     for (int i = nlimbs * 64 - 1; i >= 0; i--) {
@@ -129,7 +134,12 @@ inline RecFr fr_inv0(const RecFr& v) { return v.is_const() ? RecFr(v.val.is_zero
 
 namespace zkhip {
 
-int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* out, std::string* err) {
+// fixed_vk != null: the program of ONE APPLICATION (a registered nested verification key: aggregator_server.cpp:170-235).  The key's
+// 60 + 12 (k + 1) words are CONSTANTS of the recording: every operation that depends on the key only - the key's variables, its
+// MiMC hash chain, the lines of -beta and -delta, the doubling chains 2^j ABC_i inside the proof sections - is folded by the
+// recorder, the assignment entries it defines come out as constants (out_ref < 0) and the key-hash chain is empty.  The input block
+// keeps its layout (key | proofs | inputs), the key's part is simply never read.
+int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* out, std::string* err, const uint64_t* fixed_vk) {
   using namespace circuit_rec;
   using rec::Recorder;
   using rec::RecFr;
@@ -138,7 +148,8 @@ int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* 
     const size_t vk_w = 60 + 12 * (k + 1), pr_w = 48 * num_proofs, in_w = 6 * k * num_proofs;
     std::vector<uint64_t> arena(vk_w + pr_w + in_w, 0);
     Recorder R;
-    R.arena_lo = arena.data(); R.arena_hi = arena.data() + arena.size();
+    if (fixed_vk) memcpy(arena.data(), fixed_vk, vk_w * 8);
+    R.arena_base = arena.data(); R.arena_lo = arena.data() + (fixed_vk ? vk_w : 0); R.arena_hi = arena.data() + arena.size();
     rec::g_rec = &R;
     NestedData d{arena.data(), arena.data() + vk_w, arena.data() + vk_w + pr_w};
     Builder b;

@@ -35,6 +35,8 @@ struct WitnessTape {
 };
 
 // 0 on success
-int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* out, std::string* err);
+// fixed_vk: null = the circuit's generic program; else the nested key (60 + 12 (k + 1) limbs) of one application, folded into the
+// program as constants (witness_tape.cpp)
+int witness_tape_build(size_t num_proofs, size_t inputs_per_proof, WitnessTape* out, std::string* err, const uint64_t* fixed_vk = nullptr);
 
 }  // namespace zkhip

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <atomic>
+#include <memory>
 #include <mutex>
 
 #include "ec.cuh"
@@ -254,6 +255,13 @@ int zkhip_device_copy_in(void* dst, const void* src, size_t bytes) {
     API_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     API_HIP(hipStreamSynchronize(0));
   }
+  return ZKHIP_OK;
+}
+
+int zkhip_device_copy_out(void* dst_host, const void* src_device, size_t bytes) {
+  BIND_CUR();
+  if (bytes && (!dst_host || !src_device)) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (bytes) API_HIP(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
   return ZKHIP_OK;
 }
 
@@ -683,6 +691,47 @@ int zkhip_last_prove_timings(double out_ms[8]) {
 // z: host assignment (uploaded here) - or d_z_ready: the assignment already in device memory, ABI form, complete (GPU witness)
 // the cheap argument and size checks of a proof, before anything is started for it (the tail's scalar multiplications used to
 // be spawned before them)
+// ---- per-application constants (zkhip.h: zkhip_aggregator_app) ------------------------------------------------------------------
+struct zkhip_aggregator_app {
+  zkhip_aggregator* agg = nullptr;
+  const zkhip_crs* crs = nullptr;          // the key the cached points belong to
+  int device = 0;
+  std::vector<uint64_t> vk;                // the nested key (identity of the application)
+  std::vector<uint32_t> s_idx;             // the constant positions: auxiliary variables only, sorted
+  std::vector<uint64_t> s_val;             // their values, 6 limbs each
+  uint64_t vk_hash[6];                     // primary input 0
+  uint64_t points[4 * 36];                 // sum over s_idx of z_i Base_i for the A, B-G2, B-G1 and L queries (Jacobian)
+  void* host_state = nullptr;              // aggregator.cpp: the key with its lines
+  uint64_t* d_z_app = nullptr;             // n_vars x 6 limbs on the device: the constants at their positions, zero elsewhere
+  std::mutex mu;                           // the GPU witness program of this application, uploaded on first use
+  WitnessTape tape;
+  bool prog_ready = false;
+  WitnessProgDev prog;
+};
+
+// the proof's key and (for a host assignment) its masking
+static int app_check(const zkhip_aggregator_app* app, const zkhip_crs* crs, const uint64_t* z_host) {
+  if (app->crs != crs) return fail(ZKHIP_ERR_ARG, "this application handle was made for another proving key");
+  if (z_host)
+    for (uint32_t i : app->s_idx) {
+      const uint64_t* w = z_host + (size_t)i * 6;
+      if (w[0] | w[1] | w[2] | w[3] | w[4] | w[5])
+        return fail(ZKHIP_ERR_ARG, "assignment is not masked: a non-zero value at one of the application's constant positions (zkhip_aggregator_witness_app / zkhip_aggregator_app_mask)");
+    }
+  return ZKHIP_OK;
+}
+// A, B-G2, B-G1 and L sums of a masked proof += the application's cached points (H is untouched)
+static void app_add_points(const zkhip_aggregator_app* app, uint64_t sums[180]) {
+  using namespace host;
+  auto jac = [](const uint64_t* p) { HJac q; q.X = HFq::from_limbs(p); q.Y = HFq::from_limbs(p + 12); q.Z = HFq::from_limbs(p + 24); return q; };
+  static const int slot[4] = {0, 1, 2, 4};
+  for (int k = 0; k < 4; k++) {
+    uint64_t* s = sums + 36 * slot[k];
+    const HJac t = jac(s).add(jac(app->points + 36 * k));
+    t.X.to_limbs(s); t.Y.to_limbs(s + 12); t.Z.to_limbs(s + 24);
+  }
+}
+
 // The proving key is authoritative for the evaluation domain (a reference key of the wrapping circuit says 65,536, a key generated
 // here with ZKHIP_DOMAIN_STEP says 49,152): a shared constraint-system handle that sits on another domain is moved to the key's -
 // its matrices stay, the domain's buffers are rebuilt (once: the next proof with this key finds it there).  A key whose domain is
@@ -711,7 +760,7 @@ static int prove_check(const zkhip_crs* crs, const R1csDev* rd, size_t a_lo, siz
 }
 
 static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, const uint64_t* z, size_t a_lo, size_t h_lo, size_t l_lo,
-                         uint64_t sums[5 * 36], const uint64_t* d_z_ready = nullptr) {
+                         uint64_t sums[5 * 36], const uint64_t* d_z_ready = nullptr, const uint64_t* d_z_app = nullptr) {
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
   const size_t m = rd->n_vars, l = rd->n_primary;
@@ -757,7 +806,9 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   }
   ps.ms[0] = ms_since(t0);
   t0 = clk::now();
-  int rc = qap_h_dev(rd, dz, qst, t_err, sizeof t_err);
+  // (an application's constants - d_z_app - are part of the assignment the QAP map sees; the MSMs over z below run on the masked
+  //  vector: a zero scalar produces no bucket entry, the constants' share of A, B and L is the application's four cached points)
+  int rc = qap_h_dev(rd, dz, qst, t_err, sizeof t_err, d_z_app);
   if (rc != ZKHIP_OK) return rc;
   if (!chain) {
     API_HIP(hipEventRecord(ps.ev_st, qst));
@@ -966,7 +1017,8 @@ void zkhip_prover_free(zkhip_prover* p) {
   delete p;
 }
 
-static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t* d_z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]);
+static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t* d_z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72],
+                             const zkhip_aggregator_app* app = nullptr);
 int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]) {
   if (!z) return fail(ZKHIP_ERR_ARG, "null pointer");
   return prover_prove_impl(p, z, nullptr, r_m, s_m, proof_affine);
@@ -981,7 +1033,8 @@ int zkhip_prover_prove_partial(zkhip_prover* p, const uint64_t* z, uint64_t sums
   std::lock_guard<std::mutex> lk(p->mu);
   return prove_partial(p->ps, p->crs, p->rd, z, p->a_lo, p->h_lo, p->l_lo, sums_jac);
 }
-static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t* d_z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72]) {
+static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t* d_z, const uint64_t r_m[6], const uint64_t s_m[6], uint64_t proof_affine[72],
+                             const zkhip_aggregator_app* app) {
   if (!p || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (p->slice) return fail(ZKHIP_ERR_STATE, "this prover holds a slice of the key: zkhip_prover_prove_partial");
   BIND(p);                                    // called from pipeline / application threads that never ran zkhip_init
@@ -989,11 +1042,172 @@ static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t*
   uint64_t sums[180];
   const zkhip_crs* c = p->crs;
   { int rc_ = prove_check(c, p->rd, 0, 0, 0); if (rc_ != ZKHIP_OK) return rc_; }
+  if (app) { int rc_ = app_check(app, c, z); if (rc_ != ZKHIP_OK) return rc_; }
   TailPre pre;
   tail_begin(pre, c->delta_g1, c->delta_g2, r_m, s_m);             // the key-only part of the tail runs under the device work
-  int rc = prove_partial(p->ps, p->crs, p->rd, z, 0, 0, 0, sums, d_z);
+  int rc = prove_partial(p->ps, p->crs, p->rd, z, 0, 0, 0, sums, d_z, app ? app->d_z_app : nullptr);
   if (rc != ZKHIP_OK) return rc;
+  if (app) app_add_points(app, sums);
   return finish_impl(c->alpha_g1, c->beta_g1, c->beta_g2, c->delta_g1, c->delta_g2, sums, r_m, s_m, proof_affine, &p->ps.ms[7], &pre);
+}
+
+// ---- per-application constants: the public entry points ---------------------------------------------------------------------
+// (RegisterApplication fixes a nested verification key, aggregator_server.cpp:170-235; everything the wrapping circuit derives from
+// the key alone - its variables, its MiMC hash chain, the lines of -beta and -delta, the doubling chains of ABC_i - is the same in
+// every batch of that application: a quarter of the assignment.)
+int zkhip_aggregator_app_new(zkhip_aggregator* a, const zkhip_crs* crs, const uint64_t* nested_vk, zkhip_aggregator_app** out) {
+  if (!a || !crs || !nested_vk || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  BIND(crs);
+  const size_t m = a->n_vars, l = a->n_primary;
+  if (crs->n_vars != m || crs->n_primary != l || crs->A->len != m || crs->L->len != m - l - 1)
+    return fail(ZKHIP_ERR_ARG, "zkhip_aggregator_app_new: the proving key is not the whole key of this circuit");
+  std::unique_ptr<zkhip_aggregator_app> app(new zkhip_aggregator_app());
+  app->agg = a; app->crs = crs; app->device = crs->device;
+  const size_t vk_w = 60 + 12 * (a->inputs_per_proof + 1);
+  app->vk.assign(nested_vk, nested_vk + vk_w);
+  {
+    // the key's own points must lie on their curves (the proofs of a batch are checked per batch): checked with the key's points
+    // standing in for a proof
+    std::vector<uint64_t> stand_in(48 * a->num_proofs);
+    for (size_t q = 0; q < a->num_proofs; q++) {
+      memcpy(&stand_in[q * 48], nested_vk, 96); memcpy(&stand_in[q * 48 + 12], nested_vk + 12, 192); memcpy(&stand_in[q * 48 + 36], nested_vk, 96);
+    }
+    int ok = 0;
+    if (zkhip_aggregator_check_inputs(a, nested_vk, stand_in.data(), &ok) != ZKHIP_OK || !ok)
+      return fail(ZKHIP_ERR_ARG, "zkhip_aggregator_app_new: the nested verification key has a point that is not on its curve");
+  }
+  // the program of this application: the circuit recorded with the key as CONSTANTS (witness_tape.cpp) - what folds is constant
+  std::string terr;
+  if (witness_tape_build(a->num_proofs, a->inputs_per_proof, &app->tape, &terr, nested_vk) != 0) {
+    snprintf(t_err, sizeof t_err, "application program: %s", terr.c_str());
+    return ZKHIP_ERR_ARG;                            // (a key with a point off its curve / a degenerate key meets an inversion of zero here)
+  }
+  WitnessTape& T = app->tape;
+  if (T.n_vars != m) return fail(ZKHIP_ERR_STATE, "application program does not match the circuit");
+  if (T.out_ref[1] >= 0) return fail(ZKHIP_ERR_STATE, "application program: the key hash did not fold into a constant");
+  memcpy(app->vk_hash, &T.consts[(size_t)(-1 - T.out_ref[1]) * 6], 48);
+  // the zero constant every masked position is pointed at
+  int32_t zero_ref = 0;
+  {
+    size_t zi = T.consts.size() / 6;
+    for (size_t i = 0; i < T.consts.size() / 6; i++) {
+      const uint64_t* c = &T.consts[i * 6];
+      if (!(c[0] | c[1] | c[2] | c[3] | c[4] | c[5])) { zi = i; break; }
+    }
+    if (zi == T.consts.size() / 6) T.consts.insert(T.consts.end(), 6, 0);
+    zero_ref = -1 - (int32_t)zi;
+  }
+  std::vector<uint64_t> z_app(m * 6, 0);
+  for (size_t i = l + 1; i < m; i++) {
+    if (T.out_ref[i] >= 0) continue;
+    const uint64_t* c = &T.consts[(size_t)(-1 - T.out_ref[i]) * 6];
+    app->s_idx.push_back((uint32_t)i);
+    app->s_val.insert(app->s_val.end(), c, c + 6);
+    memcpy(&z_app[i * 6], c, 48);
+    T.out_ref[i] = zero_ref;                         // the application's generator writes the MASKED assignment
+  }
+  // Self-check: the constants came out of the RECORDING build of the circuit (the route the device takes); the host generator is the
+  // reference for parity.  One full host assignment under this key (the key's own points stand in for the proofs: the constant
+  // positions do not depend on them) must hold exactly these values there - a degenerate key, where the two routes part, gets no handle.
+  {
+    std::vector<uint64_t> stand_in(48 * a->num_proofs), zero_inputs(6 * a->inputs_per_proof * a->num_proofs, 0), z_full(m * 6);
+    for (size_t q = 0; q < a->num_proofs; q++) {
+      memcpy(&stand_in[q * 48], nested_vk, 96); memcpy(&stand_in[q * 48 + 12], nested_vk + 12, 192); memcpy(&stand_in[q * 48 + 36], nested_vk, 96);
+    }
+    if (zkhip_aggregator_witness(a, nested_vk, stand_in.data(), zero_inputs.data(), z_full.data()) != ZKHIP_OK)
+      return fail(ZKHIP_ERR_ARG, "zkhip_aggregator_app_new: the host generator refuses this nested key");
+    for (size_t j = 0; j < app->s_idx.size(); j++)
+      if (memcmp(&z_full[(size_t)app->s_idx[j] * 6], &app->s_val[j * 6], 48) != 0)
+        return fail(ZKHIP_ERR_ARG, "zkhip_aggregator_app_new: degenerate nested key (the recorded constants differ from the host generator's)");
+    if (memcmp(&z_full[6], app->vk_hash, 48) != 0) return fail(ZKHIP_ERR_STATE, "zkhip_aggregator_app_new: key hash mismatch");
+  }
+  int rc = zk_app_host_new(a, nested_vk, &app->host_state);
+  if (rc != ZKHIP_OK) return fail(rc, "zkhip_aggregator_app_new: the nested key's lines could not be computed (a degenerate key)");
+  hipError_t e = hipMalloc(&app->d_z_app, m * 48);
+  if (e == hipSuccess) e = hipMemcpy(app->d_z_app, z_app.data(), m * 48, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipStreamSynchronize(0);
+  if (e != hipSuccess) {
+    snprintf(t_err, sizeof t_err, "zkhip_aggregator_app_new: %s", hipGetErrorString(e));
+    zkhip_aggregator_app_free(app.release());
+    return ZKHIP_ERR_HIP;
+  }
+  // ONE masked MSM per query: sum over the constant positions of z_i Base_i (the positions hold zero in z_app elsewhere)
+  struct { const zkhip_bases* b; size_t off, len; } q[4] = {{crs->A, 0, m}, {crs->B2, 0, m}, {crs->B1, 0, m}, {crs->L, l + 1, m - l - 1}};
+  for (int k = 0; k < 4 && rc == ZKHIP_OK; k++)
+    rc = zkhip_msm_dev(q[k].b, 0, app->d_z_app + q[k].off * 6, q[k].len, 1, app->points + 36 * k);
+  if (rc != ZKHIP_OK) { zkhip_aggregator_app_free(app.release()); return rc; }
+  *out = app.release();
+  return ZKHIP_OK;
+}
+
+void zkhip_aggregator_app_free(zkhip_aggregator_app* app) {
+  if (!app) return;
+  (void)bind_dev(app->device);
+  if (app->prog_ready) witness_prog_free(&app->prog);
+  if (app->d_z_app) (void)hipFree(app->d_z_app);
+  zk_app_host_free(app->host_state);
+  delete app;
+}
+
+size_t zkhip_aggregator_app_num_constants(const zkhip_aggregator_app* app) { return app ? app->s_idx.size() : 0; }
+
+int zkhip_aggregator_app_constants(const zkhip_aggregator_app* app, uint32_t* positions, uint64_t* values, uint64_t vk_hash[6], uint64_t points_jac[144]) {
+  if (!app) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (positions) memcpy(positions, app->s_idx.data(), app->s_idx.size() * 4);
+  if (values) memcpy(values, app->s_val.data(), app->s_val.size() * 8);
+  if (vk_hash) memcpy(vk_hash, app->vk_hash, 48);
+  if (points_jac) memcpy(points_jac, app->points, sizeof app->points);
+  return ZKHIP_OK;
+}
+
+int zkhip_aggregator_app_mask(const zkhip_aggregator_app* app, uint64_t* z) {
+  if (!app || !z) return fail(ZKHIP_ERR_ARG, "null pointer");
+  for (size_t j = 0; j < app->s_idx.size(); j++) {
+    uint64_t* w = z + (size_t)app->s_idx[j] * 6;
+    if (memcmp(w, &app->s_val[j * 6], 48) != 0) return fail(ZKHIP_ERR_ARG, "this assignment was not generated under the application's nested key");
+    memset(w, 0, 48);
+  }
+  return ZKHIP_OK;
+}
+
+int zkhip_aggregator_witness_app(const zkhip_aggregator_app* app, const uint64_t* nested_proofs, const uint64_t* nested_inputs, uint64_t* z_out) {
+  if (!app || !nested_proofs || !nested_inputs || !z_out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  return zk_app_host_witness(app->agg, app->host_state, app->vk.data(), nested_proofs, nested_inputs, app->s_idx.data(), app->s_idx.size(), app->vk_hash, z_out);
+}
+
+int zkhip_prover_prove_app(zkhip_prover* p, const zkhip_aggregator_app* app, const uint64_t* z_masked, const uint64_t r_m[6], const uint64_t s_m[6],
+                           uint64_t proof_affine[72]) {
+  if (!z_masked || !app) return fail(ZKHIP_ERR_ARG, "null pointer");
+  return prover_prove_impl(p, z_masked, nullptr, r_m, s_m, proof_affine, app);
+}
+int zkhip_prover_prove_app_dev(zkhip_prover* p, const zkhip_aggregator_app* app, const void* d_z_masked, const uint64_t r_m[6], const uint64_t s_m[6],
+                               uint64_t proof_affine[72]) {
+  if (!d_z_masked || !app) return fail(ZKHIP_ERR_ARG, "null pointer");
+  return prover_prove_impl(p, nullptr, (const uint64_t*)d_z_masked, r_m, s_m, proof_affine, app);
+}
+
+int zkhip_groth16_prove_app(const zkhip_crs* crs, zkhip_r1cs* r1cs, const zkhip_aggregator_app* app, const uint64_t* z_masked, const uint64_t r_m[6],
+                            const uint64_t s_m[6], uint64_t proof_affine[72]) {
+  uint64_t sums[180];
+  if (!crs || !r1cs || !app || !z_masked || !r_m || !s_m || !proof_affine) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (crs->device != r1cs->device) return fail(ZKHIP_ERR_ARG, "proving key and constraint system live on different devices");
+  BIND(crs);
+  { int rc_ = app_check(app, crs, z_masked); if (rc_ != ZKHIP_OK) return rc_; }
+  TailPre pre;
+  {
+    std::lock_guard<std::mutex> lk(g.dev[crs->device].mu);
+    { int rc_ = follow_key_domain(crs, r1cs->dev); if (rc_ != ZKHIP_OK) return rc_; }
+    { int rc_ = prove_check(crs, r1cs->dev, 0, 0, 0); if (rc_ != ZKHIP_OK) return rc_; }
+    tail_begin(pre, crs->delta_g1, crs->delta_g2, r_m, s_m);
+    int rc = prove_partial(g.dev[crs->device].ps, crs, r1cs->dev, z_masked, 0, 0, 0, sums, nullptr, app->d_z_app);
+    if (rc != ZKHIP_OK) return rc;
+  }
+  app_add_points(app, sums);
+  t_prove_dev = crs->device;
+  double tail_ms = 0;
+  const int rc = finish_impl(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine, &tail_ms, &pre);
+  if (rc == ZKHIP_OK) { std::lock_guard<std::mutex> lk(g.dev[crs->device].mu); g.dev[crs->device].ps.ms[7] = tail_ms; }
+  return rc;
 }
 
 int zkhip_prover_set_streaming(zkhip_prover* p, int on) {
@@ -1308,23 +1522,38 @@ void zkhip_gpu_witness_free(zkhip_gpu_witness* w) {
 // n batches in ONE launch sequence (one workgroup each).  vk / proofs / inputs: n pointers; d_z_out: n x n_vars x 6 limbs in device
 // memory, contiguous; primary_inputs: n x n_primary x 6 limbs (host, may be null); degenerate[i] = 1 where an inversion met zero
 // (that batch's assignment is unusable: use the host generator).
-int zkhip_gpu_witness_run_batched(zkhip_gpu_witness* w, size_t n, const uint64_t* const* nested_vk, const uint64_t* const* nested_proofs,
-                                  const uint64_t* const* nested_inputs, void* d_z_out, uint64_t* primary_inputs, int* degenerate) {
-  if (!w || !nested_vk || !nested_proofs || !nested_inputs || !d_z_out || !degenerate) return fail(ZKHIP_ERR_ARG, "null pointer");
+static int gpu_witness_run_impl(zkhip_gpu_witness* w, zkhip_aggregator_app* app, size_t n, const uint64_t* const* nested_vk, const uint64_t* const* nested_proofs,
+                                const uint64_t* const* nested_inputs, void* d_z_out, uint64_t* primary_inputs, int* degenerate) {
+  if (!w || (!app && !nested_vk) || !nested_proofs || !nested_inputs || !d_z_out || !degenerate) return fail(ZKHIP_ERR_ARG, "null pointer");
   if (n < 1 || n > w->max_batches) return fail(ZKHIP_ERR_ARG, "more batches than the work space holds");
   BIND(w);
   const zkhip_aggregator* a = w->agg;
   const size_t vk_w = 60 + 12 * (a->inputs_per_proof + 1), pr_w = 48 * a->num_proofs, in_w = 6 * a->inputs_per_proof * a->num_proofs;
   if (vk_w + pr_w + in_w != w->in_words) return fail(ZKHIP_ERR_STATE, "witness program does not match the circuit");
+  WitnessProg prog = w->prog;
+  if (app) {
+    // the application's own program (its key folded in: no key-hash chain, a tenth fewer multiplications, zeros at the constant
+    // positions of the assignment), uploaded on first use
+    if (app->agg != a || app->device != w->device) return fail(ZKHIP_ERR_ARG, "application handle of another circuit or device");
+    std::lock_guard<std::mutex> lk(app->mu);
+    if (!app->prog_ready) {
+      int rc = witness_prog_upload(app->tape, &app->prog, t_err, sizeof t_err);
+      if (rc != ZKHIP_OK) return rc;
+      app->prog_ready = true;
+    }
+    if (app->prog.prog.n_pos > w->prog.n_pos || app->prog.prog.n_inputs != w->prog.n_inputs)
+      return fail(ZKHIP_ERR_STATE, "the application's program does not fit the generator's work space");
+    prog = app->prog.prog;
+  }
   for (size_t i = 0; i < n; i++) {
     uint64_t* h = w->h_in + i * w->in_words;
-    memcpy(h, nested_vk[i], vk_w * 8); memcpy(h + vk_w, nested_proofs[i], pr_w * 8); memcpy(h + vk_w + pr_w, nested_inputs[i], in_w * 8);
+    memcpy(h, app ? app->vk.data() : nested_vk[i], vk_w * 8); memcpy(h + vk_w, nested_proofs[i], pr_w * 8); memcpy(h + vk_w + pr_w, nested_inputs[i], in_w * 8);
   }
   uint64_t* h_flags = w->h_in + w->max_batches * w->in_words;            // [n flags as u32 | primary inputs]
   uint64_t* h_prim = h_flags + w->max_batches;
   API_HIP(hipMemcpyAsync(w->d_in, w->h_in, n * w->in_words * 8, hipMemcpyHostToDevice, w->st));
   API_HIP(hipMemsetAsync(w->d_flag, 0, n * 4, w->st));
-  witness_launch(w->prog, w->d_in, w->d_vals, (uint64_t*)d_z_out, w->d_flag, (uint32_t)n, w->st, w->st2, w->ev_fork, w->ev_join);
+  witness_launch(prog, w->d_in, w->d_vals, (uint64_t*)d_z_out, w->d_flag, (uint32_t)n, w->st, w->st2, w->ev_fork, w->ev_join);
   API_HIP(hipGetLastError());
   API_HIP(hipMemcpyAsync(h_flags, w->d_flag, n * 4, hipMemcpyDeviceToHost, w->st));
   for (size_t i = 0; i < n; i++)
@@ -1334,6 +1563,18 @@ int zkhip_gpu_witness_run_batched(zkhip_gpu_witness* w, size_t n, const uint64_t
   for (size_t i = 0; i < n; i++) degenerate[i] = ((const uint32_t*)h_flags)[i] != 0;
   if (primary_inputs) memcpy(primary_inputs, h_prim, n * a->n_primary * 48);
   return ZKHIP_OK;
+}
+
+int zkhip_gpu_witness_run_batched(zkhip_gpu_witness* w, size_t n, const uint64_t* const* nested_vk, const uint64_t* const* nested_proofs,
+                                  const uint64_t* const* nested_inputs, void* d_z_out, uint64_t* primary_inputs, int* degenerate) {
+  return gpu_witness_run_impl(w, nullptr, n, nested_vk, nested_proofs, nested_inputs, d_z_out, primary_inputs, degenerate);
+}
+// the same for batches of ONE registered application: MASKED assignments (zeros at the application's constant positions), ready for
+// zkhip_prover_prove_app_dev
+int zkhip_gpu_witness_run_batched_app(zkhip_gpu_witness* w, zkhip_aggregator_app* app, size_t n, const uint64_t* const* nested_proofs,
+                                      const uint64_t* const* nested_inputs, void* d_z_out, uint64_t* primary_inputs, int* degenerate) {
+  if (!app) return fail(ZKHIP_ERR_ARG, "null pointer");
+  return gpu_witness_run_impl(w, app, n, nullptr, nested_proofs, nested_inputs, d_z_out, primary_inputs, degenerate);
 }
 
 int zkhip_gpu_witness_run(zkhip_gpu_witness* w, const uint64_t* nested_vk, const uint64_t* nested_proofs, const uint64_t* nested_inputs,

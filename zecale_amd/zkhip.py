@@ -35,6 +35,9 @@ EXPORTS = [
     "zkhip_msm_stream_last_accumulate_interval", "zkhip_msm_stream_free", "zkhip_prover_new_slice", "zkhip_prover_prove_partial",
     "zkhip_dispatcher_new", "zkhip_dispatcher_size", "zkhip_dispatcher_submit", "zkhip_dispatcher_wait", "zkhip_dispatcher_stats", "zkhip_dispatcher_free",
     "zkhip_multi_prover_new", "zkhip_multi_prover_size", "zkhip_multi_prover_prove", "zkhip_multi_prover_timings", "zkhip_multi_prover_free",
+    "zkhip_aggregator_app_new", "zkhip_aggregator_app_free", "zkhip_aggregator_app_num_constants", "zkhip_aggregator_app_constants", "zkhip_aggregator_app_mask",
+    "zkhip_aggregator_witness_app", "zkhip_groth16_prove_app", "zkhip_prover_prove_app", "zkhip_prover_prove_app_dev", "zkhip_gpu_witness_run_batched_app",
+    "zkhip_aggregator_pipeline_register_app", "zkhip_aggregator_pipeline_app_hits", "zkhip_dispatcher_register_app", "zkhip_device_copy_out",
 ]
 
 
@@ -706,6 +709,93 @@ class AggregatorCircuit:
             self.handle = None
 
 
+class AggregatorApp:
+    """A registered application (zkhip_aggregator_app; RegisterApplication in the reference, aggregator_server.cpp:170-235): the
+    constants of its nested key for one proving key - positions, values, the four cached points - computed once.  `witness` gives
+    the MASKED assignment of a batch (zeros at those positions), `prove` the same proof as groth16_prove on the full one."""
+
+    def __init__(self, agg, crs, nested_vk):
+        vk = np.ascontiguousarray(nested_vk, dtype=np.uint64).reshape(-1)
+        assert vk.size == 60 + 12 * (agg.inputs_per_nested_proof + 1)
+        h = ctypes.c_void_p()
+        lib = load()
+        lib.zkhip_aggregator_app_new.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64p_t, ctypes.POINTER(ctypes.c_void_p)]
+        _check(lib.zkhip_aggregator_app_new(agg.handle, crs.handle, _p(vk), ctypes.byref(h)))
+        self.handle, self._agg, self._crs = h, agg, crs
+        lib.zkhip_aggregator_app_num_constants.restype = ctypes.c_size_t
+        lib.zkhip_aggregator_app_num_constants.argtypes = [ctypes.c_void_p]
+        self.num_constants = int(lib.zkhip_aggregator_app_num_constants(h))
+
+    def constants(self):
+        """(positions u32[n], values u64[n, 6], vk_hash u64[6], points u64[4, 36])"""
+        pos = np.zeros(self.num_constants, dtype=np.uint32)
+        val = np.zeros((self.num_constants, 6), dtype=np.uint64)
+        h, pts = np.zeros(6, dtype=np.uint64), np.zeros((4, 36), dtype=np.uint64)
+        lib = load()
+        lib.zkhip_aggregator_app_constants.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64p_t, c_u64p_t, c_u64p_t]
+        _check(lib.zkhip_aggregator_app_constants(self.handle, pos.ctypes.data, _p(val), _p(h), _p(pts)))
+        return pos, val, h, pts
+
+    def mask(self, z):
+        """A full assignment generated under this application's key, masked (copy)."""
+        zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(-1, 6).copy()
+        lib = load()
+        lib.zkhip_aggregator_app_mask.argtypes = [ctypes.c_void_p, c_u64p_t]
+        _check(lib.zkhip_aggregator_app_mask(self.handle, _p(zz)))
+        return zz
+
+    def witness(self, nested_proofs, nested_inputs):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+        pr, inp = c(nested_proofs), c(nested_inputs)
+        k = self._agg.inputs_per_nested_proof
+        assert pr.size == 48 * self._agg.num_proofs and inp.size == 6 * k * self._agg.num_proofs
+        z = np.zeros((self._agg.num_variables, 6), dtype=np.uint64)
+        lib = load()
+        lib.zkhip_aggregator_witness_app.argtypes = [ctypes.c_void_p, c_u64p_t, c_u64p_t, c_u64p_t]
+        _check(lib.zkhip_aggregator_witness_app(self.handle, _p(pr), _p(inp), _p(z)))
+        return z
+
+    def witness_gpu(self, batches):
+        """batches: list of (nested_proofs, nested_inputs) -> list of MASKED assignments generated on the GPU by the application's own
+        program in ONE launch sequence (zkhip_gpu_witness_run_batched_app); a degenerate batch yields None."""
+        lib = load()
+        n, m, l = len(batches), self._agg.num_variables, self._agg.num_primary_inputs()
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+        prs, ins = [c(b[0]) for b in batches], [c(b[1]) for b in batches]
+        gw = ctypes.c_void_p()
+        lib.zkhip_gpu_witness_new_batched.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        _check(lib.zkhip_gpu_witness_new_batched(self._agg.handle, n, ctypes.byref(gw)))
+        dz = ctypes.c_void_p()
+        _check(lib.zkhip_device_alloc(n * m * 48, ctypes.byref(dz)))
+        try:
+            arr = lambda xs: (ctypes.c_void_p * n)(*[x.ctypes.data for x in xs])
+            prim = np.zeros((n, l, 6), dtype=np.uint64)
+            deg = (ctypes.c_int * n)()
+            lib.zkhip_gpu_witness_run_batched_app.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_u64p_t, ctypes.POINTER(ctypes.c_int)]
+            _check(lib.zkhip_gpu_witness_run_batched_app(gw, self.handle, n, arr(prs), arr(ins), dz, _p(prim), deg))
+            z = np.zeros((n, m, 6), dtype=np.uint64)
+            lib.zkhip_device_copy_out.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+            _check(lib.zkhip_device_copy_out(z.ctypes.data, dz, n * m * 48))
+            return [None if deg[i] else z[i] for i in range(n)], prim
+        finally:
+            lib.zkhip_device_free(dz)
+            lib.zkhip_gpu_witness_free(gw)
+
+    def prove(self, r1cs, z_masked, r, s):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        zz, r, s = c(z_masked).reshape(r1cs.n_vars, 6), c(r), c(s)
+        out = np.zeros(72, dtype=np.uint64)
+        lib = load()
+        lib.zkhip_groth16_prove_app.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_u64p_t, c_u64p_t, c_u64p_t, c_u64p_t]
+        _check(lib.zkhip_groth16_prove_app(self._crs.handle, r1cs.handle, self.handle, _p(zz), _p(r), _p(s), _p(out)))
+        return out
+
+    def free(self):
+        if self.handle:
+            load().zkhip_aggregator_app_free(self.handle)
+            self.handle = None
+
+
 class Prover:
     """A prover instance (zkhip_prover): own streams and work space, one proof in flight; several instances, one host
     thread each, keep several proofs in flight on one GPU.  `crs` must outlive the instance."""
@@ -720,6 +810,16 @@ class Prover:
         z, r, s = c(z), c(r), c(s)
         out = np.zeros(72, dtype=np.uint64)
         _check(load().zkhip_prover_prove(self.handle, _p(z), _p(r), _p(s), _p(out)))
+        return out
+
+    def prove_app(self, app, z_masked, r, s):
+        """The same proof from a MASKED assignment and the application's constants (zkhip_prover_prove_app)."""
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        z, r, s = c(z_masked), c(r), c(s)
+        out = np.zeros(72, dtype=np.uint64)
+        lib = load()
+        lib.zkhip_prover_prove_app.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64p_t, c_u64p_t, c_u64p_t, c_u64p_t]
+        _check(lib.zkhip_prover_prove_app(self.handle, app.handle, _p(z), _p(r), _p(s), _p(out)))
         return out
 
     def set_streaming(self, on=True):
@@ -744,13 +844,29 @@ class AggregatorPipeline:
     """Streaming aggregator_circuit::prove (zkhip_aggregator_pipeline_*): submit() returns a ticket at once, wait(ticket)
     returns (primary_inputs, proof).  Witness generation, the GPU prover and the host tail of successive batches overlap."""
 
-    def __init__(self, agg, crs, gpu_slots=2, witness_workers=2, gpu_witness=False):
+    def __init__(self, agg, crs, gpu_slots=2, witness_workers=2, gpu_witness=False, app_cache=True):
+        """app_cache: keep a zkhip_aggregator_app per nested key seen and prove its batches from masked assignments (default; the
+        proofs are the same either way)."""
         h = ctypes.c_void_p()
         lib = load()
         lib.zkhip_aggregator_pipeline_new_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]
-        _check(lib.zkhip_aggregator_pipeline_new_ex(agg.handle, crs.handle, gpu_slots, witness_workers, 1 if gpu_witness else 0, ctypes.byref(h)))
+        flags = (1 if gpu_witness else 0) | (0 if app_cache else 2)
+        _check(lib.zkhip_aggregator_pipeline_new_ex(agg.handle, crs.handle, gpu_slots, witness_workers, flags, ctypes.byref(h)))
         self.handle, self._agg, self._crs = h, agg, crs
         self.n_primary = agg.num_primary_inputs()
+
+    def register_app(self, nested_vk):
+        """RegisterApplication's part in the prover: the application's constants are computed now (zkhip_aggregator_pipeline_register_app)."""
+        vk = np.ascontiguousarray(nested_vk, dtype=np.uint64).reshape(-1)
+        lib = load()
+        lib.zkhip_aggregator_pipeline_register_app.argtypes = [ctypes.c_void_p, c_u64p_t]
+        _check(lib.zkhip_aggregator_pipeline_register_app(self.handle, _p(vk)))
+
+    def app_hits(self):
+        lib = load()
+        lib.zkhip_aggregator_pipeline_app_hits.restype = ctypes.c_size_t
+        lib.zkhip_aggregator_pipeline_app_hits.argtypes = [ctypes.c_void_p]
+        return int(lib.zkhip_aggregator_pipeline_app_hits(self.handle))
 
     def submit(self, nested_vk, nested_proofs, nested_inputs, r, s):
         c = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
