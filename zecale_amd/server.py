@@ -294,6 +294,16 @@ class GpuProver:
     def nested_vk_hash(self, nested_vk_limbs):
         return self.zk.aggregator_vk_hash(nested_vk_limbs, NUM_INPUTS_PER_NESTED_PROOF)
 
+    def register_application(self, nested_vk_limbs):
+        """RegisterApplication's part in the prover (aggregator_server.cpp:170-235 stores the key): the streaming prover computes the
+        key's constants now (zkhip_aggregator_app: the key's share of every assignment and of four of the five MSMs), so that the
+        application's first batch does not pay for them.  A degenerate key gets no handle and is proved by the plain path."""
+        try:
+            self.pipe.register_app(nested_vk_limbs)
+            return True
+        except self.zk.ZkhipError:
+            return False
+
     def check_nested_proof(self, nested_vk_limbs, proof_limbs):
         """Well-formedness of ONE nested proof at submission time (libsnark's proof.is_well_formed(): every point on its curve).
         Host code.  A malformed transaction is refused before it can sit in a batch with somebody else's honest one."""
@@ -354,8 +364,11 @@ class AggregatorService:
                 if name in self.pools:
                     raise ValueError("application already registered")                   # aggregator_server.cpp:186-190
                 vk_json = verification_key_from_proto(request.vk)
-                resp, _ = self._hash_response(vk_json)
+                resp, limbs = self._hash_response(vk_json)
                 self.pools[name] = ApplicationPool(name, vk_json)
+            register = getattr(self.prover, "register_application", None)              # (outside the lock: ~0.2 s on the GPU)
+            if register is not None:
+                register(limbs)
             return resp
         return self._guard(context, run, message_class("zecale_proto.VerificationKeyHash"))
 
