@@ -464,6 +464,11 @@ int zkhip_reset_time_base(void);
  * the integer multiplier, and its rate differs between boxes and power states of the same model: a measurement states
  * its fraction against the peak of the run it was taken in. */
 int zkhip_measure_fq_mul_rate(double* fq_mul_per_s);
+/* The transform kernels of zkhip_ntt ALONE (no conversion from / to the ABI's limbs, no allocation): `batch` (1 .. 3: the QAP map
+ * transforms its A, B, C vectors in the same launches) resident vectors of 2^log_d elements, `reps` timed transforms after one
+ * untimed, HIP events on the stream the passes run on.  *ms_per_transform = elapsed / (reps x batch).  dir / coset as zkhip_ntt.
+ * replaces: nothing - the measurement behind bench.py's ntt roofline (2 d 48 B per transform). */
+int zkhip_measure_ntt(unsigned log_d, int dir, int coset, int batch, int reps, double* ms_per_transform);
 /* Test hook (no counterpart): the device build's three multiplier bodies - the code every kernel runs (fp29.cuh / fp29_chain.cuh) - on
  * operands given limb by limb: field 0 = Fq (27 limbs of 29 bits), 1 = Fr (14); limbs_in holds n cases of (a, b, c, d), limbs_out
  * receives n x { a b / R, a^2 / R, (a b + c d) / R } in the device's own form (R = 2^783 / 2^406).  Operands must respect the

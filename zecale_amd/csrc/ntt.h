@@ -14,6 +14,7 @@ namespace zkhip {
 int ntt_dev_packed(uint32_t* d_data, int log_d, int inverse, int coset, int in_transposed, hipStream_t st, char* err, size_t errlen);
 int ntt_dev_packed_batch(uint32_t* const* d_bufs, int nbuf, int log_d, int inverse, int coset, int in_transposed, hipStream_t st, char* err, size_t errlen);   // up to 3 vectors, same launches
 int ntt_layout_logk(int log_d);
+int ntt_measure(int log_d, int inverse, int coset, int batch, int reps, double* ms_per_transform, char* err, size_t errlen);   // the passes alone, HIP events
 int ntt_dev_abi(uint64_t* d_data, int log_d, int inverse, int coset, char* err, size_t errlen);
 void fr_abi_to_dev(const uint64_t* d_in, uint32_t* d_out, size_t n, hipStream_t st);
 void fr_abi_to_dev_merge(const uint64_t* d_in, const uint64_t* d_in2, uint32_t* d_out, size_t n, hipStream_t st);   // limb-wise OR of two disjoint parts

@@ -113,6 +113,19 @@ struct PassArgs {
 
 constexpr int pass_threads(int logk, int logc) { return (logk + logc) <= 8 ? 64 : (1 << (logk + logc - 2)); }
 
+// LDS bank swizzle (round 5; profiles/r05_ntt_counters_before.csv: 79 % of the kernel's LDS-array cycles were bank-conflict cycles).
+// The tile is limb-major, lds[limb * E + p]; a radix-4 round of span q = 2^(s-1) reads p0 + t q (t = 0..3) with p0 running over the
+// indices whose bits s-1 and s are clear: for q = 1, 4, 16 the 32 lanes of a half-wave then fall on 8, 8 and 16 of the 32 banks
+// (ds_read_b32 / ds_write_b32: bank = dword address mod 32, lanes conflict within a 32-lane half), and the bit-reversed placement
+// of the load phase is a power-of-two stride too.  Element p lives at p ^ m(p >> 5), m linear over GF(2) with the columns below -
+// chosen so that in EVERY phase (load natural / strided, rounds s = 1, 3, 5, 7, 9, the odd last stage, store) the 32 lanes of a
+// half-wave hit 32 different banks: the address bits that vary across a half-wave map onto the five bank bits with full rank.
+//   bit 5 -> banks {0,2}   bit 6 -> {1,3,4}   bit 7 -> {2}   bit 8 -> {3}   bit 9 -> {3,4}   bit 10 -> {0,4}
+__device__ __forceinline__ uint32_t lds_sw(uint32_t p) {
+  const uint32_t h = p >> 5;
+  return p ^ ((h & 1u) * 5u) ^ (((h >> 1) & 1u) * 26u) ^ (h & 0xcu) ^ (((h >> 4) & 1u) * 24u) ^ (((h >> 5) & 1u) * 17u);
+}
+
 // Inputs < 8r (every producer here stores < 2r); values grow by at most 2r per stage (< 2^7 r = 2^384 at the end).
 template <int LOGK, int LOGC>
 __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs a) {
@@ -133,8 +146,9 @@ __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs 
     const size_t loc = a.strided ? (size_t)q + (size_t)j * a.S : ((size_t)q << LOGK) + j;
     const FrD v = fr_load12(data + loc * 12);
     const uint32_t rj = LOGK ? (__brev(j) >> ((32 - LOGK) & 31)) : 0u;     // (LOGK = 0: a transform of size 1)
+    const uint32_t pw = lds_sw(cc * K + rj);
 #pragma unroll
-    for (int i = 0; i < 14; i++) lds[i * E + cc * K + rj] = v.l[i];
+    for (int i = 0; i < 14; i++) lds[i * E + pw] = v.l[i];
   }
   __syncthreads();
   // ---- two stages per round trip through LDS
@@ -146,11 +160,12 @@ __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs 
       const uint32_t qq = 1u << (s - 1);
       const uint32_t jj = gi & (qq - 1), blk = gi >> (s - 1);
       const uint32_t p0 = cc * K + (blk << (s + 1)) + jj;
+      const uint32_t a0 = lds_sw(p0), a1 = lds_sw(p0 + qq), a2 = lds_sw(p0 + 2 * qq), a3 = lds_sw(p0 + 3 * qq);
       FrD x0, x1, x2, x3;
 #pragma unroll
       for (int i = 0; i < 14; i++) {
-        x0.l[i] = lds[i * E + p0]; x1.l[i] = lds[i * E + p0 + qq];
-        x2.l[i] = lds[i * E + p0 + 2 * qq]; x3.l[i] = lds[i * E + p0 + 3 * qq];
+        x0.l[i] = lds[i * E + a0]; x1.l[i] = lds[i * E + a1];
+        x2.l[i] = lds[i * E + a2]; x3.l[i] = lds[i * E + a3];
       }
       FrD y0, y1, y2, y3, z0, z1, z2, z3;
       if (s == 1 && !a.tw_scaled) {                     // twiddles 1, 1 | 1, omega^(K/4): one multiplication
@@ -172,8 +187,8 @@ __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs 
       }
 #pragma unroll
       for (int i = 0; i < 14; i++) {
-        lds[i * E + p0] = z0.l[i]; lds[i * E + p0 + qq] = z1.l[i];
-        lds[i * E + p0 + 2 * qq] = z2.l[i]; lds[i * E + p0 + 3 * qq] = z3.l[i];
+        lds[i * E + a0] = z0.l[i]; lds[i * E + a1] = z1.l[i];
+        lds[i * E + a2] = z2.l[i]; lds[i * E + a3] = z3.l[i];
       }
     }
     __syncthreads();
@@ -183,7 +198,7 @@ __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs 
       const uint32_t cc = LOGK >= 1 ? (g >> ((LOGK - 1) & 31)) : 0u, gi = g & (K / 2 - 1);
       const uint32_t half = 1u << (s - 1);
       const uint32_t jj = gi & (half - 1);
-      const uint32_t p0 = cc * K + ((gi >> (s - 1)) << s) + jj, p1 = p0 + half;
+      const uint32_t p0 = lds_sw(cc * K + ((gi >> (s - 1)) << s) + jj), p1 = lds_sw(cc * K + ((gi >> (s - 1)) << s) + jj + half);
       FrD u, v;
 #pragma unroll
       for (int i = 0; i < 14; i++) { u.l[i] = lds[i * E + p0]; v.l[i] = lds[i * E + p1]; }
@@ -208,8 +223,9 @@ __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs 
     const uint32_t q = q0 + cc;
     const size_t loc = a.strided ? (size_t)q + (size_t)k * a.S : ((size_t)q << LOGK) + k;
     FrD v;
+    const uint32_t pr = lds_sw(cc * K + k);
 #pragma unroll
-    for (int i = 0; i < 14; i++) v.l[i] = lds[i * E + cc * K + k];
+    for (int i = 0; i < 14; i++) v.l[i] = lds[i * E + pr];
     if (a.mid) v = fp_mul(v, fr_load12(a.mid + loc * 12));
     if (a.post_k) v = fp_mul(v, fr_load14(a.post_k + (size_t)k * 14));
     if (a.post_const) v = fp_mul(v, fr_load14(a.post_const));
@@ -363,9 +379,14 @@ static void launch_pass(const PassArgs& a, uint32_t groups, hipStream_t st) {
   while (nbuf < NTT_MAX_BATCH && a.data[nbuf]) nbuf++;
   hipLaunchKernelGGL((k_ntt_pass<LOGK, LOGC>), dim3(groups, nbuf), dim3(pass_threads(LOGK, LOGC)), 0, st, a);
 }
-static int one_each_max() { static const int v = [] { const char* e = getenv("ZKHIP_NTT_ONE_EACH_MAX"); int x = e ? atoi(e) : 18; return x < 0 || x > 22 ? 18 : x; }(); return v; }
-// One workgroup per sub-transform up to 2^18 elements (the passes are latency-bound there: as many workgroups as possible);
-// beyond, 2048 elements per workgroup (adjacent sub-transforms: C * 48 contiguous bytes per row of the strided pass).
+static int one_each_max() { static const int v = [] { const char* e = getenv("ZKHIP_NTT_ONE_EACH_MAX"); int x = e ? atoi(e) : 22; return x < 0 || x > 22 ? 22 : x; }(); return v; }
+// One workgroup per sub-transform at every size (round 5; rounds 2-4: up to 2^18, beyond that 2048 elements per workgroup - adjacent
+// sub-transforms, C * 48 contiguous bytes per row of the strided pass).  A 2048-element tile is 112 KiB of LDS: ONE workgroup per CU,
+// whose load and store phases and seven barriers leave the CU's SIMDs idle (SQ_WAIT_ANY 35 % of the wave-cycles); two independent
+// 1024-element workgroups per CU overlap each other's phases: 2^20, three vectors: 0.260 -> 0.236 ms per transform, 2^21: 0.555 ->
+// 0.527 (profiles/r05_ntt_one_each.txt; a 2^11-point sub-transform needs the whole tile either way: 2^22 unchanged).  The strided
+// pass then reads 48 contiguous bytes per row instead of 96 - it is not what the pass waits for.  ZKHIP_NTT_ONE_EACH_MAX=18 restores
+// the wide tiles.
 static void launch_pass_dyn(int log_k, bool one_each, const PassArgs& a, uint32_t n_sub, hipStream_t st) {
   if (one_each) {
     switch (log_k) {
@@ -473,6 +494,58 @@ int ntt_dev_packed_batch(uint32_t* const* d_bufs, int nbuf, int log_d, int inver
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(err, errlen, "ntt launch: %s", hipGetErrorString(e)); return ZKHIP_ERR_HIP; }
   return ZKHIP_OK;
+}
+
+// Time the transform kernels alone (bench.py's ntt_2_20 roofline): `batch` resident vectors (1 .. 3: the QAP map transforms A, B, C
+// in the same launches) of 2^log_d packed elements with pseudo-random contents, `reps` transforms after one untimed, HIP events on
+// the stream the passes are launched on.  *ms_per_transform = elapsed / (reps * batch): the time one size-d transform costs.
+// A transform leaves its output in the other order (natural <-> transposed): successive repetitions alternate the side, as the
+// QAP map's chain does; forward coset transforms (natural input only) are put back by an untimed inverse in between.
+int ntt_measure(int log_d, int inverse, int coset, int batch, int reps, double* ms_per_transform, char* err, size_t errlen) {
+  if (log_d < 1 || log_d > 22 || batch < 1 || batch > NTT_MAX_BATCH || reps < 1 || reps > 1000 || !ms_per_transform) { snprintf(err, errlen, "ntt_measure: bad argument"); return ZKHIP_ERR_ARG; }
+  const size_t d = (size_t)1 << log_d;
+  uint32_t* bufs[NTT_MAX_BATCH] = {nullptr, nullptr, nullptr};
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = ZKHIP_OK;
+  hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  std::vector<uint32_t> h(d * 12);
+  uint64_t x = 0x9E3779B97F4A7C15ull;
+  for (size_t i = 0; i < h.size(); i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[i] = (uint32_t)x; }
+  for (size_t i = 0; i < d; i++) h[i * 12 + 11] &= 0x00ffffffu;                  // values below 2^376 < r: valid lazily-reduced elements
+  for (int b = 0; b < batch && e == hipSuccess; b++) {
+    e = hipMalloc(&bufs[b], d * 48);
+    if (e == hipSuccess) e = hipMemcpy(bufs[b], h.data(), d * 48, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) { snprintf(err, errlen, "ntt_measure: %s", hipGetErrorString(e)); rc = ZKHIP_ERR_HIP; }
+  float total = 0.f;
+  const bool fwd_coset = !inverse && coset;
+  int side = 0;                                       // 0: the vectors are in natural order
+  for (int r = -1; r < reps && rc == ZKHIP_OK; r++) {
+    if (fwd_coset && side) {                          // back to natural order, untimed
+      rc = ntt_dev_packed_batch(bufs, batch, log_d, 1, 0, 1, st, err, errlen);
+      side = 0;
+      if (rc != ZKHIP_OK) break;
+    }
+    if (r >= 0) (void)hipEventRecord(e0, st);
+    rc = ntt_dev_packed_batch(bufs, batch, log_d, inverse, coset, log_d >= 12 ? side : 0, st, err, errlen);
+    if (r >= 0) {
+      (void)hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess) { snprintf(err, errlen, "ntt_measure: event"); rc = ZKHIP_ERR_HIP; break; }
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      total += ms;
+    } else (void)hipStreamSynchronize(st);
+    if (log_d >= 12) side ^= 1;
+  }
+  if (rc == ZKHIP_OK) *ms_per_transform = (double)total / (double)(reps * batch);
+  for (uint32_t* b : bufs) if (b) (void)hipFree(b);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
 }
 
 void fr_abi_to_dev(const uint64_t* d_in, uint32_t* d_out, size_t n, hipStream_t st) {

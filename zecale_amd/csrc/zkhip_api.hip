@@ -1786,6 +1786,12 @@ int zkhip_measure_fq_mul_rate(double* fq_mul_per_s) {
   return msm_measure_fqmul_rate(fq_mul_per_s, t_err, sizeof t_err);
 }
 
+int zkhip_measure_ntt(unsigned log_d, int dir, int coset, int batch, int reps, double* ms_per_transform) {
+  BIND_CUR();
+  if (!ms_per_transform) return fail(ZKHIP_ERR_ARG, "null pointer");
+  return ntt_measure((int)log_d, dir, coset, batch, reps, ms_per_transform, t_err, sizeof t_err);
+}
+
 int zkhip_internal_field_selftest(int field, const uint32_t* limbs_in, size_t n, uint32_t* limbs_out) {
   BIND_CUR();
   if ((field != 0 && field != 1) || (n && (!limbs_in || !limbs_out)) || n > (1u << 20)) return fail(ZKHIP_ERR_ARG, "field 0 (Fq) or 1 (Fr), at most 2^20 cases");

@@ -37,7 +37,7 @@ EXPORTS = [
     "zkhip_multi_prover_new", "zkhip_multi_prover_size", "zkhip_multi_prover_prove", "zkhip_multi_prover_timings", "zkhip_multi_prover_free",
     "zkhip_aggregator_app_new", "zkhip_aggregator_app_free", "zkhip_aggregator_app_num_constants", "zkhip_aggregator_app_constants", "zkhip_aggregator_app_mask",
     "zkhip_aggregator_witness_app", "zkhip_groth16_prove_app", "zkhip_prover_prove_app", "zkhip_prover_prove_app_dev", "zkhip_gpu_witness_run_batched_app",
-    "zkhip_aggregator_pipeline_register_app", "zkhip_aggregator_pipeline_app_hits", "zkhip_dispatcher_register_app", "zkhip_device_copy_out",
+    "zkhip_aggregator_pipeline_register_app", "zkhip_aggregator_pipeline_app_hits", "zkhip_dispatcher_register_app", "zkhip_device_copy_out", "zkhip_measure_ntt",
 ]
 
 
@@ -1128,6 +1128,15 @@ def measure_fq_mul_rate():
     v = ctypes.c_double(0)
     _check(load().zkhip_measure_fq_mul_rate(ctypes.byref(v)))
     return float(v.value)
+
+
+def measure_ntt(log_d, inverse=False, coset=False, batch=1, reps=10):
+    """ms per size-2^log_d transform, the pass kernels alone (zkhip_measure_ntt: HIP events on the passes' stream)."""
+    out = ctypes.c_double(0)
+    lib = load()
+    lib.zkhip_measure_ntt.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    _check(lib.zkhip_measure_ntt(log_d, int(inverse), int(coset), batch, reps, ctypes.byref(out)))
+    return out.value
 
 
 def reset_time_base():
