@@ -505,10 +505,15 @@ int zkhip_dispatcher_stats(const zkhip_dispatcher* d, size_t* submitted_per_entr
 int zkhip_dispatcher_outstanding(const zkhip_dispatcher* d, size_t* per_entry);        /* submitted and not yet collected, per entry */
 void zkhip_dispatcher_free(zkhip_dispatcher* d);
 /* One proof over a key PARTITIONED across the list (BASELINE configs[3]): entry k holds the k-th contiguous slice of
- * the A / B, H and L queries (sizes differ by at most one, the partition of zecale_amd/dist.py) and a prover instance on it; prove
+ * the A / B, H and L queries (equal finite terms per slice: zkhip_key_partition) and a prover instance on it; prove
  * runs the slices on a host thread each, adds the 5 x 288-byte partial sums in list order on the host (zkhip_jac_add) and finishes
  * once (zkhip_groth16_finish).  Same proof as zkhip_groth16_prove over the whole key.
  * replaces: wsnarkT::generate_proof (aggregator_circuit.tcc:168) for a key that one GPU should not hold or prove alone. */
+/* How a key is cut for N devices / ranks: cuts[0 .. parts] (parts + 1 values each) of the A / B queries (one range for the three: the
+ * weight of an index is the number of its finite bases among A, B-G2, B-G1), of H and of L - contiguous slices of equal FINITE terms
+ * (a base at infinity - a third of a real key's B query - produces no bucket entry).  Host code; zkhip_multi_prover_new and
+ * zecale_amd/dist.py (one process per GPU) cut by this rule. */
+int zkhip_key_partition(const zkhip_crs_desc* key, int parts, size_t* a_cuts, size_t* h_cuts, size_t* l_cuts);
 typedef struct zkhip_multi_prover zkhip_multi_prover;
 int zkhip_multi_prover_new(const zkhip_crs_desc* key, const zkhip_r1cs_desc* cs, const zkhip_key_opts* opts, const int* devices, int n_devices,
                            zkhip_multi_prover** out);

@@ -142,11 +142,86 @@ def check_prover(rank, world):
     return ok
 
 
+def check_bench_legs(rank, world):
+    """bench.py's N > 1 legs under gloo: partitioned_prover_leg - BASELINE configs[3]: one proof per step over a key
+    cut by FINITE terms, the exchange of zecale_amd/dist.py, every rank finishing the same proof - with the C oracle standing in for
+    the partial MSMs, and replicas_leg - configs[4]: independent streams, no collective on the data path - with a stub stream; the
+    legs' own aggregation (slowest rank's time and phases, all ranks' proofs, every rank's verification) is what is checked."""
+    import json
+    import time
+    import bench
+    n, l = 150, 4
+    A, B, C, zi = make_r1cs(5, n, l, n, 0.3)
+    m = len(zi)
+    pk, d = cpu_key(A, B, C, m, l, (0x1234567, 0x2345678, 0x3456789, 0x456789a))
+    pk["B2"][::3] = 0; pk["B1"][::3] = 0                                # a sparse B query, as a real key has (the proof then differs from
+    csr = tuple(csr_from_rows(x) for x in (A, B, C))                    # the trapdoor's: it is compared with the oracle's whole-key proof)
+    z = fr_array(zi)
+    r_, s_ = fr_array_mont(random_fr_uniform(7, 1))[0], fr_array_mont(random_fr_uniform(8, 1))[0]
+    whole = O.groth16_prove(pk, z, l, O.qap_h(*csr, z, n, l), r_, s_, chunks=1)
+    ranges = zdist.key_slices_by_finite_terms(pk, m, l, d, world, rank)
+    # the slices tile the queries, carry equal finite terms (+-1 per cut) and agree with the library's own rule (zkhip_key_partition)
+    ac, hc, lc = zkhip.key_partition(pk, m, l, d, world)
+    ok = ranges == ((ac[rank], ac[rank + 1]), (hc[rank], hc[rank + 1]), (lc[rank], lc[rank + 1])) and ac[0] == 0 and ac[-1] == m and hc[-1] == d - 1 and lc[-1] == m - l - 1
+    fin = lambda a: int(np.asarray(a).reshape(-1, 24).any(axis=1).sum())
+    w_all = [fin(pk["A"][ac[k]:ac[k + 1]]) + fin(pk["B2"][ac[k]:ac[k + 1]]) + fin(pk["B1"][ac[k]:ac[k + 1]]) for k in range(world)]
+    ok = ok and max(w_all) - min(w_all) <= 6                         # (an index weighs up to 3: a cut lands within 3 of its target)
+    if not ok:
+        print('slices:', ranges, ac, hc, lc, w_all, flush=True)
+
+    class Slice:
+        pass
+    ks = Slice()
+    ks.ranges = ranges
+    (a0, a1), (h0, h1), (l0, l1) = ranges
+    ks.A, ks.B2, ks.B1, ks.H, ks.L = pk["A"][a0:a1], pk["B2"][a0:a1], pk["B1"][a0:a1], pk["H"][h0:h1], pk["L"][l0:l1]
+    be = OracleBackend(csr, n, l)
+
+    class Prover:
+        def prove(self):
+            t = time.time()
+            sums = be.groth16_prove_partial(ks, None, z)
+            self.ms = (time.time() - t) * 1e3
+            return zkhip.groth16_finish(pk, zdist.combine_partial_sums(sums), r_, s_)
+
+        def verify(self, proof):
+            return bool((proof == whole).all())
+
+        def phases(self):
+            return {"partial_sums": self.ms}
+
+        def info(self):
+            return {"constraints": n}
+    barrier = dist.barrier
+
+    def red(x, op):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+    rmax, rsum = (lambda x: red(x, dist.ReduceOp.MAX)), (lambda x: red(x, dist.ReduceOp.SUM))
+    leg = bench.partitioned_prover_leg(world, rank, Prover(), 2, 1, barrier, rmax, 8)
+
+    class Stream:
+        def run(self, k_warm, k_timed):
+            time.sleep(0.01 * (rank + 1))                              # rank r takes (r + 1) x 10 ms: the slowest rank sets the rate
+            return 0.01 * (rank + 1), 0.02 * (rank + 1), True
+    rep = bench.replicas_leg(world, rank, Stream(), 3, 16, barrier, rmax, rsum, "stub")
+    if rank == 0:
+        json.dumps(leg); json.dumps(rep)                               # both must serialise into the bench line
+        ok = ok and leg["n_gpus"] == world and leg["scaling"] == "strong" and leg["last_proof_verifies_on_every_rank"] is True and leg["value"] > 0
+        ok = ok and "partial_sums" in leg["phase_ms_slowest_rank"] and leg["steps"] == 2
+        ok = ok and rep["n_gpus"] == world and rep["scaling"] == "weak" and rep["proofs_per_rank"] == 48
+        ok = ok and abs(rep["value"] - 48 * world / (0.01 * world)) < 1e-3 * rep["value"] and abs(rep["host_cores_busy_per_rank_max"] - 2.0) < 0.01
+    else:
+        ok = ok and leg is None and rep is None
+    return bool(ok)
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     which = sys.argv[1] if len(sys.argv) > 1 else "msm"
-    ok = check_msm(rank, world) if which == "msm" else check_prover(rank, world)
+    ok = check_msm(rank, world) if which == "msm" else check_bench_legs(rank, world) if which == "legs" else check_prover(rank, world)
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()

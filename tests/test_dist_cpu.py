@@ -35,6 +35,15 @@ def test_key_partitioned_prover_gloo(world):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_gpu_legs_gloo(world):
+    """bench.py's two N > 1 legs - `prover_2_22_partitioned` (BASELINE configs[3]) and `wrapping_replicas` (configs[4]) - in real
+    multi-process jobs with stand-ins for the kernels: slices by finite terms (dist.py = zkhip_key_partition), the exchange, the finish
+    on every rank = the oracle's whole-key proof, and the legs' aggregation over ranks."""
+    p = _torchrun(world, 29640 + world, os.path.join(ROOT, "tests", "dist_worker.py"), "legs")
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def _json_line(text):
     for line in text.splitlines():
         if line.startswith("{"):

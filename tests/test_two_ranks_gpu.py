@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def _bench(*args):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(ZKHIP_BENCH_SHARE_GPU="1", ZKHIP_BENCH_BACKEND="gloo")
+    env.update(ZKHIP_BENCH_SHARE_GPU="1", ZKHIP_BENCH_BACKEND="gloo", ZKHIP_BENCH_PARTITION_LOG="16")      # (the N > 1 legs at a rehearsal size)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
@@ -33,3 +33,9 @@ def test_point_partitioned_msm_across_two_processes():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["terms_per_gpu"] == 1 << 16
     assert line["combined_result_matches_closed_form"] is True        # sum over BOTH ranks' slices = (sum s_i k_i) G
+    # the driver's N > 1 command also measures BASELINE configs[3] and [4]: one proof per step over the key cut two
+    # ways (verified on every rank), and one streaming prover per rank on the nine-input circuit
+    part, rep = line["prover_2_22_partitioned"], line["wrapping_replicas"]
+    assert part["n_gpus"] == 2 and part["scaling"] == "strong" and part["last_proof_verifies_on_every_rank"] is True and part["value"] > 0
+    assert part["constraints"] == (1 << 16) - 8 and "exchange_and_additions" in part["phase_ms_slowest_rank"]
+    assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["last_proof_verifies_on_every_rank"] is True and rep["proofs_per_rank"] == 192

@@ -37,13 +37,47 @@ int check_devices(const int* devices, int n) {
     if (devices[i] < 0 || devices[i] >= count) return fail(count ? ZKHIP_ERR_ARG : ZKHIP_ERR_NO_DEVICE, "device list: no such GPU");
   return ZKHIP_OK;
 }
-// contiguous slice [lo, hi) of n items owned by part k of `parts` (sizes differ by at most one): zecale_amd/dist.py partition()
-void part_of(size_t n, size_t parts, size_t k, size_t* lo, size_t* hi) {
-  const size_t base = n / parts, rem = n % parts;
-  *lo = k * base + (k < rem ? k : rem);
-  *hi = *lo + base + (k < rem ? 1 : 0);
+bool finite_point(const uint64_t* p) {               // the ABI's point at infinity is the all-zero pattern
+  uint64_t acc = 0;
+  for (int i = 0; i < 24; i++) acc |= p[i];
+  return acc != 0;
+}
+// cuts[0 .. parts] of n items with weights w (finite bases: a base at infinity produces no bucket entry and costs a slice nothing):
+// cut k is the first index at which the running weight reaches k W / parts - contiguous slices of equal WEIGHT, not equal length
+// (a third of a real key's B query is the point at infinity).  zecale_amd/dist.py cuts_by_weight is the same rule.
+void cuts_by_weight(const std::vector<uint32_t>& w, size_t parts, size_t* cuts) {
+  const size_t n = w.size();
+  uint64_t total = 0;
+  for (uint32_t x : w) total += x;
+  cuts[0] = 0; cuts[parts] = n;
+  uint64_t run = 0;
+  size_t i = 0;
+  for (size_t k = 1; k < parts; k++) {
+    const uint64_t want = (total * k + parts - 1) / parts;          // ceil(k W / parts)
+    while (i < n && run < want) run += w[i++];
+    cuts[k] = i;
+  }
 }
 }  // namespace
+
+extern "C" int zkhip_key_partition(const zkhip_crs_desc* key, int parts, size_t* a_cuts, size_t* h_cuts, size_t* l_cuts) {
+  if (!key || !a_cuts || !h_cuts || !l_cuts || parts < 1 || parts > 64) return fail(ZKHIP_ERR_ARG, "zkhip_key_partition: bad argument");
+  if (key->n_vars < key->n_primary + 1 || key->domain_size < 1 || !key->a_query || !key->b_g2_query || !key->b_g1_query || (key->domain_size > 1 && !key->h_query))
+    return fail(ZKHIP_ERR_ARG, "zkhip_key_partition: incomplete key");
+  const size_t m = key->n_vars, nl = m - key->n_primary - 1, nh = key->domain_size - 1;
+  if (nl && !key->l_query) return fail(ZKHIP_ERR_ARG, "zkhip_key_partition: incomplete key");
+  std::vector<uint32_t> w(m);
+  for (size_t i = 0; i < m; i++)
+    w[i] = (uint32_t)finite_point(key->a_query + i * 24) + (uint32_t)finite_point(key->b_g2_query + i * 24) + (uint32_t)finite_point(key->b_g1_query + i * 24);
+  cuts_by_weight(w, (size_t)parts, a_cuts);
+  w.assign(nh, 0);
+  for (size_t i = 0; i < nh; i++) w[i] = finite_point(key->h_query + i * 24);
+  cuts_by_weight(w, (size_t)parts, h_cuts);
+  w.assign(nl, 0);
+  for (size_t i = 0; i < nl; i++) w[i] = finite_point(key->l_query + i * 24);
+  cuts_by_weight(w, (size_t)parts, l_cuts);
+  return ZKHIP_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------- replicas
 struct zkhip_dispatcher {
@@ -186,12 +220,11 @@ int zkhip_multi_prover_new(const zkhip_crs_desc* key, const zkhip_r1cs_desc* cs,
   mp->n_vars = key->n_vars;
   memcpy(mp->alpha_g1, key->alpha_g1, 192); memcpy(mp->beta_g1, key->beta_g1, 192); memcpy(mp->beta_g2, key->beta_g2, 192);
   memcpy(mp->delta_g1, key->delta_g1, 192); memcpy(mp->delta_g2, key->delta_g2, 192);
-  const size_t m = key->n_vars, l = key->n_primary, d = key->domain_size;
+  // slices of equal FINITE terms per query group (zkhip_key_partition)
+  std::vector<size_t> ac(n_devices + 1), hc(n_devices + 1), lc(n_devices + 1);
+  rc = zkhip_key_partition(key, n_devices, ac.data(), hc.data(), lc.data());
   for (int i = 0; i < n_devices && rc == ZKHIP_OK; i++) {
-    size_t a0, a1, h0, h1, l0, l1;
-    part_of(m, (size_t)n_devices, (size_t)i, &a0, &a1);
-    part_of(d - 1, (size_t)n_devices, (size_t)i, &h0, &h1);
-    part_of(m - l - 1, (size_t)n_devices, (size_t)i, &l0, &l1);
+    const size_t a0 = ac[i], a1 = ac[i + 1], h0 = hc[i], h1 = hc[i + 1], l0 = lc[i], l1 = lc[i + 1];
     zkhip_crs* c = nullptr;
     zkhip_prover* p = nullptr;
     if ((rc = zkhip_init(devices[i])) == ZKHIP_OK && (rc = zkhip_set_device(devices[i])) == ZKHIP_OK &&

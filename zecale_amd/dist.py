@@ -82,6 +82,31 @@ def key_slices(n_vars, n_primary, domain_size, world, rank):
     return (partition(n_vars, world, rank), partition(domain_size - 1, world, rank), partition(n_vars - n_primary - 1, world, rank))
 
 
+def cuts_by_weight(w, parts):
+    """cuts[0 .. parts] of len(w) items: cut k is the first index at which the running weight reaches ceil(k W / parts) - contiguous
+    slices of equal WEIGHT (multi_device.cpp cuts_by_weight is the same rule)."""
+    w = np.asarray(w, dtype=np.uint64)
+    run = np.concatenate([[0], np.cumsum(w)])
+    total = int(run[-1])
+    cuts = [0]
+    for k in range(1, parts):
+        want = -(-total * k // parts)
+        cuts.append(int(np.searchsorted(run, want, side="left")))
+    cuts.append(len(w))
+    return cuts
+
+
+def key_slices_by_finite_terms(pk, n_vars, n_primary, domain_size, world, rank):
+    """Ranges of the A/B, H and L queries owned by `rank`, cut so that every rank gets the same number of FINITE bases (a base at
+    infinity - a third of a real key's B query - produces no bucket entry): what zkhip_key_partition computes for the one-process
+    form.  pk: dict of host arrays A, B2, B1, H, L (n x 24 limbs, all-zero = infinity)."""
+    fin = lambda a: np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 24).any(axis=1).astype(np.uint64)
+    wa = fin(pk["A"]) + fin(pk["B2"]) + fin(pk["B1"])
+    assert len(wa) == n_vars and len(pk["H"]) == domain_size - 1 and len(pk["L"]) == n_vars - n_primary - 1
+    ac, hc, lc = cuts_by_weight(wa, world), cuts_by_weight(fin(pk["H"]), world), cuts_by_weight(fin(pk["L"]), world)
+    return (ac[rank], ac[rank + 1]), (hc[rank], hc[rank + 1]), (lc[rank], lc[rank + 1])
+
+
 def prove_distributed(crs_slice, r1cs, pk_consts, z, r, s, group=None, device=None, backend=None):
     """One Groth16 proof with the proving key partitioned over the ranks of `group`: every rank runs the (cheap, replicated)
     QAP map and the five MSMs over its slice, the 5 x 288-byte partial sums are all-gathered and added in rank order on

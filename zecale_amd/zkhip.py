@@ -37,7 +37,7 @@ EXPORTS = [
     "zkhip_multi_prover_new", "zkhip_multi_prover_size", "zkhip_multi_prover_prove", "zkhip_multi_prover_timings", "zkhip_multi_prover_free",
     "zkhip_aggregator_app_new", "zkhip_aggregator_app_free", "zkhip_aggregator_app_num_constants", "zkhip_aggregator_app_constants", "zkhip_aggregator_app_mask",
     "zkhip_aggregator_witness_app", "zkhip_groth16_prove_app", "zkhip_prover_prove_app", "zkhip_prover_prove_app_dev", "zkhip_gpu_witness_run_batched_app",
-    "zkhip_aggregator_pipeline_register_app", "zkhip_aggregator_pipeline_app_hits", "zkhip_dispatcher_register_app", "zkhip_device_copy_out", "zkhip_measure_ntt",
+    "zkhip_aggregator_pipeline_register_app", "zkhip_aggregator_pipeline_app_hits", "zkhip_dispatcher_register_app", "zkhip_device_copy_out", "zkhip_measure_ntt", "zkhip_key_partition",
 ]
 
 
@@ -562,6 +562,22 @@ class Crs:
         self.handle = h
         self.ranges = (a_range, h_range, l_range)
         return self
+
+
+def key_partition(pk, n_vars, n_primary, domain_size, parts):
+    """zkhip_key_partition on host arrays: (a_cuts, h_cuts, l_cuts), parts + 1 values each.  Host code, no device."""
+    d = CrsDesc()
+    d.n_vars, d.n_primary, d.domain_size = n_vars, n_primary, domain_size
+    keep = []
+    for field, key in (("a_query", "A"), ("b_g2_query", "B2"), ("b_g1_query", "B1"), ("h_query", "H"), ("l_query", "L")):
+        a = np.ascontiguousarray(pk[key], dtype=np.uint64).reshape(-1, 24)
+        keep.append(a)
+        setattr(d, field, a.ctypes.data if len(a) else None)
+    cuts = [(ctypes.c_size_t * (parts + 1))() for _ in range(3)]
+    lib = load()
+    lib.zkhip_key_partition.argtypes = [ctypes.POINTER(CrsDesc), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    _check(lib.zkhip_key_partition(ctypes.byref(d), parts, cuts[0], cuts[1], cuts[2]))
+    return tuple([int(x) for x in c] for c in cuts)
 
 
 def crs_from_slice_arrays(consts, slices, n_vars, n_primary, domain_size, a_range, h_range, l_range):
