@@ -81,3 +81,45 @@ def test_aggregator_circuit_mirror_compiles_and_runs_host_part(tmp_path):
     assert "primary=4" in out.stdout and "caught: attempt to aggregate proof with invalid number of inputs" in out.stdout
     assert '{"proof": {"a": ["0x' in out.stdout
     assert "multi: zkhip_multi_prover_new" in out.stdout          # no device here (or a null key): refused, as a std::runtime_error
+
+
+def test_host_tail_in_a_cpp_program_and_clean_exit(tmp_path):
+    """zkhip_groth16_finish (host code: the prover's tail, row a9) from a plain C++ program: its scalar multiplications run on the
+    library's pool of host threads - the program must get the proof AND exit (round 5: a pool destroyed at exit while its workers sleep
+    on its condition variable hung the C++ boundary test), and the tail's fixed-window multiplication must agree with big integers:
+    A = alpha + 0 + r delta for alpha = delta = G1, r = 5 is 6 G1."""
+    from oracle import pyref as R
+    from tests.helpers import aff_limbs, fr_limbs
+    import numpy as np
+    g1, g2 = aff_limbs(R.G1_GEN), aff_limbs(R.G2_GEN)
+    blob = np.concatenate([g1, g2, fr_limbs(5), fr_limbs(7)]).astype(np.uint64)
+    (tmp_path / "in.bin").write_bytes(blob.tobytes())
+    src = tmp_path / "tail.cpp"
+    src.write_text(textwrap.dedent(r'''
+        #include <cstdio>
+        #include <cstdint>
+        #include "zkhip.h"
+        int main(int argc, char** argv) {
+          uint64_t in[24 + 24 + 12], sums[180] = {0}, out[72];
+          FILE* f = std::fopen(argv[1], "rb");
+          if (!f || std::fread(in, 8, 60, f) != 60) return 2;
+          std::fclose(f);
+          const uint64_t *g1 = in, *g2 = in + 24, *r = in + 48, *s = in + 54;
+          for (int rep = 0; rep < 3; rep++) {
+            int rc = zkhip_groth16_finish(g1, g1, g2, g1, g2, sums, r, s, out);          // alpha = beta1 = delta1 = G1, beta2 = delta2 = G2, all sums infinity
+            if (rc != 0) { std::printf("rc=%d %s\n", rc, zkhip_last_error()); return 1; }
+          }
+          for (int i = 0; i < 72; i++) std::printf("%016llx%s", (unsigned long long)out[i], i % 24 == 23 ? "\n" : " ");
+          return 0;
+        }
+    '''))
+    exe = tmp_path / "tail"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "zecale_amd"), "-lzkhip", "-Wl,-rpath," + os.path.join(ROOT, "zecale_amd")])
+    out = subprocess.run([str(exe), str(tmp_path / "in.bin")], capture_output=True, text=True, timeout=60)      # (a hang at exit fails here)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [np.array([int(x, 16) for x in ln.split()], dtype=np.uint64) for ln in out.stdout.strip().splitlines()]
+    # A = G + 5 G = 6 G;  B = G2 + 7 G2 = 8 G2;  C = s A + r B1 - r s delta1 with B1 = G + 7 G = 8 G:  (42 + 40 - 35) G = 47 G
+    assert (rows[0] == aff_limbs(R.ec_mul(6, R.G1_GEN))).all()
+    assert (rows[1] == aff_limbs(R.ec_mul(8, R.G2_GEN))).all()
+    assert (rows[2] == aff_limbs(R.ec_mul(47, R.G1_GEN))).all()

@@ -8,6 +8,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 #include "bw6_params.h"
 #include "fp_inv.cuh"
 
@@ -58,26 +59,32 @@ struct HF {
   }
   HF neg() const { return zero() - *this; }
   HF dbl() const { return *this + *this; }
+  // CIOS Montgomery product, the form for a modulus with spare top bits (both moduli leave seven: the running value never needs an
+  // extra carry word): per row one chain for a b_i and one for m p, fused, fully unrolled.  15-20 % faster than the textbook loop it
+  // replaces (round 5) - the host witness generator spends two thirds of its time here (105 k products per proof section).
   HF operator*(const HF& b) const {
-    uint64_t t[N + 2];
+    uint64_t t[N];
     memset(t, 0, sizeof t);
+#pragma GCC unroll 12
     for (int i = 0; i < N; i++) {
-      uint64_t c = 0;
-      for (int j = 0; j < N; j++) {
-        u128 x = (u128)v[j] * b.v[i] + t[j] + c;
-        t[j] = (uint64_t)x; c = (uint64_t)(x >> 64);
-      }
-      u128 x = (u128)t[N] + c; t[N] = (uint64_t)x; t[N + 1] = (uint64_t)(x >> 64);
-      uint64_t m = t[0] * PR::PINV64;
-      x = (u128)m * PR::P64[0] + t[0]; c = (uint64_t)(x >> 64);
+      const uint64_t bi = b.v[i];
+      u128 x = (u128)v[0] * bi + t[0];
+      uint64_t ca = (uint64_t)(x >> 64);                 // carry of the a b_i chain
+      const uint64_t m = (uint64_t)x * PR::PINV64;
+      u128 y = (u128)m * PR::P64[0] + (uint64_t)x;
+      uint64_t cm = (uint64_t)(y >> 64);                 // carry of the m p chain
+#pragma GCC unroll 12
       for (int j = 1; j < N; j++) {
-        x = (u128)m * PR::P64[j] + t[j] + c;
-        t[j - 1] = (uint64_t)x; c = (uint64_t)(x >> 64);
+        x = (u128)v[j] * bi + t[j] + ca;
+        ca = (uint64_t)(x >> 64);
+        y = (u128)m * PR::P64[j] + (uint64_t)x + cm;
+        cm = (uint64_t)(y >> 64);
+        t[j - 1] = (uint64_t)y;
       }
-      x = (u128)t[N] + c; t[N - 1] = (uint64_t)x; t[N] = t[N + 1] + (uint64_t)(x >> 64);
+      t[N - 1] = ca + cm;                                // (no overflow: p < 2^(64 N - 7))
     }
     HF r; memcpy(r.v, t, sizeof r.v);
-    if (t[N] || geq_p(r.v)) sub_p(r.v);
+    if (geq_p(r.v)) sub_p(r.v);
     return r;
   }
   HF sqr() const { return (*this) * (*this); }
@@ -161,6 +168,22 @@ struct HJac {
     return q;
   }
   HJac neg() const { HJac r = *this; r.Y = Y.neg(); return r; }
+  // this + (x2, y2), the second point affine and finite (madd-2007-bl: 7 products and 4 squarings against add's 11 and 5)
+  HJac add_affine(const HFq& x2, const HFq& y2) const {
+    if (is_inf()) return from_affine(x2, y2);
+    HFq Z1Z1 = Z.sqr();
+    HFq U2 = x2 * Z1Z1, S2 = y2 * Z * Z1Z1;
+    if (U2 == X) {
+      if (S2 == Y) return dbl();
+      return infinity();
+    }
+    HFq H = U2 - X, HH = H.sqr(), I = HH.dbl().dbl(), J = H * I, r = (S2 - Y).dbl(), V = X * I;
+    HJac q;
+    q.X = r.sqr() - J - V.dbl();
+    q.Y = r * (V - q.X) - (Y * J).dbl();
+    q.Z = (Z + H).sqr() - Z1Z1 - HH;
+    return q;
+  }
   // k * P for a canonical little-endian scalar: 4-bit fixed windows from the top (14 additions for the table, then four doublings
   // and at most one addition per window: ~100 additions instead of the ~190 of double-and-add on a 377-bit scalar)
   HJac mul_canonical(const uint64_t* k, int nlimbs) const {
@@ -181,6 +204,49 @@ struct HJac {
     if (is_inf()) { x = HFq::zero(); y = HFq::zero(); return; }
     HFq zi = Z.inv(), zi2 = zi.sqr();
     x = X * zi2; y = Y * zi2 * zi;
+  }
+};
+
+// k P for a FIXED point P and many 377-bit scalars k (the prover's tail multiplies delta_1 and delta_2 of its key by r, s, r s in
+// every proof: r1cs_gg_ppzksnark_prover, reached from aggregator_circuit.tcc:168): 48 windows of 8 bits, the 255 non-zero multiples
+// d 2^(8 w) P of every window kept AFFINE (one batch inversion when the table is built: ~0.1 s, 4.7 MB per point) - a product is at
+// most 48 mixed additions and no doubling, against 377 doublings and ~95 additions for the variable-base routine above.
+struct FixedBase8 {
+  static constexpr int W = 48;                 // ceil(377 / 8)
+  std::vector<HFq> xy;                         // [w][d - 1] -> x, y
+  bool base_inf = true;
+  void build(const HJac& P) {
+    base_inf = P.is_inf();
+    xy.assign((size_t)W * 255 * 2, HFq::zero());
+    if (base_inf) return;
+    std::vector<HJac> pts((size_t)W * 255);
+    HJac step = P;                             // 2^(8 w) P
+    for (int w = 0; w < W; w++) {
+      HJac acc = step;
+      for (int d = 1; d <= 255; d++) { pts[(size_t)w * 255 + d - 1] = acc; acc = acc.add(step); }
+      step = acc;                              // 256 step
+    }
+    // batch normalisation (a multiple of a point of prime order r by d 2^(8w) < r is never the point at infinity)
+    std::vector<HFq> pre(pts.size());
+    HFq run = HFq::one();
+    for (size_t i = 0; i < pts.size(); i++) { pre[i] = run; run = run * pts[i].Z; }
+    HFq inv = run.inv();
+    for (size_t i = pts.size(); i-- > 0;) {
+      const HFq zi = inv * pre[i];
+      inv = inv * pts[i].Z;
+      const HFq zi2 = zi.sqr();
+      xy[i * 2] = pts[i].X * zi2; xy[i * 2 + 1] = pts[i].Y * zi2 * zi;
+    }
+  }
+  // k: canonical little-endian limbs, below 2^384
+  HJac mul(const uint64_t* k) const {
+    HJac acc = HJac::infinity();
+    if (base_inf) return acc;
+    for (int w = 0; w < W; w++) {
+      const unsigned d = (unsigned)(k[w / 8] >> ((w % 8) * 8)) & 255u;
+      if (d) { const size_t i = ((size_t)w * 255 + d - 1) * 2; acc = acc.add_affine(xy[i], xy[i + 1]); }
+    }
+    return acc;
   }
 };
 

@@ -17,8 +17,13 @@
 #include "pairing_host.hpp"
 #include "witness.h"
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <future>
+#include <thread>
 #include <vector>
+#include <pthread.h>
 
 using namespace zkhip;
 
@@ -38,12 +43,15 @@ struct zkhip_r1cs {
   int device;
 };
 
+struct TailTables { host::FixedBase8 d1, d2; };      // fixed-base tables of delta_1 and delta_2 for the prover's tail
 struct zkhip_crs {
   size_t n_vars, n_primary, domain_size;
   zkhip_bases *A, *B2, *B1, *H, *L;
   uint64_t alpha_g1[24], beta_g1[24], beta_g2[24], delta_g1[24], delta_g2[24];
   int device;
   int batch_msms = 1;     // the five MSMs of a proof in one launch sequence (zkhip_key_opts; the key carries its own choice)
+  mutable std::once_flag tail_once;               // built by the key's first proof (~0.2 s of host time)
+  mutable std::unique_ptr<TailTables> tail;
 };
 
 struct zkhip_keypair {
@@ -589,10 +597,12 @@ static ResolvedOpts resolve_opts(const zkhip_key_opts* o) {
 static int crs_build_tables(zkhip_crs* c, const ResolvedOpts& o) {
   c->batch_msms = o.batch;
   if (!o.precompute) return ZKHIP_OK;
-  size_t maxlen = c->A->len > c->H->len ? c->A->len : c->H->len;
   zkhip_bases* all[5] = {c->A, c->B2, c->B1, c->H, c->L};
-  size_t total = 0, finite = 0;
-  for (zkhip_bases* b : all) { total += b->len; finite += b->n_finite; }
+  size_t total = 0, finite = 0, maxlen = 0;
+  // (the window follows the longest vector's FINITE bases: a slice cut by finite terms - zkhip_key_partition - can be long and
+  //  mostly infinity; a whole key's longest vector is H or L, all finite: unchanged)
+  for (zkhip_bases* b : all) { total += b->len; finite += b->n_finite; if (b->n_finite > maxlen) maxlen = b->n_finite; }
+  if (maxlen == 0) maxlen = c->A->len > c->H->len ? c->A->len : c->H->len;
   // one kind of table for the whole key; an explicit request for the larger kind still respects the memory guard
   const int naf = (o.naf >= 0 ? (o.naf && naf_tables_fit(total)) : naf_tables_wanted(total)) ? 1 : 0;
   int tc = o.window ? o.window : auto_table_window(maxlen);
@@ -893,17 +903,84 @@ struct TailPre {
   uint64_t rc_[6], sc_[6], rsc_[6];
   std::future<host::HJac> rd1, sd2, sd1, rsd1;
 };
+// The tail's scalar multiplications run on a small pool of host threads ("zk-tail"; round 5: rounds 2-4 started a std::async thread
+// per multiplication - six thread creations per proof, 2,400 a second in a stream).  Tasks are ~0.15 ms (fixed-base, with the key's
+// tables) or ~0.5 ms (s A, r B1: variable base); six threads serve the ~1.5 ms of them a proof needs at any rate one GPU sustains.
+namespace {
+class TailPool {
+ public:
+  // (never destroyed: its workers sleep on the condition variable for the life of the process, and destroying a condition variable
+  //  that has waiters - what a static object's destructor would do at exit - blocks)
+  static TailPool& get() { static TailPool* p = new TailPool(); return *p; }
+  std::future<host::HJac> run(std::function<host::HJac()> fn) {
+    auto task = std::make_shared<std::packaged_task<host::HJac()>>(std::move(fn));
+    std::future<host::HJac> f = task->get_future();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      q_.push_back([task] { (*task)(); });
+    }
+    cv_.notify_one();
+    return f;
+  }
+ private:
+  TailPool() {
+    const char* e = getenv("ZKHIP_TAIL_THREADS");
+    int n = e ? atoi(e) : 6;
+    if (n < 1 || n > 64) n = 6;
+    for (int i = 0; i < n; i++) {
+      std::thread([this] {
+        pthread_setname_np(pthread_self(), "zk-tail");
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return !q_.empty(); });
+            job = std::move(q_.front());
+            q_.pop_front();
+          }
+          job();
+        }
+      }).detach();                 // (process-lifetime workers: they sleep on the queue)
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> q_;
+};
+}  // namespace
 static std::future<host::HJac> tail_smul(host::HJac p, const uint64_t* k) {
-  return std::async(std::launch::async, [p, k]() { return p.mul_canonical(k, 6); });
+  return TailPool::get().run([p, k]() { return p.mul_canonical(k, 6); });
 }
-static void tail_begin(TailPre& tp, const uint64_t delta_g1[24], const uint64_t delta_g2[24], const uint64_t r_m[6], const uint64_t s_m[6]) {
+// tab: the key's fixed-base tables (null: the plain zkhip_groth16_finish, which is handed raw points: variable-base products)
+static void tail_begin(TailPre& tp, const uint64_t delta_g1[24], const uint64_t delta_g2[24], const uint64_t r_m[6], const uint64_t s_m[6],
+                       const TailTables* tab = nullptr) {
   using namespace host;
   HFr r = HFr::from_limbs(r_m), s = HFr::from_limbs(s_m), rs = r * s;
   r.to_canonical(tp.rc_); s.to_canonical(tp.sc_); rs.to_canonical(tp.rsc_);
-  auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
-  const HJac d1 = aff(delta_g1), d2 = aff(delta_g2);
-  tp.rd1 = tail_smul(d1, tp.rc_); tp.sd2 = tail_smul(d2, tp.sc_); tp.sd1 = tail_smul(d1, tp.sc_); tp.rsd1 = tail_smul(d1, tp.rsc_);
+  if (tab) {
+    const uint64_t *rc = tp.rc_, *sc = tp.sc_, *rsc = tp.rsc_;
+    tp.rd1 = TailPool::get().run([tab, rc] { return tab->d1.mul(rc); });
+    tp.sd2 = TailPool::get().run([tab, sc] { return tab->d2.mul(sc); });
+    tp.sd1 = TailPool::get().run([tab, sc] { return tab->d1.mul(sc); });
+    tp.rsd1 = TailPool::get().run([tab, rsc] { return tab->d1.mul(rsc); });
+  } else {
+    auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
+    const HJac d1 = aff(delta_g1), d2 = aff(delta_g2);
+    tp.rd1 = tail_smul(d1, tp.rc_); tp.sd2 = tail_smul(d2, tp.sc_); tp.sd1 = tail_smul(d1, tp.sc_); tp.rsd1 = tail_smul(d1, tp.rsc_);
+  }
   tp.started = true;
+}
+// the key's tables for r delta_1, s delta_1, r s delta_1, s delta_2 (built once, by the key's first proof)
+static const TailTables* crs_tail_tables(const zkhip_crs* c) {
+  std::call_once(c->tail_once, [c] {
+    using namespace host;
+    auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
+    std::unique_ptr<TailTables> t(new TailTables());
+    t->d1.build(aff(c->delta_g1));
+    t->d2.build(aff(c->delta_g2));
+    c->tail = std::move(t);
+  });
+  return c->tail.get();
 }
 
 static int finish_impl(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
@@ -956,7 +1033,7 @@ int zkhip_groth16_prove(const zkhip_crs* crs, zkhip_r1cs* r1cs, const uint64_t* 
     const size_t m = r1cs->dev->n_vars, l = r1cs->dev->n_primary, d = r1cs->dev->d;
     if (crs->A->len != m || crs->H->len != d - 1 || crs->L->len != m - l - 1) return fail(ZKHIP_ERR_ARG, "proving key and constraint system do not match");
     { int rc_ = prove_check(crs, r1cs->dev, 0, 0, 0); if (rc_ != ZKHIP_OK) return rc_; }
-    tail_begin(pre, crs->delta_g1, crs->delta_g2, r_m, s_m);       // the key-only part of the tail runs under the device work
+    tail_begin(pre, crs->delta_g1, crs->delta_g2, r_m, s_m, crs_tail_tables(crs));       // the key-only part of the tail runs under the device work
     int rc = prove_partial(g.dev[crs->device].ps, crs, r1cs->dev, z, 0, 0, 0, sums);
     if (rc != ZKHIP_OK) return rc;
   }
@@ -1044,7 +1121,7 @@ static int prover_prove_impl(zkhip_prover* p, const uint64_t* z, const uint64_t*
   { int rc_ = prove_check(c, p->rd, 0, 0, 0); if (rc_ != ZKHIP_OK) return rc_; }
   if (app) { int rc_ = app_check(app, c, z); if (rc_ != ZKHIP_OK) return rc_; }
   TailPre pre;
-  tail_begin(pre, c->delta_g1, c->delta_g2, r_m, s_m);             // the key-only part of the tail runs under the device work
+  tail_begin(pre, c->delta_g1, c->delta_g2, r_m, s_m, crs_tail_tables(c));             // the key-only part of the tail runs under the device work
   int rc = prove_partial(p->ps, p->crs, p->rd, z, 0, 0, 0, sums, d_z, app ? app->d_z_app : nullptr);
   if (rc != ZKHIP_OK) return rc;
   if (app) app_add_points(app, sums);
@@ -1198,7 +1275,7 @@ int zkhip_groth16_prove_app(const zkhip_crs* crs, zkhip_r1cs* r1cs, const zkhip_
     std::lock_guard<std::mutex> lk(g.dev[crs->device].mu);
     { int rc_ = follow_key_domain(crs, r1cs->dev); if (rc_ != ZKHIP_OK) return rc_; }
     { int rc_ = prove_check(crs, r1cs->dev, 0, 0, 0); if (rc_ != ZKHIP_OK) return rc_; }
-    tail_begin(pre, crs->delta_g1, crs->delta_g2, r_m, s_m);
+    tail_begin(pre, crs->delta_g1, crs->delta_g2, r_m, s_m, crs_tail_tables(crs));
     int rc = prove_partial(g.dev[crs->device].ps, crs, r1cs->dev, z_masked, 0, 0, 0, sums, nullptr, app->d_z_app);
     if (rc != ZKHIP_OK) return rc;
   }
