@@ -275,6 +275,9 @@ int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r[6], 
 /* the same with the assignment already in device memory (n_vars x 6 limbs, e.g. from zkhip_gpu_witness_run; must be complete) */
 int zkhip_prover_prove_dev(zkhip_prover* p, const void* d_z, const uint64_t r[6], const uint64_t s[6], uint64_t proof_affine[72]);
 int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]);   /* as zkhip_last_prove_timings, for p's last proof */
+/* 1 if p's last proof was chained (streaming mode, see zkhip_prover_set_streaming): slots [0] and [1] above are then the time it took
+ * to ENQUEUE the upload and the QAP map, and the five MSM slots hold the whole device time of the proof */
+int zkhip_prover_timings_chained(zkhip_prover* p);
 float zkhip_prover_last_accumulate_ms(zkhip_prover* p);          /* as zkhip_last_accumulate_ms, for p's last proof */
 void zkhip_prover_free(zkhip_prover* p);
 /* A prover instance over a SLICE of the key (zkhip_crs_upload_slice[_ex] with the same three offsets): own streams and work space

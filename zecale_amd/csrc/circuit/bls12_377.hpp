@@ -252,7 +252,20 @@ template <class F> inline std::vector<std::vector<std::array<HFr, 2>>> accumulat
       }
     }
   }
-  batch_inv_tree(zs);
+  // With an application's key folded into the recording (witness_tape_build(fixed_vk)) the doubling chain 2^j ABC_k is made of
+  // CONSTANTS: their Z are inverted where they stand (folded by the recorder: no instruction) and only the accumulator's own Z - which
+  // depend on the proofs' inputs - share the one inversion.  Mixed into the same product tree the constants would come back as
+  // computed values, and the doubling chain's variables (2,016 of the batch-2 circuit's) would not fold.  Generic recording: no constants.
+  {
+    std::vector<HFr> var;
+    std::vector<size_t> where;
+    for (size_t i = 0; i < zs.size(); i++) {
+      if (zs[i].is_const()) zs[i] = zs[i].inv();
+      else { var.push_back(zs[i]); where.push_back(i); }
+    }
+    if (!var.empty()) batch_inv_tree(var);
+    for (size_t i = 0; i < where.size(); i++) zs[where[i]] = var[i];
+  }
   size_t at = 0;
   for (size_t k = 0; k < input_bits.size(); k++) {
     out[k].resize(input_bits[k].size());

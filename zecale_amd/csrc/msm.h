@@ -64,6 +64,7 @@ struct MsmCtx {
   uint32_t* aff_scratch;
   size_t m_acc_max;                  // upper bound on the entries that reach k_accumulate (sizes S, T and the slot array)
   float last_accumulate_ms;
+  uint32_t acc_gen;                           // generation of the device's time base when this launch's ev_acc0 was recorded (msm_time_base_reset bumps it)
   float last_acc_begin_ms, last_acc_end_ms;   // the same launch on the device's time base (msm_time_base): lets a caller that keeps
                                               // several MSMs in flight see how their accumulations overlap
   // measurement aid (ZKHIP_DEBUG_DUMP=<dir>, tools/acc_probe.py): per-wave begin / end clocks of k_accumulate and, at collection, a dump

@@ -1336,6 +1336,7 @@ static int choose_aff_levels(size_t m_entries, size_t nb) {
 // lasts ~8 s from the origin, 0.06 ms an hour - a caller that compares intervals re-bases at the start of its timed region.
 static hipEvent_t g_time_base[64];
 static bool g_time_base_made[64];
+static uint32_t g_time_base_gen[64];        // bumped by every reset: an interval whose launch predates the current origin is dropped
 static std::mutex g_time_base_mu;           // plans are made under per-device or per-prover locks: several threads may arrive here
 static hipEvent_t time_base_locked(int dev, bool renew) {
   if (!g_time_base_made[dev] && hipEventCreate(&g_time_base[dev]) != hipSuccess) return nullptr;
@@ -1358,7 +1359,14 @@ int msm_time_base_reset() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   std::lock_guard<std::mutex> lk(g_time_base_mu);
+  g_time_base_gen[dev]++;
   return time_base_locked(dev, true) ? ZKHIP_OK : ZKHIP_ERR_HIP;
+}
+static uint32_t time_base_gen() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lk(g_time_base_mu);
+  return g_time_base_gen[dev];
 }
 
 // ZKHIP_DEBUG_DUMP=<dir>: the last launch's bucket populations and per-wave clocks of k_accumulate, for tools/acc_probe.py
@@ -1389,6 +1397,8 @@ static void read_accumulate_times(MsmCtx* ctx) {
   ctx->last_accumulate_ms = ms;
   hipEvent_t base = msm_time_base();
   float t0 = 0, t1 = 0;
+  // (a launch recorded before the last msm_time_base_reset would be measured against an origin that lies AFTER it: no interval)
+  if (ctx->acc_gen != time_base_gen()) { ctx->last_acc_begin_ms = ctx->last_acc_end_ms = -1.f; return; }
   if (base && hipEventElapsedTime(&t0, base, ctx->ev_acc0) == hipSuccess && hipEventElapsedTime(&t1, base, ctx->ev_acc1) == hipSuccess) {
     ctx->last_acc_begin_ms = t0; ctx->last_acc_end_ms = t1;
   }
@@ -1618,6 +1628,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   BasePtrs bp;
   for (int k = 0; k < MSM_MAX_JOBS; k++) bp.p[k] = jobs[k < K ? k : 0].bases;
   const int bshift = merged ? c - 1 : 31;     // bucket -> job
+  ctx->acc_gen = time_base_gen();
   if (ctx->aff_levels > 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));     // the timed accumulation includes the affine levels
   // ---- batched-affine levels: the sorted list is summed pairwise inside every bucket, ctx->aff_levels times
   const uint32_t *cur_off = ctx->offsets, *cur_cnt = ctx->counts;

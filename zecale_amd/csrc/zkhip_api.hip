@@ -74,6 +74,7 @@ struct ProveState {
   uint64_t* dz = nullptr;
   size_t dz_cap = 0;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool chained_last = false;       // the last proof put upload, QAP map and MSMs on ONE stream without host waits: ms[0..1] are enqueueing times
   float last_accumulate_ms = 0.f;
   float last_acc_interval[2] = {0.f, 0.f};   // begin / end of that launch on the device's time base
   int last_submit_slot = -1;       // zkhip_msm_submit: the slot of the previous submission (its accumulation gates the next one's)
@@ -807,6 +808,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   const bool chain = chain_env && (ps.quad_below || chain_env == 2) && crs->A->table_c > 0 && crs->batch_msms && ps.ctx[ZK_MSM_SLOTS].stream &&
                      ctx_reusable(&ps.ctx[ZK_MSM_SLOTS], ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf, total_finite ? total_finite : 1);
   hipStream_t qst = chain ? ps.ctx[ZK_MSM_SLOTS].stream : ps.st;
+  ps.chained_last = chain;
   if (!d_z_ready) {
     API_HIP(hipMemcpyAsync(ps.dz, z, m * 48, hipMemcpyHostToDevice, qst));
     if (!chain) {
@@ -836,7 +838,15 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     const size_t total = total_finite;
     rc = ensure_ctx(&ps.ctx[ZK_MSM_SLOTS], &ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf, total ? total : 1);
     if (rc == ZKHIP_OK && ps.quad_below) { ps.ctx[ZK_MSM_SLOTS].quad_below = ps.quad_below; ps.ctx[ZK_MSM_SLOTS].one_stream = 1; }
-    if (rc == ZKHIP_ERR_ARG) batched = false;
+    if (rc == ZKHIP_ERR_ARG) {
+      // (a silent performance cliff) the plan's 32-bit entry positions / slice weights do not hold this key's terms at
+      // this window: said once per process, then one launch sequence per MSM
+      static std::atomic<bool> told{false};
+      if (!told.exchange(true))
+        fprintf(stderr, "zkhip: the five MSMs of this key do not fit ONE launch sequence (window %d, %zu terms: 32-bit slice weights); "
+                        "using one sequence per MSM - a larger table window (zkhip_key_opts.window) avoids this\n", tc, total);
+      batched = false;
+    }
     else if (rc != ZKHIP_OK) return rc;
   }
   if (batched) {
@@ -847,7 +857,11 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
                      jobs[j].len == jobs[j].b->len ? jobs[j].b->n_finite : 0};
     auto tl0 = clk::now();
     if ((rc = msm_launch_multi(cx, 5, mj)) == ZKHIP_OK) rc = msm_finish_multi(cx, 5, sums);
-    if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", cx->errbuf); return rc; }
+    if (rc != ZKHIP_OK) {
+      // (a chained proof's stream also carried the upload and the QAP map: their failure surfaces here)
+      snprintf(t_err, sizeof t_err, "%s%s", cx->errbuf, chain ? " [chained proof: this stream also carried the upload of the assignment and the QAP map]" : "");
+      return rc;
+    }
     for (int j = 0; j < 5; j++) ps.ms[2 + j] = ms_since(tl0);
     ps.last_accumulate_ms = cx->last_accumulate_ms;
     return ZKHIP_OK;
@@ -1308,6 +1322,14 @@ int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]) {
   std::lock_guard<std::mutex> lk(p->mu);
   memcpy(out_ms, p->ps.ms, sizeof p->ps.ms);
   return ZKHIP_OK;
+}
+
+// 1: p's last proof was CHAINED (a streaming prover enqueues upload, QAP map and the five MSMs on one stream and waits once): slots [0]
+// and [1] of zkhip_prover_timings then hold the time it took to ENQUEUE those phases, and the MSM slots the whole device time
+int zkhip_prover_timings_chained(zkhip_prover* p) {
+  if (!p) return 0;
+  std::lock_guard<std::mutex> lk(p->mu);
+  return p->ps.chained_last ? 1 : 0;
 }
 
 int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_g2[24], const uint64_t vk_delta_g2[24],

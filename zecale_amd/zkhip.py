@@ -37,7 +37,7 @@ EXPORTS = [
     "zkhip_multi_prover_new", "zkhip_multi_prover_size", "zkhip_multi_prover_prove", "zkhip_multi_prover_timings", "zkhip_multi_prover_free",
     "zkhip_aggregator_app_new", "zkhip_aggregator_app_free", "zkhip_aggregator_app_num_constants", "zkhip_aggregator_app_constants", "zkhip_aggregator_app_mask",
     "zkhip_aggregator_witness_app", "zkhip_groth16_prove_app", "zkhip_prover_prove_app", "zkhip_prover_prove_app_dev", "zkhip_gpu_witness_run_batched_app",
-    "zkhip_aggregator_pipeline_register_app", "zkhip_aggregator_pipeline_app_hits", "zkhip_dispatcher_register_app", "zkhip_device_copy_out", "zkhip_measure_ntt", "zkhip_key_partition",
+    "zkhip_aggregator_pipeline_register_app", "zkhip_aggregator_pipeline_app_hits", "zkhip_dispatcher_register_app", "zkhip_device_copy_out", "zkhip_measure_ntt", "zkhip_key_partition", "zkhip_prover_timings_chained",
 ]
 
 
@@ -848,7 +848,9 @@ class Prover:
     def timings(self):
         t = (ctypes.c_double * 8)()
         _check(load().zkhip_prover_timings(self.handle, t))
-        return dict(zip(["upload_z", "qap", "msm_A", "msm_B2", "msm_B1", "msm_H", "msm_L", "host_tail"], list(t)))
+        out = dict(zip(["upload_z", "qap", "msm_A", "msm_B2", "msm_B1", "msm_H", "msm_L", "host_tail"], list(t)))
+        out["chained"] = bool(load().zkhip_prover_timings_chained(self.handle))       # True: upload_z / qap are enqueueing times
+        return out
 
     def free(self):
         if self.handle:
