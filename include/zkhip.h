@@ -419,6 +419,10 @@ int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int
  * batch of a key or by zkhip_aggregator_pipeline_register_app) and proves that key's batches from masked assignments; this flag (or
  * ZKHIP_NO_APP_CACHE in the environment) turns that off.  The proofs are the same either way. */
 #define ZKHIP_PIPELINE_NO_APP_CACHE 2u
+/* ZKHIP_PIPELINE_HYBRID_WITNESS (with ZKHIP_PIPELINE_GPU_WITNESS) - two host generator threads (ZKHIP_HYBRID_HOST_WORKERS: 1 .. 16) work
+ * the same queue as the GPU batchers: the stream's rate and its host cores land between the two pure modes' (host: the fastest, ~6.5
+ * cores at 420 proofs/s; GPU: ~2 cores, 5 % slower).  Results are the same proofs. */
+#define ZKHIP_PIPELINE_HYBRID_WITNESS 4u
 int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, unsigned flags, zkhip_pipeline** out);
 /* replaces: RegisterApplication's part in the prover (aggregator_server.cpp:170-235 stores the key; here its constants are computed,
  * ~0.2 s, so that the application's first batch does not pay for them).  ZKHIP_ERR_ARG: a key with a point off its curve. */

@@ -167,3 +167,61 @@ def test_degenerate_key_gets_no_handle_and_is_still_proved(zk):
     assert (proof == zk.groth16_prove(crs, r1, z, fr_limbs(5), fr_limbs(6))).all() and (prim == z[1:5]).all()
     assert zk.groth16_verify(kp.vk(), prim, proof) and pipe.app_hits() == 0
     pipe.free(); crs.free(); r1.free(); kp.free(); agg.free()
+
+
+def test_nine_inputs_application(zk):
+    """The Zeth-shaped circuit (nine inputs per nested proof, aggregator_test.cpp:222-254): the handle's constants, the masked proof =
+    the plain proof, and the count the bench reports (the key's 30 variables, its hash and lines, eighteen doubling chains)."""
+    import bench
+    nvk_l, npr, nin, trapdoor = bench.aggregator_inputs(9)
+    agg = zk.AggregatorCircuit(2, 9)
+    desc = zk.r1cs_desc_from_aggregator(agg)
+    kp = zk.Keypair(desc, *trapdoor)
+    crs, r1 = kp.upload_crs(zk.key_opts(table_naf=True)), zk.r1cs_from_desc(desc)
+    app = zk.AggregatorApp(agg, crs, nvk_l)
+    pos, val, h, pts = app.constants()
+    print("nine inputs: constants per application: %d of %d variables" % (len(pos), agg.num_variables))
+    z = agg.witness(nvk_l, npr, nin)
+    assert (z[pos] == val).all() and len(pos) > 20000
+    zm = app.witness(npr, nin)
+    assert (zm == app.mask(z)).all()
+    rs = random_fr_uniform(99, 2)
+    plain = zk.groth16_prove(crs, r1, z, rs[0], rs[1])
+    assert (app.prove(r1, zm, rs[0], rs[1]) == plain).all()
+    assert zk.groth16_verify(kp.vk(), z[1:1 + agg.num_primary_inputs()], plain)
+    app.free(); crs.free(); r1.free(); kp.free(); agg.free()
+
+
+def test_hybrid_witness_and_dispatcher_registration(zk):
+    """ZKHIP_PIPELINE_HYBRID_WITNESS: host generators and GPU batchers on one queue - every proof equals the plain serial proof whichever
+    generator produced its assignment; zkhip_dispatcher_register_app registers the application on every entry of a device list."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
+    pipe = zk.AggregatorPipeline(agg, crs, gpu_slots=3, witness_workers=2, gpu_witness=True, hybrid=True)
+    pipe.register_app(nvk_l)
+    jobs = []
+    for i in range(40):
+        npr, nin = _batch(proofs, i % 6, (i * 5 + 1) % 6, int(i % 7 == 3))
+        r, s = fr_limbs(0x1000 + i), fr_limbs(0x2000 + 3 * i)
+        jobs.append((npr, nin, r, s, pipe.submit(nvk_l, npr, nin, r, s)))
+    for npr, nin, r, s, t in jobs:
+        prim, proof = pipe.wait(t)
+        z = agg.witness(nvk_l, npr, nin)
+        assert (prim == z[1:1 + agg.num_primary_inputs()]).all()
+        assert (proof == zk.groth16_prove(crs, r1, z, r, s)).all()
+    assert pipe.app_hits() == 40
+    pipe.free()
+    disp = zk.AggregatorDispatcher(agg, kp, [0, 0], zk.key_opts(table_naf=False), gpu_slots=2, witness_workers=2)
+    disp.register_app(nvk_l)
+    npr, nin = _batch(proofs, 0, 1)
+    ts = [disp.submit(nvk_l, npr, nin, fr_limbs(3), fr_limbs(4)) for _ in range(4)]
+    z = agg.witness(nvk_l, npr, nin)
+    want = zk.groth16_prove(crs, r1, z, fr_limbs(3), fr_limbs(4))
+    for t in ts:
+        prim, proof = disp.wait(t)
+        assert (proof == want).all()
+    bad = nvk_l.copy(); bad[6] ^= np.uint64(1)
+    with pytest.raises(zk.ZkhipError):
+        disp.register_app(bad)                     # off-curve key: refused on the first entry
+    disp.free()
+    crs.free(); r1.free(); kp.free(); agg.free()

@@ -42,3 +42,4 @@ with open(os.path.join(o, "summary.csv"), "w") as f:
 print(open(os.path.join(o, "summary.csv")).read())
 print(open(os.path.join(o, "trace.log")).read()[-3000:])
 PYEOF
+find $O -name "*kernel_trace.csv" -delete 2>/dev/null; find $O -name "*.db" -delete 2>/dev/null

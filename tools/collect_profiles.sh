@@ -11,7 +11,9 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 [ -x $ROOT/build/fetch_calib ] || hipcc --offload-arch=gfx950 -O3 -o $ROOT/build/fetch_calib $ROOT/tools/ubench/fetch_calib.hip
 cd /tmp && export TMPDIR=/tmp
-run() { name=$1; shift; timeout -k 10 500 rocprofv3 "$@" > $OUT/$name.log 2>&1; echo "$name done"; }
+# (the per-dispatch traces of the full bench are tens of MiB each and gpurun copies back at most 64 MiB: only the --stats summaries and
+#  the counter tables are kept)
+run() { name=$1; shift; timeout -k 10 500 rocprofv3 "$@" > $OUT/$name.log 2>&1; find $OUT/$name -name "*kernel_trace.csv" -delete 2>/dev/null; find $OUT/$name -name "*.db" -delete 2>/dev/null; echo "$name done"; }
 run msm_trace        --kernel-trace --stats --output-format csv -d $OUT/msm_trace -o msm -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5
 run msm_only_trace   --kernel-trace --stats --output-format csv -d $OUT/msm_only_trace -o msm -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary
 run msm_serial_trace --kernel-trace --stats --output-format csv -d $OUT/msm_serial_trace -o msm -- python3 $ROOT/bench.py --serial --steps 10 --warmup 2 --no-cpu-baseline --no-secondary

@@ -351,6 +351,14 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
   }
   for (int i = 0; i < witness_workers; i++) p->threads.emplace_back(p->gpu_witness ? gpu_witness_loop : witness_loop, p);
   if (p->gpu_witness) p->threads.emplace_back(host_fallback_loop, p);
+  // HYBRID (ZKHIP_PIPELINE_HYBRID_WITNESS with ZKHIP_PIPELINE_GPU_WITNESS): host generators beside the GPU batchers, on the same queue - a
+  // host worker takes one batch at a time, a batcher up to wit_batch of one key.  The host share sets the host cores: every host
+  // worker adds ~150 witnesses/s for ~2 cores; the batchers take the rest (the stream's rate between the two pure modes').
+  if (p->gpu_witness && (flags & ZKHIP_PIPELINE_HYBRID_WITNESS)) {
+    int hw = 2;
+    if (const char* e = getenv("ZKHIP_HYBRID_HOST_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 16) hw = v; }
+    for (int i = 0; i < hw; i++) p->threads.emplace_back(witness_loop, p);
+  }
   for (zkhip_prover* pr : p->provers) p->threads.emplace_back(gpu_loop, p, pr);
   *out = p;
   return ZKHIP_OK;

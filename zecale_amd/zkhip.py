@@ -862,13 +862,13 @@ class AggregatorPipeline:
     """Streaming aggregator_circuit::prove (zkhip_aggregator_pipeline_*): submit() returns a ticket at once, wait(ticket)
     returns (primary_inputs, proof).  Witness generation, the GPU prover and the host tail of successive batches overlap."""
 
-    def __init__(self, agg, crs, gpu_slots=2, witness_workers=2, gpu_witness=False, app_cache=True):
+    def __init__(self, agg, crs, gpu_slots=2, witness_workers=2, gpu_witness=False, app_cache=True, hybrid=False):
         """app_cache: keep a zkhip_aggregator_app per nested key seen and prove its batches from masked assignments (default; the
-        proofs are the same either way)."""
+        proofs are the same either way).  hybrid (with gpu_witness): two host generators beside the GPU batchers."""
         h = ctypes.c_void_p()
         lib = load()
         lib.zkhip_aggregator_pipeline_new_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]
-        flags = (1 if gpu_witness else 0) | (0 if app_cache else 2)
+        flags = (1 if gpu_witness else 0) | (0 if app_cache else 2) | (4 if (hybrid and gpu_witness) else 0)
         _check(lib.zkhip_aggregator_pipeline_new_ex(agg.handle, crs.handle, gpu_slots, witness_workers, flags, ctypes.byref(h)))
         self.handle, self._agg, self._crs = h, agg, crs
         self.n_primary = agg.num_primary_inputs()
