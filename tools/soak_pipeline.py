@@ -1,6 +1,8 @@
 """Soak run of the streaming prover on the GPU box: N batches with varying nested proofs, inputs (some bumped -> invalid nested
 proof -> result bit 0) and (r, s); every wrapping proof is verified with the host pairing verifier and its public inputs checked.
-Usage: python tools/soak_pipeline.py [N] [gpu]      ("gpu": the assignments are generated on the GPU)"""
+Usage: python tools/soak_pipeline.py [N] [gpu] [hybrid] [nocache] [twokeys]
+  gpu: assignments generated on the GPU; hybrid: two host generators beside it; nocache: per-application constants off;
+  twokeys: every third batch belongs to a SECOND application (the fixture's key with ABC_0 / ABC_1 exchanged: result bits 0)"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +21,10 @@ agg = zkhip.AggregatorCircuit(2, 1)
 kp = zkhip.Keypair(zkhip.r1cs_desc_from_aggregator(agg), *trapdoor)
 vk, crs = kp.vk(), kp.upload_crs()
 GPU_WITNESS = "gpu" in sys.argv[2:]
-pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=14, witness_workers=2 if GPU_WITNESS else 8, gpu_witness=GPU_WITNESS)
+HYBRID, NOCACHE, TWOKEYS = "hybrid" in sys.argv[2:], "nocache" in sys.argv[2:], "twokeys" in sys.argv[2:]
+nvk2 = nvk.copy()
+nvk2[60:72], nvk2[72:84] = nvk[72:84], nvk[60:72]
+pipe = zkhip.AggregatorPipeline(agg, crs, gpu_slots=14, witness_workers=2 if GPU_WITNESS else 8, gpu_witness=GPU_WITNESS, app_cache=not NOCACHE, hybrid=HYBRID)
 rng = np.random.default_rng(1)
 rs = bench.random_fr_canonical(77, 2 * N)
 jobs, bad, t0 = [], 0, time.time()
@@ -35,7 +40,10 @@ for i in range(N):
             nin[p] = np.array(E.fr_from_json(hex(x)), dtype=np.uint64)
         else:
             expect |= 1 << p
-    jobs.append((pipe.submit(nvk, np.concatenate([txs[a][1], txs[b][1]]), nin, rs[2 * i], rs[2 * i + 1]), expect, nin))
+    key = nvk2 if (TWOKEYS and i % 3 == 2) else nvk
+    if key is nvk2:
+        expect = 0                                   # the fixtures' proofs do not verify under the second key
+    jobs.append((pipe.submit(key, np.concatenate([txs[a][1], txs[b][1]]), nin, rs[2 * i], rs[2 * i + 1]), expect, nin))
     if len(jobs) > (96 if GPU_WITNESS else 32):
         t, exp, nin_ = jobs.pop(0)
         prim, proof = pipe.wait(t)
@@ -47,6 +55,7 @@ while jobs:
     ok = zkhip.groth16_verify(vk, prim, proof) and int(E.fr_to_json(prim[1]), 16) == exp and (prim[2:] == nin_.reshape(-1, 6)).all()
     bad += 0 if ok else 1
 dt = time.time() - t0
-print(f"soak ({'GPU' if GPU_WITNESS else 'host'} witness): {N} wrapping proofs in {dt:.1f} s ({N/dt:.1f} proofs/s including host verification of each), failures: {bad}")
+hits = pipe.app_hits()
+print(f"soak ({'GPU' if GPU_WITNESS else 'host'} witness{', hybrid' if HYBRID else ''}{', no cache' if NOCACHE else ''}{', two applications' if TWOKEYS else ''}; {hits} batches from an application's constants): {N} wrapping proofs in {dt:.1f} s ({N/dt:.1f} proofs/s including host verification of each), failures: {bad}")
 pipe.free(); crs.free(); kp.free(); agg.free()
 sys.exit(1 if bad else 0)

@@ -388,7 +388,12 @@ int zkhip_aggregator_pipeline_register_app(zkhip_pipeline* p, const uint64_t* ne
   if (!p || !nested_vk) return ZKHIP_ERR_ARG;
   if (!p->app_cache) return ZKHIP_OK;
   std::vector<uint64_t> vk(nested_vk, nested_vk + p->vk_words);
-  return find_app(p, vk, true) ? ZKHIP_OK : ZKHIP_ERR_ARG;
+  if (find_app(p, vk, true)) return ZKHIP_OK;
+  // no handle: the key could not be given one (a point off its curve, a degenerate key: ZKHIP_ERR_ARG - its batches will be proved by
+  // the plain path and report their own errors), or the pipeline's table of applications is full (the cache is best effort: OK)
+  std::lock_guard<std::mutex> lk(p->mu_apps);
+  auto it = p->apps.find(vk);
+  return (it != p->apps.end() && it->second->state == 2) ? ZKHIP_ERR_ARG : ZKHIP_OK;
 }
 size_t zkhip_aggregator_pipeline_app_hits(const zkhip_pipeline* p) { return p ? (size_t)p->st_app_hits.load() : 0; }
 
