@@ -253,7 +253,7 @@ class GpuProver:
     """The wrapping prover behind the service: circuit, keypair (file or fresh setup), HBM-resident key, streaming pipeline."""
     snark_name = "GROTH16"
 
-    def __init__(self, keypair_file=None, device=0, gpu_slots=24, witness_workers=10, gpu_witness=False, devices=None):
+    def __init__(self, keypair_file=None, device=0, gpu_slots=24, witness_workers=10, gpu_witness=False, devices=None, hybrid_witness=False):
         """devices: the GPUs of the node this ONE server process drives (the reference server is one process that owns its prover:
         aggregator_server.cpp:106-118, 390-416) - a resident copy of the key and a streaming pipeline on each, behind a dispatcher
         (zkhip_dispatcher_*); an index may repeat (two contexts on one GPU).  None / one entry: that GPU alone (`device`)."""
@@ -283,10 +283,11 @@ class GpuProver:
         if len(devices) > 1:
             self.crs = None                               # (the dispatcher uploads a copy of the key to every entry of the list)
             self.pipe = zkhip.AggregatorDispatcher(self.agg, self.kp, devices, opts, gpu_slots=gpu_slots, witness_workers=witness_workers,
-                                                   gpu_witness=gpu_witness)
+                                                   gpu_witness=gpu_witness or hybrid_witness, hybrid=hybrid_witness)
         else:
             self.crs = self.kp.upload_crs(opts)
-            self.pipe = zkhip.AggregatorPipeline(self.agg, self.crs, gpu_slots=gpu_slots, witness_workers=witness_workers, gpu_witness=gpu_witness)
+            self.pipe = zkhip.AggregatorPipeline(self.agg, self.crs, gpu_slots=gpu_slots, witness_workers=witness_workers,
+                                                 gpu_witness=gpu_witness or hybrid_witness, hybrid=hybrid_witness)
 
     def verification_key_json(self):
         return E.verification_key_to_json(self.vk)
@@ -519,10 +520,12 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--devices", default="", help="comma list of GPUs this one process drives (replicas behind a dispatcher), e.g. 0,1,2,3,4,5,6,7; "
                                                   "overrides --device")
-    ap.add_argument("--gpu-witness", action="store_true", help="generate the assignments on the GPU (fewer host cores per GPU)")
+    ap.add_argument("--gpu-witness", action="store_true", help="generate the assignments on the GPU: a third of the host cores per GPU (the faster mode "
+                                                               "too when the host is slow or busy, and for circuits with many inputs per nested proof)")
+    ap.add_argument("--hybrid-witness", action="store_true", help="two host generators beside the GPU generator")
     args = ap.parse_args(argv)
     print("[INFO] Init params of both curves")
-    prover = GpuProver(args.keypair, device=args.device, gpu_witness=args.gpu_witness,
+    prover = GpuProver(args.keypair, device=args.device, gpu_witness=args.gpu_witness, hybrid_witness=args.hybrid_witness,
                        devices=[int(x) for x in args.devices.split(",")] if args.devices else None)
     print("[INFO] Circuit has %d constraints" % prover.agg.num_constraints)
     print("[INFO] Setup successful, starting the server...")

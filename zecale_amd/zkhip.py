@@ -917,13 +917,14 @@ class AggregatorDispatcher:
     `devices` (an index may repeat: two contexts on one GPU), every batch goes to the entry with the fewest batches outstanding.
     Same submit / wait as AggregatorPipeline.  keypair: a Keypair (its proving half is uploaded to every entry)."""
 
-    def __init__(self, agg, keypair, devices, opts=None, gpu_slots=24, witness_workers=10, gpu_witness=False, app_cache=True):
+    def __init__(self, agg, keypair, devices, opts=None, gpu_slots=24, witness_workers=10, gpu_witness=False, app_cache=True, hybrid=False):
         d = CrsDesc()
         _check(load().zkhip_keypair_crs_desc(keypair.handle, ctypes.byref(d)))
         arr, n = _int_list(devices)
         h = ctypes.c_void_p()
         _check(load().zkhip_dispatcher_new(agg.handle, ctypes.byref(d), ctypes.byref(opts) if opts is not None else None, arr, n,
-                                           gpu_slots, witness_workers, (1 if gpu_witness else 0) | (0 if app_cache else 2), ctypes.byref(h)))
+                                           gpu_slots, witness_workers, (1 if gpu_witness else 0) | (0 if app_cache else 2) | (4 if (hybrid and gpu_witness) else 0),
+                                           ctypes.byref(h)))
         self.handle, self._agg, self._kp = h, agg, keypair
         self.n_primary = agg.num_primary_inputs()
         self.size = n
