@@ -58,7 +58,8 @@ extern "C" int zkhip_bls12_377_groth16_verify(const uint64_t vk_alpha_g1[12], co
 namespace {
 
 // assignment only, sections on separate threads
-void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const NestedData* data) {
+void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const NestedData* data, size_t n_vars_hint = 0) {
+  const size_t section_cap = n_vars_hint ? n_vars_hint / (num_proofs ? num_proofs : 1) + 64 : 0;
   Builder b0;
   current_builder() = &b0;
   Inputs<WV> in;
@@ -73,6 +74,7 @@ void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const Ne
     try {
       Builder bs;
       bs.z.clear();                                     // a section holds no constant ONE of its own
+      bs.z.reserve(section_cap);                        // (one allocation per section, not one per doubling of the vector)
       current_builder() = &bs;
       if (s == 0) results[s] = section_hash(in).value();
       else if (s == 1) vk_precompute(in.vk);
@@ -89,6 +91,7 @@ void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const Ne
   for (auto& t : th) t.join();
   for (auto& e : errs) if (e) std::rethrow_exception(e);
   z = std::move(b0.z);
+  if (n_vars_hint) z.reserve(n_vars_hint);
   for (auto& p : parts) z.insert(z.end(), p.begin(), p.end());
   z[1] = results[0];
   HFr packed = HFr::zero(), pow2 = HFr::one();
@@ -114,6 +117,7 @@ void witness_proofs_only(std::vector<HFr>& z, const zkhip_aggregator* a, const N
     try {
       Builder bs;
       bs.z.clear();
+      bs.z.reserve((a->n_vars - a->sec_proofs) / num_proofs + 64);
       current_builder() = &bs;
       results[p] = section_proof(in, p, k).value();
       current_builder() = nullptr;
@@ -127,6 +131,7 @@ void witness_proofs_only(std::vector<HFr>& z, const zkhip_aggregator* a, const N
   for (auto& e : errs) if (e) std::rethrow_exception(e);
   z = std::move(b0.z);
   if (z.size() != a->sec_hash) throw std::runtime_error("assignment layout changed");
+  z.reserve(a->n_vars);
   z.resize(a->sec_proofs, HFr::zero());                 // the hash and key sections: the application's constants, left at zero
   for (auto& p : parts) z.insert(z.end(), p.begin(), p.end());
   HFr packed = HFr::zero(), pow2 = HFr::one();
@@ -199,7 +204,7 @@ int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, con
   std::vector<HFr> z;                  // re-entrant: the circuit description is read-only after zkhip_aggregator_new
   NestedData d{nested_vk, nested_proofs, nested_inputs};
   try {
-    witness_parallel(z, a->num_proofs, a->inputs_per_proof, &d);
+    witness_parallel(z, a->num_proofs, a->inputs_per_proof, &d, a->n_vars);
   } catch (const std::exception&) {
     current_builder() = nullptr;
     return ZKHIP_ERR_ARG;

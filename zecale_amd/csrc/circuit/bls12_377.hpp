@@ -175,7 +175,6 @@ template <class F> struct NestedProof { G1<F> a; G2<F> b; G1<F> c; };
 
 template <class F> inline G2<F> g2_neg(const G2<F>& p) { return G2<F>{p.x, p.y.neg()}; }
 
-#ifdef ZK_CIRCUIT_FR
 // The recorded witness program (witness_tape.cpp) must not contain the accumulator's chain of 2 x 253 dependent inversions - an
 // inversion costs a GPU lane what thirty multiplications do and a level of the program waits for it.  The denominators of the
 // slopes are therefore derived from a Jacobian run of the same two chains (the doublings pw_j = 2^j ABC_k, the conditional
@@ -183,7 +182,9 @@ template <class F> inline G2<F> g2_neg(const G2<F>& p) { return G2<F>{p.x, p.y.n
 //   x(pw_j) - x(acc_j) = H_j / (Za Zp)^2      so  1 / (...) = (Za Zp)^3 / Zs_j       (Zs_j = Za Zp H_j, the Z of the Jacobian sum)
 //   2 y(pw_j)          = 2 Yp / Zp^3          so  1 / (...) = Zp^4 / Zp_{j+1}        (Zp_{j+1} = 2 Yp Zp, the Z of the double)
 // and every Zs_j, Zp_{j+1} of the accumulator is inverted in ONE inversion (a product tree).  The same field elements as the
-// affine chain of the host generator computes, by another route.
+// affine chain computes, by another route.  Round 5: the HOST generator takes this route too (253 inversions of 4.7 us per input and
+// proof section were a fifth of its time: one inversion and ~7 k products instead) - unless a Z of the run is zero (degenerate
+// points: pw = +-acc), where it keeps the affine chain with its zero-stays-zero inversions.
 struct JacH { HFr X, Y, Z; };
 inline JacH jac_dbl(const JacH& p) {                       // y^2 = x^3 + b
   HFr A = p.X * p.X, B = p.Y * p.Y, C = B * B;
@@ -256,6 +257,7 @@ template <class F> inline std::vector<std::vector<std::array<HFr, 2>>> accumulat
   // CONSTANTS: their Z are inverted where they stand (folded by the recorder: no instruction) and only the accumulator's own Z - which
   // depend on the proofs' inputs - share the one inversion.  Mixed into the same product tree the constants would come back as
   // computed values, and the doubling chain's variables (2,016 of the batch-2 circuit's) would not fold.  Generic recording: no constants.
+#ifdef ZK_CIRCUIT_FR
   {
     std::vector<HFr> var;
     std::vector<size_t> where;
@@ -266,6 +268,10 @@ template <class F> inline std::vector<std::vector<std::array<HFr, 2>>> accumulat
     if (!var.empty()) batch_inv_tree(var);
     for (size_t i = 0; i < where.size(); i++) zs[where[i]] = var[i];
   }
+#else
+  for (const HFr& zv : zs) if (zv.is_zero()) return {};          // a degenerate step: the caller keeps the affine chain
+  batch_inv_tree(zs);
+#endif
   size_t at = 0;
   for (size_t k = 0; k < input_bits.size(); k++) {
     out[k].resize(input_bits[k].size());
@@ -276,24 +282,26 @@ template <class F> inline std::vector<std::vector<std::array<HFr, 2>>> accumulat
   }
   return out;
 }
-#endif
 
 // acc = ABC_0 + sum_j bits_j (2^j ABC_1) ...: one input, bits little-endian
 template <class F> inline G1<F> input_accumulator(const NestedVk<F>& vk, const std::vector<std::vector<F>>& input_bits) {
+  const auto den = accumulator_denominators(vk, input_bits);       // (host build: empty when a step is degenerate)
 #ifdef ZK_CIRCUIT_FR
-  const auto den = accumulator_denominators(vk, input_bits);
+  const bool have_den = true;
+#else
+  const bool have_den = !den.empty() || input_bits.empty();
 #endif
   G1<F> acc = vk.abc[0];
   for (size_t k = 0; k < input_bits.size(); k++) {
     G1<F> pw = vk.abc[k + 1];
     for (size_t j = 0; j < input_bits[k].size(); j++) {
       const bool more = j + 1 < input_bits[k].size();
-#ifdef ZK_CIRCUIT_FR
-      HFr dinv[2] = {den[k][j][0], den[k][j][1]};
-#else
-      HFr dinv[2] = {(pw.x - acc.x).value(), (pw.y + pw.y).value()};      // denominators of the addition and of the doubling
-      batch_inv(dinv, more ? 2 : 1);
-#endif
+      HFr dinv[2];
+      if (have_den) { dinv[0] = den[k][j][0]; dinv[1] = den[k][j][1]; }
+      else {
+        dinv[0] = (pw.x - acc.x).value(); dinv[1] = (pw.y + pw.y).value();      // denominators of the addition and of the doubling
+        batch_inv(dinv, more ? 2 : 1);
+      }
       G1<F> s = g1_add(acc, pw, &dinv[0]);
       acc = g1_select(input_bits[k][j], s, acc);
       if (more) pw = g1_dbl(pw, &dinv[1]);

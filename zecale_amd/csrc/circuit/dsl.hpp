@@ -211,6 +211,11 @@ struct WV {
   static void assert_product(const WV&, const WV&, const WV&) {}
 };
 inline bool f_is_const(const WV& x) { return x.cst; }
+// F only replays values (WV): a gadget's assertions are no-ops there, and so is everything that merely prepares their arguments -
+// linear combinations and multiplications by constants allocate nothing, so skipping them leaves the allocation order alone
+// (round 5: in the host generator a third of a cyclotomic squaring's products fed assertions that do nothing)
+template <class F> struct witness_only { static constexpr bool value = false; };
+template <> struct witness_only<WV> { static constexpr bool value = true; };
 
 // helpers shared by the instantiations
 template <class F> inline F f_const_u64(uint64_t x) { return F::constant(HFr::from_u64(x)); }

@@ -42,11 +42,12 @@ struct Fq2 {
 
 // native value helpers on Fq2 (for witnesses)
 struct V2 { HFr a, b; };
-inline V2 v2_mul(const V2& x, const V2& y) {
+inline HFr fr_times5(const HFr& v) { HFr t = v + v; t = t + t; return t + v; }              // three additions, not a product
+inline V2 v2_mul(const V2& x, const V2& y) {                                               // u^2 = -5: three products (Karatsuba)
   HFr v0 = x.a * y.a, v1 = x.b * y.b;
-  return V2{v0 - v1 * HFr::from_u64(5), (x.a + x.b) * (y.a + y.b) - v0 - v1};
+  return V2{v0 - fr_times5(v1), (x.a + x.b) * (y.a + y.b) - v0 - v1};
 }
-inline HFr v2_norm(const V2& x) { return x.a * x.a + x.b * x.b * HFr::from_u64(5); }      // a^2 + 5 b^2
+inline HFr v2_norm(const V2& x) { return x.a * x.a + fr_times5(x.b * x.b); }               // a^2 + 5 b^2
 // ninv: the inverse of the norm if the caller already has it (batch_inv), else null
 inline V2 v2_inv(const V2& x, const HFr* ninv = nullptr) {
   HFr ni;
@@ -64,6 +65,7 @@ template <class F> inline bool fq2_is_const(const Fq2<F>& x) { return f_is_const
 //   x0 y0 = t0 + 5 v1,   (x0 + x1)(y0 + y1) = t1 + t0 + 6 v1          (3 constraints, like a Karatsuba product)
 template <class F> inline void fq2_assert_mul(const Fq2<F>& x, const Fq2<F>& y, const Fq2<F>& t) {
   F v1 = x.c1 * y.c1;
+  if (witness_only<F>::value) return;                      // (the variable above is allocated either way)
   F::assert_product(x.c0, y.c0, t.c0 + v1.mulc(HFr::from_u64(5)));
   F::assert_product(x.c0 + x.c1, y.c0 + y.c1, t.c1 + t.c0 + v1.mulc(HFr::from_u64(6)));
 }
@@ -144,11 +146,52 @@ struct Fq12 {
 };
 
 // native product of coefficient vectors: full 23-coefficient product
+#ifdef ZK_CIRCUIT_FR
+// (the recording build: every product and sum is an instruction of the GPU generator's program; products by the structural zeros of a
+//  line are folded by the recorder)
 inline void v12_full_product(const HFr* a, const HFr* b, HFr* c /*23*/) {
   for (int i = 0; i < 23; i++) c[i] = HFr::zero();
   for (int i = 0; i < 12; i++)
     for (int j = 0; j < 12; j++) c[i + j] = c[i + j] + a[i] * b[j];
 }
+inline void v12_line_product(const HFr* a, const HFr* l, HFr* c /*23*/) { v12_full_product(a, l, c); }
+inline void v12_square(const HFr* a, HFr* c /*23*/) { v12_full_product(a, a, c); }
+#else
+// Host generator (round 5): these products were 40 % of a witness - 378 per proof section, 144 Montgomery products each.  A
+// coefficient of the product is a SUM of products: its terms are accumulated as plain 768-bit integers and reduced ONCE (lazy
+// reduction: 36 limb products per term + 42 per coefficient instead of 78 per term); a LINE has five non-zero coefficients (w^0, w^1,
+// w^3, w^7, w^9: 280 of the 378 products are by a line: 60 terms instead of 144); a square needs each cross term once.  The same
+// field elements, fully reduced: the assignment is unchanged limb for limb (tests/test_aggregator_host.py, tests/test_witness_gpu.py).
+inline void v12_full_product(const HFr* a, const HFr* b, HFr* c /*23*/) {
+  for (int k = 0; k < 23; k++) {
+    uint64_t acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int lo = k > 11 ? k - 11 : 0, hi = k < 11 ? k : 11;
+    for (int i = lo; i <= hi; i++) HFr::mul_wide_add(acc, a[i], b[k - i]);
+    c[k] = HFr::redc_wide(acc);
+  }
+}
+// l: a line - non-zero at the indices below ONLY (line_at, bls12_377.hpp); c[21], c[22] are zero
+inline void v12_line_product(const HFr* a, const HFr* l, HFr* c /*23*/) {
+  static const int LI[5] = {0, 1, 3, 7, 9};
+  for (int k = 0; k < 21; k++) {
+    uint64_t acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j : LI) { const int i = k - j; if (i >= 0 && i < 12) HFr::mul_wide_add(acc, a[i], l[j]); }
+    c[k] = HFr::redc_wide(acc);
+  }
+  c[21] = HFr::zero(); c[22] = HFr::zero();
+}
+inline void v12_square(const HFr* a, HFr* c /*23*/) {
+  for (int k = 0; k < 23; k++) {
+    uint64_t acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int lo = k > 11 ? k - 11 : 0, hi = k < 11 ? k : 11;
+    for (int i = lo; 2 * i < k && i <= hi; i++) HFr::mul_wide_add(acc, a[i], a[k - i]);      // cross terms, once
+    uint64_t carry = 0;                                                                      // ... doubled (at most 6 terms: no overflow)
+    for (int t = 0; t < 12; t++) { const uint64_t w = acc[t]; acc[t] = (w << 1) | carry; carry = w >> 63; }
+    if (!(k & 1) && k / 2 >= lo && k / 2 <= hi) HFr::mul_wide_add(acc, a[k / 2], a[k / 2]);
+    c[k] = HFr::redc_wide(acc);
+  }
+}
+#endif
 
 template <> inline Fq12<NF> fq12_mul_impl<NF>(const Fq12<NF>& a, const Fq12<NF>& b) {
   HFr av[12], bv[12], cv[23];
@@ -182,7 +225,8 @@ template <> inline Fq12<CV> fq12_mul_impl<CV>(const Fq12<CV>& a, const Fq12<CV>&
 template <> inline Fq12<WV> fq12_mul_impl<WV>(const Fq12<WV>& a, const Fq12<WV>& b) {
   HFr av[12], bv[12], cv[23];
   for (int i = 0; i < 12; i++) { av[i] = a.c[i].val; bv[i] = b.c[i].val; }
-  v12_full_product(av, bv, cv);
+  if (&a == &b) v12_square(av, cv);                      // Fq12::sqr()
+  else v12_full_product(av, bv, cv);
   WV cc[23];
   for (int m = 0; m < 23; m++) cc[m] = WV::witness(cv[m]);       // same 23 allocations as the CV version
   Fq12<WV> r;
@@ -219,7 +263,7 @@ template <> inline Fq12<CV> fq12_mul_line<CV>(const Fq12<CV>& a, const Fq12<CV>&
 template <> inline Fq12<WV> fq12_mul_line<WV>(const Fq12<WV>& a, const Fq12<WV>& l) {
   HFr av[12], bv[12], cv[23];
   for (int i = 0; i < 12; i++) { av[i] = a.c[i].val; bv[i] = l.c[i].val; }
-  v12_full_product(av, bv, cv);
+  v12_line_product(av, bv, cv);
   WV cc[FQ12_LINE_PTS];
   for (int m = 0; m < FQ12_LINE_PTS; m++) cc[m] = WV::witness(cv[m]);       // same 21 allocations as the CV version
   Fq12<WV> r;
@@ -247,6 +291,7 @@ template <class F> inline Fq2<F> fq2_mul_u(const Fq2<F>& a) { return Fq2<F>(a.c1
 template <class F> inline Fq2<F> fq2_div_u(const Fq2<F>& a) { return Fq2<F>(a.c1, a.c0.mulc(small_consts().fifth_neg)); }      // (c0 + c1 u) / u
 // enforce a^2 = t for a linear t (2 constraints)
 template <class F> inline void fq2_assert_sqr(const Fq2<F>& a, const Fq2<F>& t) {
+  if (witness_only<F>::value) return;
   const SmallConsts& K = small_consts();
   F::assert_product(a.c0, a.c1, t.c1.mulc(K.half));
   F::assert_product(a.c0 + a.c1, a.c0 - a.c1.mulc(K.five), t.c0 - t.c1.mulc(K.two));
@@ -255,7 +300,7 @@ inline V2 v2_add(const V2& x, const V2& y) { return V2{x.a + y.a, x.b + y.b}; }
 inline V2 v2_sub(const V2& x, const V2& y) { return V2{x.a - y.a, x.b - y.b}; }
 inline V2 v2_dbl(const V2& x) { return V2{x.a + x.a, x.b + x.b}; }
 inline V2 v2_tpl(const V2& x) { return V2{x.a + x.a + x.a, x.b + x.b + x.b}; }
-inline V2 v2_mul_u(const V2& x) { return V2{x.b * small_consts().five_neg, x.a}; }
+inline V2 v2_mul_u(const V2& x) { return V2{fr_times5(x.b).neg(), x.a}; }
 
 // One Fq4 squaring g = a + b s:  g^2 = (a^2 + u b^2) + (2 a b) s.  The caller supplies P (= a^2) and S (= 2 a b) as LINEAR
 // expressions in its own fresh outputs; Q = b^2 is a fresh variable here.  6 constraints.
@@ -276,38 +321,46 @@ template <class F> inline Fq12<F> fq12_cyclotomic_sqr(const Fq12<F>& x) {
   auto val = [](const Fq2<F>& t) { return v2_of(t); };
   Fq2<F> h[6];
   // native values of the three Fq4 squares
-  auto sq = [&](const Fq2<F>& p, const Fq2<F>& q, V2& re, V2& im) {      // (p + q s)^2 = re + im s
-    V2 pp = v2_mul(val(p), val(p)), qq = v2_mul(val(q), val(q)), pq = v2_mul(val(p), val(q));
+  auto sq = [&](const Fq2<F>& p, const Fq2<F>& q, V2& re, V2& im, V2& qq) {      // (p + q s)^2 = re + im s;  qq = q^2
+    V2 pp = v2_mul(val(p), val(p)), pq = v2_mul(val(p), val(q));
+    qq = v2_mul(val(q), val(q));
     re = v2_add(pp, v2_mul_u(qq)); im = v2_add(pq, pq);
   };
-  V2 r0, i0, r1, i1, r2, i2;
-  sq(a[0], a[3], r0, i0); sq(a[1], a[4], r1, i1); sq(a[2], a[5], r2, i2);
+  V2 r0, i0, r1, i1, r2, i2, q0, q1, q2;
+  sq(a[0], a[3], r0, i0, q0); sq(a[1], a[4], r1, i1, q1); sq(a[2], a[5], r2, i2, q2);
+  constexpr bool W = witness_only<F>::value;            // values only: P and S below exist for the assertions alone
   // h0 = 3 g0^2 - 2 conj g0:  (3 r0 - 2 a0) + (3 i0 + 2 a3) s
   {
     V2 hx = v2_sub(v2_tpl(r0), v2_dbl(val(a[0]))), hy = v2_add(v2_tpl(i0), v2_dbl(val(a[3])));
     h[0] = Fq2<F>::witness(hx.a, hx.b); h[3] = Fq2<F>::witness(hy.a, hy.b);
-    Fq2<F> Q = fq4_sqr_witness_q(a[3]);
-    Fq2<F> P = (h[0] + a[0].dbl()).mulc(third) - fq2_mul_u(Q);           // a0^2 = (h0x + 2 a0)/3 - u Q
-    Fq2<F> S = (h[3] - a[3].dbl()).mulc(third);                          // 2 a0 a3 = (h0y - 2 a3)/3
-    fq4_sqr_assert(a[0], a[3], P, Q, S);
+    Fq2<F> Q = Fq2<F>::witness(q0.a, q0.b);                              // a3^2
+    if (!W) {
+      Fq2<F> P = (h[0] + a[0].dbl()).mulc(third) - fq2_mul_u(Q);         // a0^2 = (h0x + 2 a0)/3 - u Q
+      Fq2<F> S = (h[3] - a[3].dbl()).mulc(third);                        // 2 a0 a3 = (h0y - 2 a3)/3
+      fq4_sqr_assert(a[0], a[3], P, Q, S);
+    }
   }
   // h2 = 3 g1^2 - 2 conj g2:  (3 r1 - 2 a2) + (3 i1 + 2 a5) s
   {
     V2 hx = v2_sub(v2_tpl(r1), v2_dbl(val(a[2]))), hy = v2_add(v2_tpl(i1), v2_dbl(val(a[5])));
     h[2] = Fq2<F>::witness(hx.a, hx.b); h[5] = Fq2<F>::witness(hy.a, hy.b);
-    Fq2<F> Q = fq4_sqr_witness_q(a[4]);
-    Fq2<F> P = (h[2] + a[2].dbl()).mulc(third) - fq2_mul_u(Q);
-    Fq2<F> S = (h[5] - a[5].dbl()).mulc(third);
-    fq4_sqr_assert(a[1], a[4], P, Q, S);
+    Fq2<F> Q = Fq2<F>::witness(q1.a, q1.b);                              // a4^2
+    if (!W) {
+      Fq2<F> P = (h[2] + a[2].dbl()).mulc(third) - fq2_mul_u(Q);
+      Fq2<F> S = (h[5] - a[5].dbl()).mulc(third);
+      fq4_sqr_assert(a[1], a[4], P, Q, S);
+    }
   }
   // h1 = 3 s g2^2 + 2 conj g1:  s (r2 + i2 s) = u i2 + r2 s  ->  (3 u i2 + 2 a1) + (3 r2 - 2 a4) s
   {
     V2 hx = v2_add(v2_tpl(v2_mul_u(i2)), v2_dbl(val(a[1]))), hy = v2_sub(v2_tpl(r2), v2_dbl(val(a[4])));
     h[1] = Fq2<F>::witness(hx.a, hx.b); h[4] = Fq2<F>::witness(hy.a, hy.b);
-    Fq2<F> Q = fq4_sqr_witness_q(a[5]);
-    Fq2<F> P = (h[4] + a[4].dbl()).mulc(third) - fq2_mul_u(Q);           // a2^2 = (h1y + 2 a4)/3 - u Q
-    Fq2<F> S = fq2_div_u(h[1] - a[1].dbl()).mulc(third);                  // 2 a2 a5 = (h1x - 2 a1) / (3 u)
-    fq4_sqr_assert(a[2], a[5], P, Q, S);
+    Fq2<F> Q = Fq2<F>::witness(q2.a, q2.b);                              // a5^2
+    if (!W) {
+      Fq2<F> P = (h[4] + a[4].dbl()).mulc(third) - fq2_mul_u(Q);         // a2^2 = (h1y + 2 a4)/3 - u Q
+      Fq2<F> S = fq2_div_u(h[1] - a[1].dbl()).mulc(third);                // 2 a2 a5 = (h1x - 2 a1) / (3 u)
+      fq4_sqr_assert(a[2], a[5], P, Q, S);
+    }
   }
   Fq12<F> r;
   for (int j = 0; j < 6; j++) { r.c[j] = h[j].c0; r.c[j + 6] = h[j].c1; }

@@ -88,6 +88,40 @@ struct HF {
     return r;
   }
   HF sqr() const { return (*this) * (*this); }
+  // Lazy reduction for sums of products (the host witness generator's Fq12 products: 144 products feed 23 coefficients):
+  //   mul_wide_add   acc (2N limbs) += a b, the plain 2N-limb product - half the work of a Montgomery product;
+  //   redc_wide      T -> T / R mod p, fully reduced, for T < p R (R = 2^(64 N)): sums of up to 2^7 products of reduced elements fit
+  //                  (the moduli leave seven spare bits); T is consumed.
+  // sum_i a_i b_i / R through these = the sum of the Montgomery products a_i * b_i, the same fully reduced limbs.
+  static inline void mul_wide_add(uint64_t* acc, const HF& a, const HF& b) {
+#pragma GCC unroll 12
+    for (int i = 0; i < N; i++) {
+      const uint64_t bi = b.v[i];
+      uint64_t c = 0;
+#pragma GCC unroll 12
+      for (int j = 0; j < N; j++) {
+        u128 x = (u128)a.v[j] * bi + acc[i + j] + c;
+        acc[i + j] = (uint64_t)x; c = (uint64_t)(x >> 64);
+      }
+      for (int k = i + N; c && k < 2 * N; k++) { u128 x = (u128)acc[k] + c; acc[k] = (uint64_t)x; c = (uint64_t)(x >> 64); }
+    }
+  }
+  static inline HF redc_wide(uint64_t* T) {
+#pragma GCC unroll 12
+    for (int i = 0; i < N; i++) {
+      const uint64_t m = T[i] * PR::PINV64;
+      uint64_t c = 0;
+#pragma GCC unroll 12
+      for (int j = 0; j < N; j++) {
+        u128 x = (u128)m * PR::P64[j] + T[i + j] + c;
+        T[i + j] = (uint64_t)x; c = (uint64_t)(x >> 64);
+      }
+      for (int k = i + N; c && k < 2 * N; k++) { u128 x = (u128)T[k] + c; T[k] = (uint64_t)x; c = (uint64_t)(x >> 64); }
+    }
+    HF r; memcpy(r.v, T + N, sizeof r.v);
+    if (geq_p(r.v)) sub_p(r.v);
+    return r;
+  }
   // canonical integer (little-endian limbs) of the represented value
   void to_canonical(uint64_t* out) const {
     HF o = zero(); o.v[0] = 1;

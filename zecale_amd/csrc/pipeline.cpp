@@ -19,6 +19,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <malloc.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -307,6 +308,17 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
   zkhip_r1cs_desc desc;
   int rc = zkhip_aggregator_get_r1cs(a, &desc);
   if (rc != ZKHIP_OK) return rc;
+  // A witness is a handful of vectors of 2-5 MB that live for milliseconds.  glibc serves blocks above 128 KiB with mmap and gives
+  // them back with munmap: per proof that is a dozen address-space changes and a thousand page faults, all under the PROCESS's
+  // memory-map lock - which the prover threads also need for every upload from pageable memory.  Measured (round 5, nine inputs per
+  // nested proof, 4.4 MB assignments, ten witness workers): 177 proofs/s, and the MORE workers the fewer (three: 233); with the blocks
+  // kept on the heap and the heap not trimmed after every free, 246 at any number of workers.  So a process that opens a streaming
+  // prover keeps blocks up to 32 MiB (glibc's maximum) on the heap, trims only beyond 512 MiB of free top and grows the heap in 64 MiB
+  // steps (a process-wide allocator setting; ZKHIP_KEEP_MALLOC=1 leaves the allocator alone).
+  if (!getenv("ZKHIP_KEEP_MALLOC")) {
+    static std::once_flag once;
+    std::call_once(once, [] { (void)mallopt(M_MMAP_THRESHOLD, 32 << 20); (void)mallopt(M_TRIM_THRESHOLD, 512 << 20); (void)mallopt(M_TOP_PAD, 64 << 20); });
+  }
   zkhip_pipeline* p = new zkhip_pipeline();
   p->agg = a; p->crs = crs;
   p->app_cache = (flags & ZKHIP_PIPELINE_NO_APP_CACHE) == 0 && !getenv("ZKHIP_NO_APP_CACHE");
