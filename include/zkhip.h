@@ -279,6 +279,7 @@ int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]);   /* as zkhip_last_
  * to ENQUEUE the upload and the QAP map, and the five MSM slots hold the whole device time of the proof */
 int zkhip_prover_timings_chained(zkhip_prover* p);
 float zkhip_prover_last_accumulate_ms(zkhip_prover* p);          /* as zkhip_last_accumulate_ms, for p's last proof */
+int zkhip_prover_last_accumulate_entries(zkhip_prover* p, uint64_t* out);   /* as zkhip_last_accumulate_entries, for p's last proof */
 void zkhip_prover_free(zkhip_prover* p);
 /* A prover instance over a SLICE of the key (zkhip_crs_upload_slice[_ex] with the same three offsets): own streams and work space
  * like any zkhip_prover, so several slices - on several GPUs, or several contexts of one - run side by side.  It only produces
@@ -459,6 +460,10 @@ void zkhip_keypair_free(zkhip_keypair* kp);
 
 /* duration (ms, HIP events on the library's stream) of the dominant kernel of the last MSM */
 float zkhip_last_accumulate_ms(void);
+/* The entries that launch accumulated: the non-zero digits of its scalars = the mixed additions of k_accumulate (a zero scalar, a zero
+ * digit and a base at infinity produce none - a witness of mostly small values has far fewer than terms x digits).  Read back from the
+ * sort's histogram: a measurement aid that synchronises the device (bench.py's roofline numerator); 0 before the first launch. */
+int zkhip_last_accumulate_entries(uint64_t* out);
 /* begin and end of that launch (ms, HIP events) on a per-device time base: a caller that keeps several MSMs in flight
  * (zkhip_msm_submit / collect) can see how their accumulations overlap and take the union of the intervals */
 int zkhip_last_accumulate_interval(float out_ms[2]);

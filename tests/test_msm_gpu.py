@@ -107,6 +107,21 @@ def test_witness_like_scalars(zk, oracle_lib):
     assert (_msm_aff(zk, bases, scal) == O.jac_to_affine(O.msm(bases, scal))).all()
 
 
+def test_the_accumulation_reports_the_entries_it_sorted(zk):
+    """zkhip_last_accumulate_entries (bench.py's roofline numerator for witness-like scalars): zero scalars produce no entry, a scalar
+    of one digit produces one, a full-size scalar one per non-zero window."""
+    n = 2048
+    bases = zk.fixed_base_mul(aff_limbs(R.G1_GEN), random_fr_canonical(61, n), montgomery=False)
+    b = zk.Bases.upload(bases)
+    scal = fr_array([0] * 1000 + [1] * 1048)             # (Montgomery residues)
+    b.msm(scal)
+    assert zk.last_accumulate_entries() == 1048
+    b.msm(random_fr_canonical(62, n), montgomery=False)
+    full = zk.last_accumulate_entries()
+    assert 20 * n < full <= 48 * n              # (c-bit windows over 378 bits, nearly all of them non-zero)
+    b.free()
+
+
 def test_resident_bases_offset_and_reuse(zk, oracle_lib):
     O = oracle_lib
     n = 2048

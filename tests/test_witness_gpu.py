@@ -38,7 +38,7 @@ def test_gpu_witness_equals_host_witness(zk, num_proofs, k, bump):
     dt = time.time() - t
     st = agg.gpu_witness_stats()
     print("GPU witness:", st, "first call %.1f ms" % (dt * 1e3))
-    assert st["multiplications"] > 10000 and st["inversions"] > 100
+    assert st["multiplications"] > 10000 and st["inversions"] > 20      # (54 since the G2 line denominators come from one Jacobian run per point)
     assert (z_gpu == z_host).all(), "first difference at variable %d" % int(np.nonzero((z_gpu != z_host).any(axis=1))[0][0])
     r1 = zk.r1cs_from_desc(zk.r1cs_desc_from_aggregator(agg))
     assert r1.is_satisfied(z_gpu)

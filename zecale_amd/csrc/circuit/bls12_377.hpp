@@ -58,16 +58,88 @@ template <class F> inline G1<F> g1_select(const F& bit, const G1<F>& a, const G1
 template <class F> struct LineCoeffs { Fq2<F> lam, b; };
 template <class F> using G2Lines = std::vector<LineCoeffs<F>>;          // Miller-schedule order: per bit of u a doubling, then an addition if set
 
-// Walks the schedule for several G2 points in lock-step: the slopes of one step need one Fq2 inversion each, all independent, so they
-// share one field inversion (batch_inv).
+// The inverse NORMS of the slope denominators of the schedule below for one G2 point Q, in schedule order, WITHOUT walking the affine
+// chain (round 5): a Jacobian run of the same doublings and additions over Fq2 inverts nothing, and
+//   2 y(T) = 2 Y / Z^3            so  1 / N(2 y(T))       = N(Z)^3 / N(2 Y)
+//   x(Q) - x(T) = (x(Q) Z^2 - X) / Z^2   so  1 / N(x(Q) - x(T)) = N(Z)^2 / N(x(Q) Z^2 - X)         (N = the norm to Fq)
+// - the 69 denominators N(2 Y), N(x(Q) Z^2 - X) of the schedule are then inverted TOGETHER (one inversion, a product tree).  The same
+// field elements as the step-by-step inversions give (69 per proof section: a tenth of the host generator's time, and 69 dependent
+// inversion levels of the GPU generator's program).  false: a denominator is zero (host build; the caller keeps the step-by-step form).
+inline void batch_inv_tree(std::vector<HFr>& v);
+struct JacV2 { V2 X, Y, Z; };
+inline JacV2 jacv2_dbl(const JacV2& p) {                     // y^2 = x^3 + b over Fq2 (dbl-2009-l)
+  V2 A = v2_mul(p.X, p.X), B = v2_mul(p.Y, p.Y), C = v2_mul(B, B);
+  V2 t = v2_add(p.X, B);
+  V2 D = v2_dbl(v2_sub(v2_sub(v2_mul(t, t), A), C));
+  V2 E = v2_add(v2_add(A, A), A), Fv = v2_mul(E, E);
+  JacV2 r;
+  r.X = v2_sub(Fv, v2_dbl(D));
+  r.Y = v2_sub(v2_mul(E, v2_sub(D, r.X)), v2_dbl(v2_dbl(v2_dbl(C))));
+  r.Z = v2_dbl(v2_mul(p.Y, p.Z));
+  return r;
+}
+inline bool g2_schedule_norm_invs(const V2& qx, const V2& qy, std::vector<HFr>& out) {
+  JacV2 T{qx, qy, V2{HFr::one(), HFr::zero()}};
+  std::vector<HFr> den, num;
+  for (int i = 62; i >= 0; i--) {
+    {
+      const HFr nz = v2_norm(T.Z);
+      den.push_back(v2_norm(v2_dbl(T.Y))); num.push_back(nz * nz * nz);
+      T = jacv2_dbl(T);
+    }
+    if ((BLS_U >> i) & 1) {                                   // T + Q, Q affine (madd-2007-bl)
+      const V2 ZZ = v2_mul(T.Z, T.Z);
+      const V2 H = v2_sub(v2_mul(qx, ZZ), T.X);
+      const HFr nz = v2_norm(T.Z);
+      den.push_back(v2_norm(H)); num.push_back(nz * nz);
+      const V2 S2 = v2_mul(qy, v2_mul(T.Z, ZZ));
+      const V2 HH = v2_mul(H, H), I = v2_dbl(v2_dbl(HH)), Jv = v2_mul(H, I), r = v2_dbl(v2_sub(S2, T.Y)), V = v2_mul(T.X, I);
+      JacV2 n;
+      n.X = v2_sub(v2_sub(v2_mul(r, r), Jv), v2_dbl(V));
+      n.Y = v2_sub(v2_mul(r, v2_sub(V, n.X)), v2_dbl(v2_mul(T.Y, Jv)));
+      const V2 zh = v2_add(T.Z, H);
+      n.Z = v2_sub(v2_sub(v2_mul(zh, zh), ZZ), HH);
+      T = n;
+    }
+  }
+#ifdef ZK_CIRCUIT_FR
+  {
+    std::vector<HFr> var;
+    std::vector<size_t> where;
+    for (size_t i = 0; i < den.size(); i++) {
+      if (den[i].is_const()) den[i] = den[i].inv();          // (the generator's lines, an application's key: folded by the recorder)
+      else { var.push_back(den[i]); where.push_back(i); }
+    }
+    if (!var.empty()) batch_inv_tree(var);
+    for (size_t i = 0; i < where.size(); i++) den[where[i]] = var[i];
+  }
+#else
+  for (const HFr& d : den) if (d.is_zero()) return false;
+  batch_inv_tree(den);
+#endif
+  out.resize(den.size());
+  for (size_t i = 0; i < den.size(); i++) out[i] = num[i] * den[i];
+  return true;
+}
+
+// Walks the schedule for several G2 points in lock-step.  The slopes of one step need one Fq2 inversion each: their inverse norms
+// come from g2_schedule_norm_invs (one inversion per POINT), or - a degenerate point, host build - from one inversion per step
+// shared by the points (batch_inv).
 template <class F> inline std::vector<G2Lines<F>> g2_precompute(const std::vector<G2<F>>& Qs) {
   const int n = (int)Qs.size();
   std::vector<G2<F>> T = Qs;
   std::vector<G2Lines<F>> out(n);
   HFr ninv[8];
+  std::vector<std::vector<HFr>> pre(n);
+  bool have_pre = true;
+  for (int k = 0; k < n && have_pre; k++) have_pre = g2_schedule_norm_invs(v2_of(Qs[k].x), v2_of(Qs[k].y), pre[k]);
+  size_t at = 0;
   for (int i = 62; i >= 0; i--) {
-    for (int k = 0; k < n; k++) ninv[k] = v2_norm(v2_of(T[k].y + T[k].y));
-    batch_inv(ninv, n);
+    if (have_pre) { for (int k = 0; k < n; k++) ninv[k] = pre[k][at]; at++; }
+    else {
+      for (int k = 0; k < n; k++) ninv[k] = v2_norm(v2_of(T[k].y + T[k].y));
+      batch_inv(ninv, n);
+    }
     for (int k = 0; k < n; k++) {
       Fq2<F> xx = T[k].x.sqr();
       Fq2<F> lam = fq2_div(xx + xx + xx, T[k].y + T[k].y, &ninv[k]);
@@ -77,8 +149,11 @@ template <class F> inline std::vector<G2Lines<F>> g2_precompute(const std::vecto
       T[k].x = x3; T[k].y = y3;
     }
     if ((BLS_U >> i) & 1) {
-      for (int k = 0; k < n; k++) ninv[k] = v2_norm(v2_of(Qs[k].x - T[k].x));
-      batch_inv(ninv, n);
+      if (have_pre) { for (int k = 0; k < n; k++) ninv[k] = pre[k][at]; at++; }
+      else {
+        for (int k = 0; k < n; k++) ninv[k] = v2_norm(v2_of(Qs[k].x - T[k].x));
+        batch_inv(ninv, n);
+      }
       for (int k = 0; k < n; k++) {
         Fq2<F> lam = fq2_div(Qs[k].y - T[k].y, Qs[k].x - T[k].x, &ninv[k]);
         out[k].push_back(LineCoeffs<F>{lam, lam * T[k].x - T[k].y});

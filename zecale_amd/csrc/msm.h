@@ -64,6 +64,7 @@ struct MsmCtx {
   uint32_t* aff_scratch;
   size_t m_acc_max;                  // upper bound on the entries that reach k_accumulate (sizes S, T and the slot array)
   float last_accumulate_ms;
+  size_t last_hist_m;                // words of hist the last launch scanned: the last one holds the number of entries it sorted (msm_last_entries)
   uint32_t acc_gen;                           // generation of the device's time base when this launch's ev_acc0 was recorded (msm_time_base_reset bumps it)
   float last_acc_begin_ms, last_acc_end_ms;   // the same launch on the device's time base (msm_time_base): lets a caller that keeps
                                               // several MSMs in flight see how their accumulations overlap
@@ -94,6 +95,9 @@ int msm_bases_convert(const uint64_t* d_bases_abi, size_t n, AffPacked* d_out, u
 int msm_launch(MsmCtx* ctx, const AffPacked* d_bases, const uint8_t* d_inf_flags, const uint64_t* d_scalars, size_t n,
                int scalars_montgomery, size_t table_stride);
 int msm_finish(MsmCtx* ctx, uint64_t out_jac[36]);
+// The entries (non-zero digits = mixed additions of k_accumulate, no affine levels in front) of the last launch of this plan, read
+// back from the sort's histogram: a measurement aid, synchronises the device.  0: nothing launched yet.
+int msm_last_entries(MsmCtx* ctx, uint64_t* out);
 // merged plans: up to ctx->K independent MSMs (same window, each at most max_n terms) through ONE launch sequence:
 // one sort, one accumulation launch, one reduction chain with a bucket window per job.  out_jac: K x 36.
 int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs);

@@ -1390,6 +1390,16 @@ static void debug_dump(MsmCtx* ctx) {
   fclose(f);
 }
 
+int msm_last_entries(MsmCtx* ctx, uint64_t* out) {
+  *out = 0;
+  if (!ctx->last_hist_m) return ZKHIP_OK;
+  uint32_t v = 0;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&v, ctx->hist + ctx->last_hist_m - 1, 4, hipMemcpyDeviceToHost));
+  *out = v;
+  return ZKHIP_OK;
+}
+
 static void read_accumulate_times(MsmCtx* ctx) {
   debug_dump(ctx);
   float ms = 0;
@@ -1611,6 +1621,7 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   ge.nparts = (uint32_t)(nb >> ge.LB);
   const size_t hist_m = (size_t)ge.nparts * ge.nbx + 1;
   if (hist_m > ctx->hist_len) return ZKHIP_ERR_ARG;
+  ctx->last_hist_m = hist_m;
   const int KK = merged ? ctx->K : 1;                            // every bucket window's rows of hist are (re)written
   for (int k = K; k < KK; k++) dj.n[k] = 0;
   const dim3 dgrid(ge.nbx, KK);

@@ -71,6 +71,7 @@ struct zkhip_pipeline {
   bool stop = false;
   // witness generation on the GPU (ZKHIP_PIPELINE_GPU_WITNESS): device buffers for the assignments in flight
   bool gpu_witness = false;
+  bool hybrid = false;                            // host generators wait on cv_wit beside the batchers: submit wakes all of them
   int device = 0;
   size_t wit_batch = 16;                          // batches per witness launch (one workgroup each: 16 take as long as one)
   struct Slab { void* base = nullptr; int outstanding = 0; };
@@ -133,14 +134,21 @@ std::shared_ptr<AppEntry> find_app(zkhip_pipeline* p, const std::vector<uint64_t
   return rc == ZKHIP_OK ? e : nullptr;
 }
 
-void witness_loop(zkhip_pipeline* p) {
+// overflow_only (a HYBRID pipeline's host generators): take a batch only while MORE than one full witness launch is queued - what
+// the batchers cannot start on anyway.  A host generator that takes every batch it sees leaves the batchers launching a few batches
+// at a time, and a launch of 3 takes as long as a launch of 16 (nine inputs per nested proof, round 5: 149 proofs/s against 298
+// from the batchers alone).
+void witness_loop(zkhip_pipeline* p, bool overflow_only = false) {
   pthread_setname_np(pthread_self(), "zk-witness");
   lower_priority();
   for (;;) {
     std::shared_ptr<Job> j;
     {
       std::unique_lock<std::mutex> lk(p->mu);
-      p->cv_wit.wait(lk, [&] { return p->stop || !p->q_wit.empty(); });
+      if (overflow_only) {
+        p->cv_wit.wait(lk, [&] { return p->stop || p->q_wit.size() > p->wit_batch; });
+      } else
+        p->cv_wit.wait(lk, [&] { return p->stop || !p->q_wit.empty(); });
       if (p->stop) return;
       j = p->q_wit.front();
       p->q_wit.pop_front();
@@ -174,7 +182,7 @@ void witness_loop(zkhip_pipeline* p) {
 void gpu_witness_loop(zkhip_pipeline* p) {
   pthread_setname_np(pthread_self(), "zk-gpu-witness");
   zkhip_gpu_witness* gw = nullptr;
-  if (zkhip_set_device(p->device) != ZKHIP_OK || zkhip_gpu_witness_new_batched(p->agg, p->wit_batch, &gw) != ZKHIP_OK) { witness_loop(p); return; }
+  if (zkhip_set_device(p->device) != ZKHIP_OK || zkhip_gpu_witness_new_batched(p->agg, p->wit_batch, &gw) != ZKHIP_OK) { witness_loop(p, false); return; }
   std::vector<std::shared_ptr<Job>> jobs, good;
   std::vector<const uint64_t*> vks, prs, ins;
   std::vector<uint64_t> prim(p->wit_batch * p->n_primary * 6);
@@ -361,15 +369,16 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
     }
     p->provers.push_back(pr);
   }
-  for (int i = 0; i < witness_workers; i++) p->threads.emplace_back(p->gpu_witness ? gpu_witness_loop : witness_loop, p);
+  for (int i = 0; i < witness_workers; i++) { if (p->gpu_witness) p->threads.emplace_back(gpu_witness_loop, p); else p->threads.emplace_back(witness_loop, p, false); }
   if (p->gpu_witness) p->threads.emplace_back(host_fallback_loop, p);
   // HYBRID (ZKHIP_PIPELINE_HYBRID_WITNESS with ZKHIP_PIPELINE_GPU_WITNESS): host generators beside the GPU batchers, on the same queue - a
-  // host worker takes one batch at a time, a batcher up to wit_batch of one key.  The host share sets the host cores: every host
-  // worker adds ~150 witnesses/s for ~2 cores; the batchers take the rest (the stream's rate between the two pure modes').
+  // host worker takes one batch at a time - and only from what exceeds one full witness launch in the queue (witness_loop) - a batcher up
+  // to wit_batch of one key: the host generators work when the batchers are behind, and idle otherwise.
   if (p->gpu_witness && (flags & ZKHIP_PIPELINE_HYBRID_WITNESS)) {
     int hw = 2;
     if (const char* e = getenv("ZKHIP_HYBRID_HOST_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 16) hw = v; }
-    for (int i = 0; i < hw; i++) p->threads.emplace_back(witness_loop, p);
+    p->hybrid = true;
+    for (int i = 0; i < hw; i++) p->threads.emplace_back(witness_loop, p, true);
   }
   for (zkhip_prover* pr : p->provers) p->threads.emplace_back(gpu_loop, p, pr);
   *out = p;
@@ -425,7 +434,7 @@ int zkhip_aggregator_pipeline_submit(zkhip_pipeline* p, const uint64_t* nested_v
   p->jobs[j->id] = j;
   p->q_wit.push_back(j);
   *ticket = j->id;
-  p->cv_wit.notify_one();
+  if (p->hybrid) p->cv_wit.notify_all(); else p->cv_wit.notify_one();   // (a host generator that wants more than wit_batch queued must not swallow a batcher's wake-up)
   return ZKHIP_OK;
 }
 

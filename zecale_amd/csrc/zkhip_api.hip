@@ -76,6 +76,7 @@ struct ProveState {
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool chained_last = false;       // the last proof put upload, QAP map and MSMs on ONE stream without host waits: ms[0..1] are enqueueing times
   float last_accumulate_ms = 0.f;
+  MsmCtx* last_acc_ctx = nullptr;  // the plan last_accumulate_ms was read from (zkhip_last_accumulate_entries)
   float last_acc_interval[2] = {0.f, 0.f};   // begin / end of that launch on the device's time base
   int last_submit_slot = -1;       // zkhip_msm_submit: the slot of the previous submission (its accumulation gates the next one's)
   uint32_t quad_below = 0;         // 0: the engine's default; else the MSM contexts' quad_below (zkhip_prover_set_streaming)
@@ -404,7 +405,7 @@ int zkhip_msm_dev(const zkhip_bases* bases, size_t offset, const void* d_scalars
   rc = msm_run(&ps.ctx[0], bases->d_pts + offset, bases->d_inf ? bases->d_inf + offset : nullptr, (const uint64_t*)d_scalars, len,
                scalars_montgomery, bases->len, out_jac);
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", ps.ctx[0].errbuf);
-  else { ps.last_accumulate_ms = ps.ctx[0].last_accumulate_ms; ps.last_acc_interval[0] = ps.ctx[0].last_acc_begin_ms; ps.last_acc_interval[1] = ps.ctx[0].last_acc_end_ms; t_prove_dev = bases->device; }
+  else { ps.last_acc_ctx = &ps.ctx[0]; ps.last_accumulate_ms = ps.ctx[0].last_accumulate_ms; ps.last_acc_interval[0] = ps.ctx[0].last_acc_begin_ms; ps.last_acc_interval[1] = ps.ctx[0].last_acc_end_ms; t_prove_dev = bases->device; }
   return rc;
 }
 
@@ -447,7 +448,7 @@ int zkhip_msm_collect(int slot, uint64_t out_jac[36]) {
   if (!ps.ready[slot] || !cx->pending) return fail(ZKHIP_ERR_STATE, "nothing submitted on this slot");
   int rc = msm_finish(cx, out_jac);
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", cx->errbuf);
-  else { ps.last_accumulate_ms = cx->last_accumulate_ms; ps.last_acc_interval[0] = cx->last_acc_begin_ms; ps.last_acc_interval[1] = cx->last_acc_end_ms; t_prove_dev = dev; }
+  else { ps.last_acc_ctx = cx; ps.last_accumulate_ms = cx->last_accumulate_ms; ps.last_acc_interval[0] = cx->last_acc_begin_ms; ps.last_acc_interval[1] = cx->last_acc_end_ms; t_prove_dev = dev; }
   return rc;
 }
 
@@ -864,6 +865,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     }
     for (int j = 0; j < 5; j++) ps.ms[2 + j] = ms_since(tl0);
     ps.last_accumulate_ms = cx->last_accumulate_ms;
+    ps.last_acc_ctx = cx;
     return ZKHIP_OK;
   }
   // MSMs in flight: while MSM j reduces its buckets (latency-bound, few lanes), MSM j+1 accumulates.  Large
@@ -894,6 +896,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", ctxs[j % nctx]->errbuf); return rc; }
   }
   ps.last_accumulate_ms = ctxs[4 % nctx]->last_accumulate_ms;
+  ps.last_acc_ctx = ctxs[4 % nctx];
   return ZKHIP_OK;
 }
 
@@ -1311,6 +1314,19 @@ int zkhip_prover_set_streaming(zkhip_prover* p, int on) {
   return ZKHIP_OK;
 }
 
+static int last_entries_of(ProveState& ps, uint64_t* out) {
+  *out = 0;
+  if (!ps.last_acc_ctx) return ZKHIP_OK;
+  int rc = msm_last_entries(ps.last_acc_ctx, out);
+  if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", ps.last_acc_ctx->errbuf);
+  return rc;
+}
+int zkhip_prover_last_accumulate_entries(zkhip_prover* p, uint64_t* out) {
+  if (!p || !out) return fail(ZKHIP_ERR_ARG, "null argument");
+  BIND(p);
+  std::lock_guard<std::mutex> lk(p->mu);
+  return last_entries_of(p->ps, out);
+}
 float zkhip_prover_last_accumulate_ms(zkhip_prover* p) {
   if (!p) return 0.f;
   std::lock_guard<std::mutex> lk(p->mu);
@@ -1545,6 +1561,14 @@ int zkhip_last_accumulate_interval(float out_ms[2]) {
   std::lock_guard<std::mutex> lk(g.dev[dev].mu);
   out_ms[0] = g.dev[dev].ps.last_acc_interval[0]; out_ms[1] = g.dev[dev].ps.last_acc_interval[1];
   return ZKHIP_OK;
+}
+int zkhip_last_accumulate_entries(uint64_t* out) {
+  if (!out) return fail(ZKHIP_ERR_ARG, "null argument");
+  const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();
+  if (dev < 0) { *out = 0; return ZKHIP_OK; }
+  { int rc_ = bind_dev(dev); if (rc_ != ZKHIP_OK) return rc_; }
+  std::lock_guard<std::mutex> lk(g.dev[dev].mu);
+  return last_entries_of(g.dev[dev].ps, out);
 }
 float zkhip_last_accumulate_ms(void) {
   const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();       // where this thread's last MSM / proof ran

@@ -15,7 +15,7 @@ EXPORTS = [
     "zkhip_bases_upload", "zkhip_bases_upload_dev", "zkhip_bases_len", "zkhip_bases_free",
     "zkhip_bases_precompute", "zkhip_bases_table_window", "zkhip_set_crs_precompute", "zkhip_crs_table_window", "zkhip_set_batch_msms",
     "zkhip_msm", "zkhip_msm_dev", "zkhip_msm_raw", "zkhip_msm_submit", "zkhip_msm_collect",
-    "zkhip_device_alloc", "zkhip_device_free", "zkhip_device_copy_in", "zkhip_last_accumulate_ms",
+    "zkhip_device_alloc", "zkhip_device_free", "zkhip_device_copy_in", "zkhip_last_accumulate_ms", "zkhip_last_accumulate_entries", "zkhip_prover_last_accumulate_entries",
     "zkhip_prover_set_streaming", "zkhip_set_table_naf", "zkhip_fixed_base_mul", "zkhip_fixed_base_mul_dev", "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_r1cs_upload", "zkhip_r1cs_upload_ex", "zkhip_r1cs_set_domain", "zkhip_r1cs_free", "zkhip_r1cs_log_domain", "zkhip_r1cs_domain_size",
     "zkhip_domain_size", "zkhip_step_domain_size", "zkhip_domain_is_valid", "zkhip_groth16_setup_ex", "zkhip_dispatcher_outstanding", "zkhip_r1cs_is_satisfied", "zkhip_qap_h",
@@ -145,6 +145,8 @@ def load():
     lib.zkhip_groth16_finish.argtypes = [c_u64p] * 9
     lib.zkhip_groth16_verify.argtypes = [c_u64p, c_u64p, c_u64p, c_u64p, c_u64p, ctypes.c_size_t, c_u64p, ctypes.POINTER(ctypes.c_int)]
     lib.zkhip_last_accumulate_ms.restype = ctypes.c_float
+    lib.zkhip_last_accumulate_entries.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    lib.zkhip_prover_last_accumulate_entries.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
     lib.zkhip_jac_to_affine.argtypes = [c_u64p, c_u64p]
     lib.zkhip_jac_add.argtypes = [c_u64p, c_u64p, c_u64p]
     lib.zkhip_keypair_write.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
@@ -845,6 +847,11 @@ class Prover:
     def last_accumulate_ms(self):
         return float(load().zkhip_prover_last_accumulate_ms(self.handle))
 
+    def last_accumulate_entries(self):
+        out = ctypes.c_uint64(0)
+        _check(load().zkhip_prover_last_accumulate_entries(self.handle, ctypes.byref(out)))
+        return int(out.value)
+
     def timings(self):
         t = (ctypes.c_double * 8)()
         _check(load().zkhip_prover_timings(self.handle, t))
@@ -1128,6 +1135,13 @@ def jac_add(a, b):
 
 def last_accumulate_ms():
     return float(load().zkhip_last_accumulate_ms())
+
+
+def last_accumulate_entries():
+    """Mixed additions of the k_accumulate launch zkhip_last_accumulate_ms timed (the non-zero digits it sorted)."""
+    out = ctypes.c_uint64(0)
+    _check(load().zkhip_last_accumulate_entries(ctypes.byref(out)))
+    return int(out.value)
 
 
 def field_selftest(field, limbs_in):
