@@ -9,7 +9,9 @@ rows = [("r04_host", "round 4 tree (1b01b24): host witness generator, 49,152-poi
         ("r05_host_nocache", "this tree: host witness generator, 65,536-point domain, per-application constants OFF"),
         ("r05_host", "this tree: host witness generator, per-application constants (the default)"),
         ("r05_gpu", "this tree: GPU witness generator, per-application constants")]
-out = ["# Host side of the streaming prover, one box, `bench.py --workload aggregator --steps 2000` (tools/collect_pipeline_stats.sh)", ""]
+out = ["# Host side of the streaming prover, one box, `bench.py --workload aggregator --steps 2000` (tools/collect_pipeline_stats.sh)",
+       "# (CPU seconds per thread name: threads alive at the end of the run, whole process life including set-up; the host witness generator's",
+       "#  per-section helper threads end with their witness and are missing from it - host_cores_busy, process CPU time over the timed region, has them)", ""]
 for name, what in rows:
     path = os.path.join(src, name + ".log")
     if not os.path.exists(path):
