@@ -95,6 +95,38 @@ def test_proof_from_the_masked_assignment_is_the_plain_proof(zk, naf, domain):
     pr.free(); app.free(); crs.free(); r1.free(); kp.free(); agg.free()
 
 
+@pytest.mark.parametrize("num_proofs", [1, 3])
+def test_other_batch_sizes(zk, num_proofs):
+    """The handle for circuits of one and of three nested proofs (the reference's batch size is a template parameter,
+    aggregator_circuit.tcc:33-60): the constants scale with the proof sections (the key's share once, the folded doubling chains per
+    section), the masked generators - host and GPU - agree, and the proof from the masked assignment is the plain proof."""
+    from tests.test_aggregator_host import load_nested_fixtures, nested_vk_limbs
+    agg = zk.AggregatorCircuit(num_proofs, 1)
+    desc = zk.r1cs_desc_from_aggregator(agg)
+    kp = zk.Keypair(desc, fr_limbs(0x1234567), fr_limbs(0x2345678), fr_limbs(0x3456789), fr_limbs(0x456789a))
+    nvk, proofs = load_nested_fixtures()
+    nvk_l = nested_vk_limbs(nvk)
+    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
+    app = zk.AggregatorApp(agg, crs, nvk_l)
+    print("batch %d: %d constants of %d variables" % (num_proofs, app.num_constants, agg.num_variables))
+    assert 8759 <= app.num_constants < agg.num_variables // 2
+    rs = random_fr_uniform(99 + num_proofs, 2)
+    bumps = [0, 1, 0][:num_proofs]
+    npr = np.concatenate([nested_proof_limbs(proofs[k][0]) for k in range(num_proofs)])
+    nin = np.array([fr_limbs(proofs[k][1][0] + bumps[k]) for k in range(num_proofs)])
+    z = agg.witness(nvk_l, npr, nin)
+    zm = app.witness(npr, nin)
+    assert (zm == app.mask(z)).all()
+    (zg,), (pi,) = app.witness_gpu([(npr, nin)])
+    assert zg is not None and (zg == zm).all()
+    expect_bits = sum(0 if bumps[k] else (1 << k) for k in range(num_proofs))
+    assert fr_int(pi[1]) == expect_bits
+    plain = zk.groth16_prove(crs, r1, z, rs[0], rs[1])
+    assert (app.prove(r1, zm, rs[0], rs[1]) == plain).all()
+    assert zk.groth16_verify(kp.vk(), z[1:1 + agg.num_primary_inputs()], plain)
+    app.free(); crs.free(); r1.free(); kp.free(); agg.free()
+
+
 def test_gpu_generator_of_an_application(zk):
     """zkhip_gpu_witness_run_batched_app: the application's own device program (its key folded in as constants: no key-hash launch)
     writes the MASKED assignment - three batches in one launch, equal to the masked host generator limb for limb; the primary inputs
