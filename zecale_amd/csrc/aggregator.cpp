@@ -57,9 +57,50 @@ extern "C" int zkhip_bls12_377_groth16_verify(const uint64_t vk_alpha_g1[12], co
 
 namespace {
 
+// A section's values live for one witness (a few ms) in a vector of 1-2 MB: glibc would serve each from mmap and return it with munmap -
+// a dozen address-space changes and a thousand page faults per witness under the process's memory-map lock, which throttled ten
+// generator threads (round 5: nine inputs per nested proof, MORE workers gave FEWER proofs).  The vectors are kept and reused instead
+// (at most 48 of them: ten generators x four sections in flight, and what a burst leaves behind is freed as it comes back).
+struct SectionPool {
+  std::mutex mu;
+  std::vector<std::vector<HFr>> free_;
+  std::vector<HFr> get(size_t cap) {
+    std::vector<HFr> v;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!free_.empty()) { v.swap(free_.back()); free_.pop_back(); }
+    }
+    v.clear();
+    v.reserve(cap);                                       // (one allocation per section, not one per doubling of the vector)
+    return v;
+  }
+  void put(std::vector<HFr>& v) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_.size() < 48) { free_.emplace_back(); free_.back().swap(v); }
+  }
+};
+SectionPool& section_pool() { static SectionPool* p = new SectionPool(); return *p; }     // (never destroyed: generator threads may outlive main)
+
+// the assembled assignment, straight into the caller's buffer: [ONE, primary inputs, inputs' variables | section 0 | section 1 | ...]
+// (`gap`: entries left ZERO between the head and the first section - the sections an application's handle holds)
+void write_assignment(uint64_t* z_out, size_t n_vars, const std::vector<HFr>& head, size_t gap, std::vector<std::vector<HFr>>& parts) {
+  size_t total = head.size() + gap;
+  for (auto& p : parts) total += p.size();
+  if (total != n_vars) throw std::runtime_error("assignment layout changed");
+  static_assert(sizeof(HFr) == 48, "an assignment entry is six u64 limbs");
+  memcpy(z_out, head.data(), head.size() * 48);
+  size_t at = head.size();
+  if (gap) { memset(z_out + at * 6, 0, gap * 48); at += gap; }
+  for (auto& p : parts) {
+    if (!p.empty()) memcpy(z_out + at * 6, p.data(), p.size() * 48);
+    at += p.size();
+    section_pool().put(p);
+  }
+}
+
 // assignment only, sections on separate threads
-void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const NestedData* data, size_t n_vars_hint = 0) {
-  const size_t section_cap = n_vars_hint ? n_vars_hint / (num_proofs ? num_proofs : 1) + 64 : 0;
+void witness_parallel(uint64_t* z_out, size_t n_vars, size_t num_proofs, size_t k, const NestedData* data) {
+  const size_t section_cap = n_vars / (num_proofs ? num_proofs : 1) + 64;
   Builder b0;
   current_builder() = &b0;
   Inputs<WV> in;
@@ -73,14 +114,13 @@ void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const Ne
   auto run = [&](size_t s) {
     try {
       Builder bs;
-      bs.z.clear();                                     // a section holds no constant ONE of its own
-      bs.z.reserve(section_cap);                        // (one allocation per section, not one per doubling of the vector)
+      bs.z = section_pool().get(section_cap);           // a section holds no constant ONE of its own
       current_builder() = &bs;
       if (s == 0) results[s] = section_hash(in).value();
       else if (s == 1) vk_precompute(in.vk);
       else results[s] = section_proof(in, s - 2, k).value();
       current_builder() = nullptr;
-      parts[s] = std::move(bs.z);
+      parts[s].swap(bs.z);
     } catch (...) { errs[s] = std::current_exception(); current_builder() = nullptr; }
   };
   std::thread t_hash(run, 0);
@@ -89,19 +129,17 @@ void witness_parallel(std::vector<HFr>& z, size_t num_proofs, size_t k, const Ne
   if (!errs[1]) for (size_t s = 2; s < ns; s++) th.emplace_back(run, s);
   t_hash.join();
   for (auto& t : th) t.join();
-  for (auto& e : errs) if (e) std::rethrow_exception(e);
-  z = std::move(b0.z);
-  if (n_vars_hint) z.reserve(n_vars_hint);
-  for (auto& p : parts) z.insert(z.end(), p.begin(), p.end());
-  z[1] = results[0];
+  for (auto& e : errs) if (e) { for (auto& p : parts) section_pool().put(p); std::rethrow_exception(e); }
+  b0.z[1] = results[0];
   HFr packed = HFr::zero(), pow2 = HFr::one();
   for (size_t p = 0; p < num_proofs; p++) { packed = packed + results[p + 2] * pow2; pow2 = pow2 + pow2; }
-  z[2] = packed;
+  b0.z[2] = packed;
+  write_assignment(z_out, n_vars, b0.z, 0, parts);
 }
 
 // Proof sections only, for a batch under a REGISTERED key (zk_app_host_witness): the key's variables are allocated as always (the
 // numbering must not move), its hash and its lines are not recomputed - `vk` carries the lines - and their slices stay zero.
-void witness_proofs_only(std::vector<HFr>& z, const zkhip_aggregator* a, const NestedVk<WV>& vk, const NestedData* data) {
+void witness_proofs_only(uint64_t* z_out, const zkhip_aggregator* a, const NestedVk<WV>& vk, const NestedData* data) {
   const size_t num_proofs = a->num_proofs, k = a->inputs_per_proof;
   Builder b0;
   current_builder() = &b0;
@@ -116,27 +154,23 @@ void witness_proofs_only(std::vector<HFr>& z, const zkhip_aggregator* a, const N
   auto run = [&](size_t p) {
     try {
       Builder bs;
-      bs.z.clear();
-      bs.z.reserve((a->n_vars - a->sec_proofs) / num_proofs + 64);
+      bs.z = section_pool().get((a->n_vars - a->sec_proofs) / num_proofs + 64);
       current_builder() = &bs;
       results[p] = section_proof(in, p, k).value();
       current_builder() = nullptr;
-      parts[p] = std::move(bs.z);
+      parts[p].swap(bs.z);
     } catch (...) { errs[p] = std::current_exception(); current_builder() = nullptr; }
   };
   std::vector<std::thread> th;
   for (size_t p = 1; p < num_proofs; p++) th.emplace_back(run, p);
   run(0);
   for (auto& t : th) t.join();
-  for (auto& e : errs) if (e) std::rethrow_exception(e);
-  z = std::move(b0.z);
-  if (z.size() != a->sec_hash) throw std::runtime_error("assignment layout changed");
-  z.reserve(a->n_vars);
-  z.resize(a->sec_proofs, HFr::zero());                 // the hash and key sections: the application's constants, left at zero
-  for (auto& p : parts) z.insert(z.end(), p.begin(), p.end());
+  for (auto& e : errs) if (e) { for (auto& p : parts) section_pool().put(p); std::rethrow_exception(e); }
+  if (b0.z.size() != a->sec_hash) throw std::runtime_error("assignment layout changed");
   HFr packed = HFr::zero(), pow2 = HFr::one();
   for (size_t p = 0; p < num_proofs; p++) { packed = packed + results[p] * pow2; pow2 = pow2 + pow2; }
-  z[2] = packed;
+  b0.z[2] = packed;
+  write_assignment(z_out, a->n_vars, b0.z, a->sec_proofs - a->sec_hash, parts);     // the hash and key sections: the application's constants, left at zero
 }
 
 void to_csr(const std::vector<LC>& M, std::vector<uint32_t>& rp, std::vector<uint32_t>& col, std::vector<uint64_t>& val) {
@@ -201,16 +235,13 @@ int zkhip_aggregator_get_r1cs(const zkhip_aggregator* a, zkhip_r1cs_desc* d) {
 int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, const uint64_t* nested_proofs,
                              const uint64_t* nested_inputs, uint64_t* z_out) {
   if (!a || !nested_vk || !nested_proofs || !nested_inputs || !z_out) return ZKHIP_ERR_ARG;
-  std::vector<HFr> z;                  // re-entrant: the circuit description is read-only after zkhip_aggregator_new
-  NestedData d{nested_vk, nested_proofs, nested_inputs};
+  NestedData d{nested_vk, nested_proofs, nested_inputs};     // re-entrant: the circuit description is read-only after zkhip_aggregator_new
   try {
-    witness_parallel(z, a->num_proofs, a->inputs_per_proof, &d, a->n_vars);
+    witness_parallel(z_out, a->n_vars, a->num_proofs, a->inputs_per_proof, &d);
   } catch (const std::exception&) {
     current_builder() = nullptr;
     return ZKHIP_ERR_ARG;
   }
-  if (z.size() != a->n_vars) return ZKHIP_ERR_STATE;
-  for (size_t i = 0; i < z.size(); i++) z[i].to_limbs(z_out + i * 6);
   return ZKHIP_OK;
 }
 
@@ -244,16 +275,13 @@ void zk_app_host_free(void* state) { delete (AppHost*)state; }
 int zk_app_host_witness(const zkhip_aggregator* a, const void* state, const uint64_t* nested_vk, const uint64_t* nested_proofs,
                         const uint64_t* nested_inputs, const uint32_t* s_idx, size_t n_s, const uint64_t vk_hash[6], uint64_t* z_out) {
   if (!a || !state || !nested_vk || !nested_proofs || !nested_inputs || !vk_hash || !z_out || (n_s && !s_idx)) return ZKHIP_ERR_ARG;
-  std::vector<HFr> z;
   NestedData d{nested_vk, nested_proofs, nested_inputs};
   try {
-    witness_proofs_only(z, a, ((const AppHost*)state)->vk, &d);
+    witness_proofs_only(z_out, a, ((const AppHost*)state)->vk, &d);
   } catch (const std::exception&) {
     current_builder() = nullptr;
     return ZKHIP_ERR_ARG;
   }
-  if (z.size() != a->n_vars) return ZKHIP_ERR_STATE;
-  for (size_t i = 0; i < z.size(); i++) z[i].to_limbs(z_out + i * 6);
   memcpy(z_out + 6, vk_hash, 48);                              // primary input 0 (not a masked position: the caller gets it back)
   for (size_t j = 0; j < n_s; j++) {
     if (s_idx[j] <= a->n_primary || s_idx[j] >= a->n_vars) return ZKHIP_ERR_ARG;

@@ -19,7 +19,6 @@
 #include <mutex>
 #include <thread>
 #include <vector>
-#include <malloc.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -57,6 +56,21 @@ struct zkhip_pipeline {
   std::mutex mu_apps;
   std::map<std::vector<uint64_t>, std::shared_ptr<AppEntry>> apps;      // by nested key
   std::atomic<uint64_t> st_app_hits{0};
+  // assignment buffers (n_vars x 48 bytes: 2-4 MB) are reused from job to job: allocated per job they are mmap'ed and munmap'ed by the
+  // allocator, and ten generator threads doing that held the process in the kernel (aggregator.cpp: SectionPool)
+  std::mutex mu_z;
+  std::vector<std::vector<uint64_t>> z_free;
+  void take_z(std::vector<uint64_t>& z) {
+    {
+      std::lock_guard<std::mutex> lk(mu_z);
+      if (!z_free.empty()) { z.swap(z_free.back()); z_free.pop_back(); }
+    }
+    z.resize(n_vars * 6);                          // (the generators write every entry)
+  }
+  void give_z(std::vector<uint64_t>& z) {
+    std::lock_guard<std::mutex> lk(mu_z);
+    if (z_free.size() < 64) { z_free.emplace_back(); z_free.back().swap(z); }
+  }
   size_t n_vars = 0, n_primary = 0, vk_words = 0, proofs_words = 0, inputs_words = 0;
   std::vector<zkhip_prover*> provers;
   std::vector<std::thread> threads;
@@ -157,7 +171,7 @@ void witness_loop(zkhip_pipeline* p, bool overflow_only = false) {
     int rc = zkhip_aggregator_check_inputs(p->agg, j->vk.data(), j->proofs.data(), &wf);      // off-curve points: no proof exists
     if (rc == ZKHIP_OK && !wf) rc = ZKHIP_ERR_ARG;
     if (rc == ZKHIP_OK) {
-      j->z.resize(p->n_vars * 6);
+      p->take_z(j->z);
       j->app = find_app(p, j->vk);
       const auto t0 = std::chrono::steady_clock::now();
       // a registered application: the proof sections only, MASKED assignment (the key's hash, lines and doubling chains are its constants)
@@ -260,7 +274,7 @@ void host_fallback_loop(zkhip_pipeline* p) {
       j = p->q_host.front();
       p->q_host.pop_front();
     }
-    j->z.resize(p->n_vars * 6);
+    p->take_z(j->z);
     j->app = nullptr;                                  // (the full assignment, the plain proof)
     const int rc = zkhip_aggregator_witness(p->agg, j->vk.data(), j->proofs.data(), j->inputs.data(), j->z.data());
     std::lock_guard<std::mutex> lk(p->mu);
@@ -296,6 +310,7 @@ void gpu_loop(zkhip_pipeline* p, zkhip_prover* pr) {
     } else {
       std::vector<uint64_t> prim(j->z.begin() + 6, j->z.begin() + 6 + p->n_primary * 6);   // keep the primary inputs, drop the 2.4 MB witness
       j->z.swap(prim);
+      p->give_z(prim);
     }
     p->unfinished--;
     p->cv_done.notify_all();
@@ -316,17 +331,6 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
   zkhip_r1cs_desc desc;
   int rc = zkhip_aggregator_get_r1cs(a, &desc);
   if (rc != ZKHIP_OK) return rc;
-  // A witness is a handful of vectors of 2-5 MB that live for milliseconds.  glibc serves blocks above 128 KiB with mmap and gives
-  // them back with munmap: per proof that is a dozen address-space changes and a thousand page faults, all under the PROCESS's
-  // memory-map lock - which the prover threads also need for every upload from pageable memory.  Measured (round 5, nine inputs per
-  // nested proof, 4.4 MB assignments, ten witness workers): 177 proofs/s, and the MORE workers the fewer (three: 233); with the blocks
-  // kept on the heap and the heap not trimmed after every free, 246 at any number of workers.  So a process that opens a streaming
-  // prover keeps blocks up to 32 MiB (glibc's maximum) on the heap, trims only beyond 512 MiB of free top and grows the heap in 64 MiB
-  // steps (a process-wide allocator setting; ZKHIP_KEEP_MALLOC=1 leaves the allocator alone).
-  if (!getenv("ZKHIP_KEEP_MALLOC")) {
-    static std::once_flag once;
-    std::call_once(once, [] { (void)mallopt(M_MMAP_THRESHOLD, 32 << 20); (void)mallopt(M_TRIM_THRESHOLD, 512 << 20); (void)mallopt(M_TOP_PAD, 64 << 20); });
-  }
   zkhip_pipeline* p = new zkhip_pipeline();
   p->agg = a; p->crs = crs;
   p->app_cache = (flags & ZKHIP_PIPELINE_NO_APP_CACHE) == 0 && !getenv("ZKHIP_NO_APP_CACHE");
