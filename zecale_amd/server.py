@@ -253,7 +253,7 @@ class GpuProver:
     """The wrapping prover behind the service: circuit, keypair (file or fresh setup), HBM-resident key, streaming pipeline."""
     snark_name = "GROTH16"
 
-    def __init__(self, keypair_file=None, device=0, gpu_slots=24, witness_workers=10, gpu_witness=False, devices=None, hybrid_witness=False):
+    def __init__(self, keypair_file=None, device=0, gpu_slots=32, witness_workers=10, gpu_witness=False, devices=None, hybrid_witness=False):
         """devices: the GPUs of the node this ONE server process drives (the reference server is one process that owns its prover:
         aggregator_server.cpp:106-118, 390-416) - a resident copy of the key and a streaming pipeline on each, behind a dispatcher
         (zkhip_dispatcher_*); an index may repeat (two contexts on one GPU).  None / one entry: that GPU alone (`device`)."""

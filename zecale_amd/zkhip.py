@@ -924,7 +924,7 @@ class AggregatorDispatcher:
     `devices` (an index may repeat: two contexts on one GPU), every batch goes to the entry with the fewest batches outstanding.
     Same submit / wait as AggregatorPipeline.  keypair: a Keypair (its proving half is uploaded to every entry)."""
 
-    def __init__(self, agg, keypair, devices, opts=None, gpu_slots=24, witness_workers=10, gpu_witness=False, app_cache=True, hybrid=False):
+    def __init__(self, agg, keypair, devices, opts=None, gpu_slots=32, witness_workers=10, gpu_witness=False, app_cache=True, hybrid=False):
         d = CrsDesc()
         _check(load().zkhip_keypair_crs_desc(keypair.handle, ctypes.byref(d)))
         arr, n = _int_list(devices)
