@@ -271,6 +271,12 @@ int zkhip_prover_new(const zkhip_crs* crs, const zkhip_r1cs_desc* cs, zkhip_prov
    launch sequence: the calling thread waits once, for the MSM results (zkhip_prover_timings then reports enqueueing times for the
    first two phases; ZKHIP_STREAM_CHAIN=0 in the environment keeps the waits).  The streaming pipeline sets it on its provers. */
 int zkhip_prover_set_streaming(zkhip_prover* p, int on);
+/* no counterpart: for a caller that owns SEVERAL instances which will prove at the same time (the streaming prover does this itself).
+ * The runtime spreads streams over its hardware queues in creation order and kernels of streams that share a queue do not overlap; an
+ * instance in streaming mode keeps one of its three streams busy.  Call with which = 0 for every instance (the busy streams: spread
+ * evenly), then with which = 1 for every instance (the idle ones), before the first proof; without it the streams are created by the
+ * first proofs, in whatever order the provers' threads arrive. */
+int zkhip_prover_create_streams(zkhip_prover* p, int which);
 int zkhip_prover_prove(zkhip_prover* p, const uint64_t* z, const uint64_t r[6], const uint64_t s[6], uint64_t proof_affine[72]);
 /* the same with the assignment already in device memory (n_vars x 6 limbs, e.g. from zkhip_gpu_witness_run; must be complete) */
 int zkhip_prover_prove_dev(zkhip_prover* p, const void* d_z, const uint64_t r[6], const uint64_t s[6], uint64_t proof_affine[72]);

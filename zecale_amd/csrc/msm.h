@@ -84,7 +84,8 @@ struct MsmCtx {
 void msm_force_aff_levels(int levels);
 int msm_forced_aff_levels();
 // total_terms: upper bound on the terms (finite bases) of all K jobs of one launch together; 0 = K * max_n
-int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t total_terms = 0);
+// adopt: two streams created by the caller beforehand (or null): the plan's main and side stream - the plan owns them from here on
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t total_terms = 0, hipStream_t* adopt = nullptr);
 // a per-device event recorded once: the origin of last_acc_begin_ms / last_acc_end_ms
 hipEvent_t msm_time_base();
 // record the origin again (now): intervals read afterwards are relative to this moment

@@ -1414,7 +1414,7 @@ static void read_accumulate_times(MsmCtx* ctx) {
   }
 }
 
-int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t total_terms) {
+int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t total_terms, hipStream_t* adopt) {
   memset(ctx, 0, sizeof *ctx);
   // terms of ALL jobs of one launch sequence together: K * max_n unless the caller knows better (a proving key's five query vectors
   // differ in length and a third of the B query is the point at infinity: the wrapping key has 192,664 finite bases where
@@ -1441,8 +1441,11 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t to
   ctx->max_n = max_n;
   ctx->logL = env_int("ZKHIP_SUM_LOGL", 2, 2, 5); ctx->L = 1 << ctx->logL;      // fan-in of the reduction trees (tuning knob; the R arrays are sized for L >= 4)
   size_t nb = ctx->B * ctx->W;
-  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));   // no implicit ordering against the null stream (the host application's, e.g. torch's)
-  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  if (adopt && adopt[0] && adopt[1]) { ctx->stream = adopt[0]; ctx->stream2 = adopt[1]; adopt[0] = adopt[1] = nullptr; }
+  else {
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));   // no implicit ordering against the null stream (the host application's, e.g. torch's)
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  }
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&ctx->ev_acc0));

@@ -373,6 +373,10 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
     }
     p->provers.push_back(pr);
   }
+  // the provers' busy streams first, one after the other, then their idle ones: evenly over the runtime's hardware queues
+  // (zkhip_prover_create_streams; created by the provers' own threads they land as the race decides)
+  for (int which = 0; which < 2; which++)
+    for (zkhip_prover* pr : p->provers) (void)zkhip_prover_create_streams(pr, which);
   for (int i = 0; i < witness_workers; i++) { if (p->gpu_witness) p->threads.emplace_back(gpu_witness_loop, p); else p->threads.emplace_back(witness_loop, p, false); }
   if (p->gpu_witness) p->threads.emplace_back(host_fallback_loop, p);
   // HYBRID (ZKHIP_PIPELINE_HYBRID_WITNESS with ZKHIP_PIPELINE_GPU_WITNESS): host generators beside the GPU batchers, on the same queue - a

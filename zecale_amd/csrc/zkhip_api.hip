@@ -80,7 +80,9 @@ struct ProveState {
   float last_acc_interval[2] = {0.f, 0.f};   // begin / end of that launch on the device's time base
   int last_submit_slot = -1;       // zkhip_msm_submit: the slot of the previous submission (its accumulation gates the next one's)
   uint32_t quad_below = 0;         // 0: the engine's default; else the MSM contexts' quad_below (zkhip_prover_set_streaming)
+  hipStream_t pre[2] = {nullptr, nullptr};   // streams made ahead of the first proof (zkhip_prover_create_streams): the launch sequence's plan adopts them
   void release() {
+    for (int k = 0; k < 2; k++) if (pre[k]) { (void)hipStreamDestroy(pre[k]); pre[k] = nullptr; }
     for (int k = 0; k <= ZK_MSM_SLOTS; k++) if (ready[k]) { msm_plan_free(&ctx[k]); ready[k] = false; }
     if (st) { (void)hipStreamDestroy(st); st = nullptr; }
     if (ev_st) { (void)hipEventDestroy(ev_st); ev_st = nullptr; }
@@ -171,13 +173,13 @@ static bool ctx_reusable(const MsmCtx* cx, bool ready, size_t n, int table_c, in
   return ready && !cx->pending && cx->max_n >= n && cx->total_terms >= total && cx->c == c && cx->merged == merged && cx->K == K &&
          cx->aff_forced == msm_forced_aff_levels();
 }
-int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1, int naf = 0, size_t total = 0, int plain_c = 0) {
+int ensure_ctx(MsmCtx* cx, bool* ready, size_t n, int table_c, int K = 1, int naf = 0, size_t total = 0, int plain_c = 0, hipStream_t* adopt = nullptr) {
   const int c = table_c ? table_c : (plain_c ? plain_c : auto_window(n)), merged = table_c ? (naf ? 2 : 1) : 0;
   if (total == 0 || total > (size_t)K * n) total = (size_t)K * n;
   if (*ready && cx->pending) return fail(ZKHIP_ERR_STATE, "an MSM submitted on this context has not been collected (zkhip_msm_collect)");
   if (*ready && cx->max_n >= n && cx->total_terms >= total && cx->c == c && cx->merged == merged && cx->K == K && cx->aff_forced == msm_forced_aff_levels()) return ZKHIP_OK;
   if (*ready) { msm_plan_free(cx); *ready = false; }
-  int rc = msm_plan_init(cx, n, c, merged, K, total);
+  int rc = msm_plan_init(cx, n, c, merged, K, total, adopt);
   if (rc != ZKHIP_OK) {
     snprintf(t_err, sizeof t_err, "msm_plan_init: %s", cx->errbuf);
     msm_plan_free(cx);          // whatever was allocated before the failure
@@ -837,7 +839,7 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
     // lists, one reduction chain with a bucket window per MSM) - a fifth of the launches, five times the lanes in each.
     // (A plan that does not fit the engine's 32-bit entry positions is refused with ZKHIP_ERR_ARG: one sequence per MSM then.)
     const size_t total = total_finite;
-    rc = ensure_ctx(&ps.ctx[ZK_MSM_SLOTS], &ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf, total ? total : 1);
+    rc = ensure_ctx(&ps.ctx[ZK_MSM_SLOTS], &ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf, total ? total : 1, 0, ps.pre);
     if (rc == ZKHIP_OK && ps.quad_below) { ps.ctx[ZK_MSM_SLOTS].quad_below = ps.quad_below; ps.ctx[ZK_MSM_SLOTS].one_stream = 1; }
     if (rc == ZKHIP_ERR_ARG) {
       // (a silent performance cliff) the plan's 32-bit entry positions / slice weights do not hold this key's terms at
@@ -1302,6 +1304,27 @@ int zkhip_groth16_prove_app(const zkhip_crs* crs, zkhip_r1cs* r1cs, const zkhip_
   const int rc = finish_impl(crs->alpha_g1, crs->beta_g1, crs->beta_g2, crs->delta_g1, crs->delta_g2, sums, r_m, s_m, proof_affine, &tail_ms, &pre);
   if (rc == ZKHIP_OK) { std::lock_guard<std::mutex> lk(g.dev[crs->device].mu); g.dev[crs->device].ps.ms[7] = tail_ms; }
   return rc;
+}
+
+// The HIP runtime spreads streams over a fixed number of hardware queues in the order they are CREATED, and kernels of streams that
+// share a queue do not overlap.  A streaming prover runs a whole proof on one stream (its launch sequence's main stream); its other two
+// streams idle.  Created lazily by the provers' own threads at their first proofs - thirty-two threads at once - the busy streams land
+// on the queues as the race decides: a pipeline whose busy streams crowd a few queues proves 8-10 % fewer proofs/s for as long as it
+// lives (round 5: 391 against 425-434 proofs/s, instance after instance in one process; same clock, 10 % less power).  A caller
+// that owns several instances therefore creates the streams itself, in two passes over the instances: which = 0 the stream that will be
+// busy (consecutive creations go to different queues), which = 1 the two that idle.
+int zkhip_prover_create_streams(zkhip_prover* p, int which) {
+  if (!p || which < 0 || which > 1) return fail(ZKHIP_ERR_ARG, "null prover or unknown pass");
+  BIND(p);
+  std::lock_guard<std::mutex> lk(p->mu);
+  ProveState& ps = p->ps;
+  if (which == 0) {
+    if (!ps.pre[0] && !ps.ready[ZK_MSM_SLOTS]) API_HIP(hipStreamCreateWithFlags(&ps.pre[0], hipStreamNonBlocking));
+  } else {
+    if (!ps.pre[1] && !ps.ready[ZK_MSM_SLOTS]) API_HIP(hipStreamCreateWithFlags(&ps.pre[1], hipStreamNonBlocking));
+    if (!ps.st) API_HIP(hipStreamCreateWithFlags(&ps.st, hipStreamNonBlocking));
+  }
+  return ZKHIP_OK;
 }
 
 int zkhip_prover_set_streaming(zkhip_prover* p, int on) {

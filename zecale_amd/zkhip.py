@@ -25,7 +25,7 @@ EXPORTS = [
     "zkhip_aggregator_num_variables", "zkhip_aggregator_num_primary_inputs", "zkhip_aggregator_get_r1cs",
     "zkhip_aggregator_witness", "zkhip_aggregator_witness_gpu", "zkhip_gpu_witness_new", "zkhip_gpu_witness_new_batched", "zkhip_gpu_witness_run", "zkhip_gpu_witness_run_batched", "zkhip_gpu_witness_free",
     "zkhip_gpu_witness_stats", "zkhip_prover_prove_dev", "zkhip_aggregator_check_inputs", "zkhip_aggregator_vk_hash", "zkhip_aggregator_num_proofs", "zkhip_aggregator_inputs_per_proof",
-    "zkhip_prover_new", "zkhip_prover_prove", "zkhip_prover_timings", "zkhip_prover_free", "zkhip_prover_last_accumulate_ms",
+    "zkhip_prover_new", "zkhip_prover_create_streams", "zkhip_prover_prove", "zkhip_prover_timings", "zkhip_prover_free", "zkhip_prover_last_accumulate_ms",
     "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_new_ex", "zkhip_crs_device", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
@@ -152,6 +152,7 @@ def load():
     lib.zkhip_keypair_write.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
     lib.zkhip_keypair_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
     lib.zkhip_prover_new.argtypes = [ctypes.c_void_p, ctypes.POINTER(R1csDesc), ctypes.POINTER(ctypes.c_void_p)]
+    lib.zkhip_prover_create_streams.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.zkhip_prover_set_streaming.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.zkhip_prover_prove.argtypes = [ctypes.c_void_p, c_u64p, c_u64p, c_u64p, c_u64p]
     lib.zkhip_prover_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
@@ -839,6 +840,10 @@ class Prover:
         lib.zkhip_prover_prove_app.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_u64p_t, c_u64p_t, c_u64p_t, c_u64p_t]
         _check(lib.zkhip_prover_prove_app(self.handle, app.handle, _p(z), _p(r), _p(s), _p(out)))
         return out
+
+    def create_streams(self, which):
+        """zkhip_prover_create_streams: for a caller with several instances - which = 0 for all of them, then which = 1 for all"""
+        _check(load().zkhip_prover_create_streams(self.handle, int(which)))
 
     def set_streaming(self, on=True):
         """this instance shares the GPU with others: total work over single-proof latency (zkhip_prover_set_streaming)"""
