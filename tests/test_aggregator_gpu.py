@@ -65,6 +65,11 @@ def test_prover_instances_match_the_plain_entry_point(zk):
         rs.append((fr_limbs(0x1111 + a), fr_limbs(0x2222 + b)))
     expected = [zk.groth16_prove(crs, r1, z, r, s) for z, (r, s) in zip(zs, rs)]
     provers = [zk.Prover(crs, desc), zk.Prover(crs, desc)]
+    for which in (0, 1):                       # streams made ahead of the first proof, in the caller's order (zkhip_prover_create_streams)
+        for p_ in provers:
+            p_.create_streams(which)
+    with pytest.raises(zk.ZkhipError):
+        provers[0].create_streams(2)
     with ThreadPoolExecutor(max_workers=2) as pool:
         for rep in range(2):
             futs = [pool.submit(provers[i % 2].prove, zs[i], *rs[i]) for i in range(4)]
