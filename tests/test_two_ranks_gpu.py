@@ -38,4 +38,4 @@ def test_point_partitioned_msm_across_two_processes():
     part, rep = line["prover_2_22_partitioned"], line["wrapping_replicas"]
     assert part["n_gpus"] == 2 and part["scaling"] == "strong" and part["last_proof_verifies_on_every_rank"] is True and part["value"] > 0
     assert part["constraints"] == (1 << 16) - 8 and "exchange_and_additions" in part["phase_ms_slowest_rank"]
-    assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["last_proof_verifies_on_every_rank"] is True and rep["proofs_per_rank"] == 192
+    assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["last_proof_verifies_on_every_rank"] is True and rep["proofs_per_rank"] == 576
