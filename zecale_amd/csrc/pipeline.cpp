@@ -345,7 +345,7 @@ int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, 
   }
   p->device = zkhip_crs_device(crs);
   if (p->gpu_witness) {
-    if (witness_workers > 4) witness_workers = 4;     // batcher threads: each keeps one launch of wit_batch witnesses in flight
+    if (witness_workers > 8) witness_workers = 8;     // batcher threads: each keeps one launch of wit_batch witnesses in flight
     if (zkhip_set_device(p->device) != ZKHIP_OK) { delete p; return ZKHIP_ERR_STATE; }
     const size_t n_slabs = (size_t)witness_workers + (size_t)gpu_slots / 2 + 2;
     for (size_t i = 0; i < n_slabs; i++) {
