@@ -139,7 +139,7 @@ void witness_parallel(uint64_t* z_out, size_t n_vars, size_t num_proofs, size_t 
 
 // Proof sections only, for a batch under a REGISTERED key (zk_app_host_witness): the key's variables are allocated as always (the
 // numbering must not move), its hash and its lines are not recomputed - `vk` carries the lines - and their slices stay zero.
-void witness_proofs_only(uint64_t* z_out, const zkhip_aggregator* a, const NestedVk<WV>& vk, const NestedData* data) {
+void witness_proofs_only(uint64_t* z_out, const zkhip_aggregator* a, const NestedVk<WV>& vk, const NestedData* data, const DblChain* chain) {
   const size_t num_proofs = a->num_proofs, k = a->inputs_per_proof;
   Builder b0;
   current_builder() = &b0;
@@ -148,6 +148,7 @@ void witness_proofs_only(uint64_t* z_out, const zkhip_aggregator* a, const Neste
   current_builder() = nullptr;
   in.vk.neg_beta_lines = vk.neg_beta_lines;
   in.vk.neg_delta_lines = vk.neg_delta_lines;
+  in.vk.dbl_chain = chain;                              // (read-only, shared by the section threads)
   std::vector<std::vector<HFr>> parts(num_proofs);
   std::vector<HFr> results(num_proofs);
   std::vector<std::exception_ptr> errs(num_proofs);
@@ -245,7 +246,7 @@ int zkhip_aggregator_witness(zkhip_aggregator* a, const uint64_t* nested_vk, con
   return ZKHIP_OK;
 }
 
-struct AppHost { NestedVk<WV> vk; };
+struct AppHost { NestedVk<WV> vk; DblChain chain; };     // chain: the doubling chains 2^j ABC_k of the input accumulators (bls12_377.hpp)
 
 int zk_app_host_new(const zkhip_aggregator* a, const uint64_t* nested_vk, void** state) {
   if (!a || !nested_vk || !state) return ZKHIP_ERR_ARG;
@@ -261,6 +262,9 @@ int zk_app_host_new(const zkhip_aggregator* a, const uint64_t* nested_vk, void**
     for (size_t i = 0; i <= a->inputs_per_proof; i++) st->vk.abc.push_back(g1_from<WV>(d.vk + 60 + i * 12, true));
     vk_precompute(st->vk);
     current_builder() = nullptr;
+    std::vector<std::array<HFr, 2>> abc;
+    for (size_t i = 1; i <= a->inputs_per_proof; i++) abc.push_back({st->vk.abc[i].x.value(), st->vk.abc[i].y.value()});
+    st->chain = doubling_chain_values(abc, NESTED_INPUT_BITS);
   } catch (const std::exception&) {
     current_builder() = nullptr;
     delete st;
@@ -277,7 +281,7 @@ int zk_app_host_witness(const zkhip_aggregator* a, const void* state, const uint
   if (!a || !state || !nested_vk || !nested_proofs || !nested_inputs || !vk_hash || !z_out || (n_s && !s_idx)) return ZKHIP_ERR_ARG;
   NestedData d{nested_vk, nested_proofs, nested_inputs};
   try {
-    witness_proofs_only(z_out, a, ((const AppHost*)state)->vk, &d);
+    witness_proofs_only(z_out, a, ((const AppHost*)state)->vk, &d, ((const AppHost*)state)->chain.empty() ? nullptr : &((const AppHost*)state)->chain);
   } catch (const std::exception&) {
     current_builder() = nullptr;
     return ZKHIP_ERR_ARG;

@@ -242,9 +242,14 @@ struct BlsG2Gen {
 };
 inline const BlsG2Gen& bls_g2_gen() { static BlsG2Gen g; return g; }
 
+// dbl_chain (host generator of a REGISTERED application, aggregator.cpp: AppHost): the doubling chains 2^j ABC_k of the input
+// accumulators depend on the key alone - [k][j] holds the values of the four variables doubling j of input k allocates
+// (x^2, slope, x', y'), computed once per application; the generator then allocates them without computing them.
+using DblChain = std::vector<std::vector<std::array<HFr, 4>>>;
 template <class F> struct NestedVk {
   G1<F> alpha; G2<F> beta, delta; std::vector<G1<F>> abc;
   G2Lines<F> neg_beta_lines, neg_delta_lines;       // vk_precompute: shared by every proof verified under this key
+  const DblChain* dbl_chain = nullptr;
 };
 template <class F> struct NestedProof { G1<F> a; G2<F> b; G1<F> c; };
 
@@ -306,6 +311,62 @@ inline void batch_inv_tree(std::vector<HFr>& v) {          // none of them zero
   }
   v.swap(inv);
 }
+// p + (x2, y2), the second point affine (madd-2007-bl); p != +-q as in jac_add
+inline JacH jac_madd(const JacH& p, const HFr& x2, const HFr& y2) {
+  HFr z1z1 = p.Z * p.Z;
+  HFr U2 = x2 * z1z1, S2 = y2 * (p.Z * z1z1);
+  HFr H = U2 - p.X, R = S2 - p.Y;
+  HFr HH = H * H, HHH = H * HH, V = p.X * HH;
+  JacH r;
+  r.X = R * R - HHH - (V + V);
+  r.Y = R * (V - r.X) - p.Y * HHH;
+  r.Z = p.Z * H;
+  return r;
+}
+#ifndef ZK_CIRCUIT_FR
+// The addition denominators alone, for a generator that has the doubling chain from its application (NestedVk::dbl_chain): the powers
+// pw_j are affine points it already knows, so the Jacobian run is the accumulator's only (mixed additions) and half as long a product
+// tree.  1 / (x(pw_j) - x(acc_j)) = Za^3 / Zs_j with Zs_j = Za H_j.  Empty: a degenerate step (the caller keeps the affine chain).
+template <class F> inline std::vector<std::vector<HFr>> accumulator_add_denominators(const NestedVk<F>& vk, const std::vector<std::vector<F>>& input_bits) {
+  std::vector<std::vector<HFr>> out(input_bits.size());
+  std::vector<HFr> zs, num;
+  const DblChain& ch = *vk.dbl_chain;
+  JacH acc{vk.abc[0].x.value(), vk.abc[0].y.value(), HFr::one()};
+  for (size_t k = 0; k < input_bits.size(); k++) {
+    HFr px = vk.abc[k + 1].x.value(), py = vk.abc[k + 1].y.value();
+    for (size_t j = 0; j < input_bits[k].size(); j++) {
+      JacH s = jac_madd(acc, px, py);
+      zs.push_back(s.Z); num.push_back(acc.Z * acc.Z * acc.Z);
+      const HFr b = input_bits[k][j].value();
+      acc = JacH{acc.X + b * (s.X - acc.X), acc.Y + b * (s.Y - acc.Y), acc.Z + b * (s.Z - acc.Z)};
+      if (j + 1 < input_bits[k].size()) { px = ch[k][j][2]; py = ch[k][j][3]; }
+    }
+  }
+  for (const HFr& zv : zs) if (zv.is_zero()) return {};
+  batch_inv_tree(zs);
+  size_t at = 0;
+  for (size_t k = 0; k < input_bits.size(); k++) {
+    out[k].resize(input_bits[k].size());
+    for (size_t j = 0; j < input_bits[k].size(); j++) { out[k][j] = num[at] * zs[at]; at++; }
+  }
+  return out;
+}
+// the chain itself, once per application: plain values (the inversions of 252 doublings per input are paid once); empty: degenerate
+inline DblChain doubling_chain_values(const std::vector<std::array<HFr, 2>>& abc_from_1, size_t bits) {
+  DblChain ch(abc_from_1.size());
+  for (size_t k = 0; k < abc_from_1.size(); k++) {
+    HFr x = abc_from_1[k][0], y = abc_from_1[k][1];
+    for (size_t j = 0; j + 1 < bits; j++) {
+      if ((y + y).is_zero()) return {};                      // a point of order two in the key: no chain, the generator computes as ever
+      const HFr xx = x * x, lam = (xx + xx + xx) * (y + y).inv();
+      const HFr x3 = lam * lam - (x + x), y3 = lam * (x - x3) - y;
+      ch[k].push_back({xx, lam, x3, y3});
+      x = x3; y = y3;
+    }
+  }
+  return ch;
+}
+#endif
 // dinv[k][j] = {1 / (x(pw) - x(acc)), 1 / (2 y(pw))} at step j of input k
 template <class F> inline std::vector<std::vector<std::array<HFr, 2>>> accumulator_denominators(const NestedVk<F>& vk, const std::vector<std::vector<F>>& input_bits) {
   std::vector<std::vector<std::array<HFr, 2>>> out(input_bits.size());
@@ -360,6 +421,32 @@ template <class F> inline std::vector<std::vector<std::array<HFr, 2>>> accumulat
 
 // acc = ABC_0 + sum_j bits_j (2^j ABC_1) ...: one input, bits little-endian
 template <class F> inline G1<F> input_accumulator(const NestedVk<F>& vk, const std::vector<std::vector<F>>& input_bits) {
+#ifndef ZK_CIRCUIT_FR
+  if constexpr (witness_only<F>::value) {
+    // a registered application's generator: the doubling chain comes from the handle (its variables are allocated with the values
+    // kept there - four per doubling, in g1_dbl's order), the accumulator's additions are all that is computed
+    if (vk.dbl_chain && vk.dbl_chain->size() == input_bits.size()) {
+      const auto den = accumulator_add_denominators(vk, input_bits);
+      if (!den.empty() || input_bits.empty()) {
+        const DblChain& ch = *vk.dbl_chain;
+        G1<F> acc = vk.abc[0];
+        for (size_t k = 0; k < input_bits.size(); k++) {
+          G1<F> pw = vk.abc[k + 1];
+          for (size_t j = 0; j < input_bits[k].size(); j++) {
+            G1<F> s = g1_add(acc, pw, &den[k][j]);
+            acc = g1_select(input_bits[k][j], s, acc);
+            if (j + 1 < input_bits[k].size()) {
+              const std::array<HFr, 4>& c = ch[k][j];
+              (void)F::witness(c[0]); (void)F::witness(c[1]);
+              pw = G1<F>{F::witness(c[2]), F::witness(c[3])};
+            }
+          }
+        }
+        return acc;
+      }
+    }
+  }
+#endif
   const auto den = accumulator_denominators(vk, input_bits);       // (host build: empty when a step is degenerate)
 #ifdef ZK_CIRCUIT_FR
   const bool have_den = true;
