@@ -520,10 +520,10 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--devices", default="", help="comma list of GPUs this one process drives (replicas behind a dispatcher), e.g. 0,1,2,3,4,5,6,7; "
                                                   "overrides --device")
-    ap.add_argument("--gpu-witness", action="store_true", help="generate the assignments on the GPU: half the host cores per GPU, 3-9 % fewer proofs/s "
-                                                               "(round 5: 419 proofs/s on 2.2 cores against 435 on 4.3)")
-    ap.add_argument("--hybrid-witness", action="store_true", help="host generators beside the GPU generator, taking what its launches leave: the host mode's "
-                                                                   "proofs/s on a quarter fewer host cores")
+    ap.add_argument("--gpu-witness", action="store_true", help="generate the assignments on the GPU: half the host cores per GPU, 4 % fewer proofs/s "
+                                                               "(round 5: 421 proofs/s on 2.2 cores against 439 on 4.1)")
+    ap.add_argument("--hybrid-witness", action="store_true", help="host generators beside the GPU generator, taking what its launches leave: between the two "
+                                                                   "modes in host cores, up to the host mode's proofs/s")
     args = ap.parse_args(argv)
     print("[INFO] Init params of both curves")
     prover = GpuProver(args.keypair, device=args.device, gpu_witness=args.gpu_witness, hybrid_witness=args.hybrid_witness,
