@@ -130,3 +130,38 @@ def test_nine_inputs_per_nested_proof(oracle_lib):
     assert fr_int(z[2]) == 0                                  # both nested proofs rejected
     assert [fr_int(z[3 + i]) for i in range(2 * k)] == xs[0] + xs[1]
     c.free()
+
+
+@pytest.mark.parametrize("inputs_per_proof", [1, 9])
+def test_application_host_generator_equals_the_full_generator(inputs_per_proof):
+    """The host generator of a REGISTERED application (aggregator.cpp: zk_app_host_* - what zkhip_aggregator_witness_app runs on the
+    host; the reference registers a key once, aggregator_server.cpp:170-235) computes the proof sections only: the key's hash and lines
+    are not recomputed (their slices stay zero) and the doubling chains 2^j ABC_k of the input accumulators are allocated from the
+    values the handle keeps.  Everything it does write equals the full generator's assignment, limb for limb - one and nine inputs per
+    nested proof, a valid batch and one with a bumped input.  CPU only: the library's internal entry points, no device."""
+    import ctypes
+    import bench
+    from zecale_amd import zkhip
+    lib = zkhip.load()
+    lib.zk_app_host_new.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    lib.zk_app_host_witness.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    lib.zk_app_host_free.argtypes = [ctypes.c_void_p]
+    agg = zkhip.AggregatorCircuit(2, inputs_per_proof)
+    nvk, proofs, inputs, _ = bench.aggregator_inputs(inputs_per_proof)
+    nvk, proofs = np.ascontiguousarray(nvk), np.ascontiguousarray(proofs)
+    st = ctypes.c_void_p()
+    assert lib.zk_app_host_new(agg.handle, nvk.ctypes.data, ctypes.byref(st)) == 0
+    for bump in (0, 1):
+        nin = np.ascontiguousarray(inputs).copy()
+        if bump:
+            nin.reshape(-1, 6)[-1] = fr_limbs(fr_int(nin.reshape(-1, 6)[-1]) + 1)
+        z = agg.witness(nvk, proofs, nin)
+        out = np.full_like(z, 0xFFFFFFFFFFFFFFFF)                     # (every entry must be written)
+        h = np.ascontiguousarray(z[1])
+        assert lib.zk_app_host_witness(agg.handle, st, nvk.ctypes.data, proofs.ctypes.data, nin.ctypes.data, None, 0, h.ctypes.data, out.ctypes.data) == 0
+        differ = np.nonzero((out != z).any(axis=1))[0]
+        assert len(differ) > 8000 and not out[differ].any()          # the key's own sections, left at zero
+        assert differ.max() < len(z) // 2                             # ... which precede the proof sections
+        assert (out[:3] == z[:3]).all()                               # ONE, the key's hash, the packed result bits
+    lib.zk_app_host_free(st)
+    agg.free()
