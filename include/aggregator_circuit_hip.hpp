@@ -183,7 +183,7 @@ class aggregator_circuit {
     zkhip_pipeline* p_ = nullptr;
   };
   // witness_on_gpu: the assignments are generated by a device kernel (zkhip_gpu_witness_*): fewer host cores, a deeper stream
-  std::unique_ptr<stream> open_stream(const keypair& kp, int gpu_slots = 14, int witness_workers = 8, bool witness_on_gpu = false) {
+  std::unique_ptr<stream> open_stream(const keypair& kp, int gpu_slots = 32, int witness_workers = 10, bool witness_on_gpu = false) {
     return std::unique_ptr<stream>(new stream(*this, kp, gpu_slots, witness_workers, witness_on_gpu));
   }
 
@@ -233,7 +233,7 @@ class aggregator_circuit {
     aggregator_circuit& c_;
     zkhip_dispatcher* d_ = nullptr;
   };
-  std::unique_ptr<node_stream> open_node_stream(const keypair& kp, const std::vector<int>& devices, int gpu_slots = 14, int witness_workers = 8,
+  std::unique_ptr<node_stream> open_node_stream(const keypair& kp, const std::vector<int>& devices, int gpu_slots = 32, int witness_workers = 10,
                                            bool witness_on_gpu = false, const zkhip_key_opts* opts = nullptr) {
     return std::unique_ptr<node_stream>(new node_stream(*this, kp, devices, gpu_slots, witness_workers, witness_on_gpu, opts));
   }
