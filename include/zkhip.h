@@ -429,7 +429,7 @@ int zkhip_aggregator_pipeline_new(zkhip_aggregator* a, const zkhip_crs* crs, int
 /* ZKHIP_PIPELINE_HYBRID_WITNESS (with ZKHIP_PIPELINE_GPU_WITNESS) - two host generator threads (ZKHIP_HYBRID_HOST_WORKERS: 1 .. 16) work
  * the same queue as the GPU batchers, taking a batch only while MORE than one full witness launch (16 batches) is queued - what the
  * batchers could not start on anyway (a launch of three batches takes as long as one of sixteen).  Round 5, one MI355X, batch 2: between
- * the pure modes in host cores (2.9-3.4; host 4.1-4.7, GPU 2.1-2.4) and, run by run, between 6 % below and level with the host
+ * the pure modes in host cores (2.9-3.4; host 4.1-4.7, GPU 2.1-2.4) and, run by run, between 6 % below and 3 % above the host
  * generator in proofs/s.  Results are the same proofs. */
 #define ZKHIP_PIPELINE_HYBRID_WITNESS 4u
 int zkhip_aggregator_pipeline_new_ex(zkhip_aggregator* a, const zkhip_crs* crs, int gpu_slots, int witness_workers, unsigned flags, zkhip_pipeline** out);
