@@ -494,6 +494,11 @@ int zkhip_measure_ntt(unsigned log_d, int dir, int coset, int batch, int reps, d
  * receives n x { a b / R, a^2 / R, (a b + c d) / R } in the device's own form (R = 2^783 / 2^406).  Operands must respect the
  * bodies' contract (limbs below 2^29 except the top one, products below 2^10 R p). */
 int zkhip_internal_field_selftest(int field, const uint32_t* limbs_in, size_t n, uint32_t* limbs_out);
+/* Test hook (no counterpart), HOST ONLY - works without a device: the prover's tail (row a9) on the paths a healthy proof never
+ * takes: `rounds` proofs abandoned between the start of the tail's key-only scalar multiplications and their collection, the key's
+ * tables freed at once (run under the CPU AddressSanitizer build); a delta of small order (`small_order_g1`, e.g. (1, 0)) whose
+ * fixed-base table must be refused in favour of variable-base products.  g1 / g2: the curve generators, 24 limbs each. */
+int zkhip_internal_tail_selftest(const uint64_t g1[24], const uint64_t g2[24], const uint64_t small_order_g1[24], int rounds);
 
 /* replaces: libff::Fr<wppT>::random_element() as r1cs_gg_ppzksnark_prover draws the proof's randomisers r, s (reached from
  * aggregator_circuit.tcc:168) and the generator its toxic waste: one field element uniform in Fr, 6 Montgomery limbs, from the

@@ -690,6 +690,73 @@ BLS_G2_GEN = (
 BLS_G1_B = 1
 
 
+# G1 generator of BLS12-377 (libff bls12_377_G1::G1_one) [UPSTREAM-RECALL]; checked on the curve and of order r
+# (tests/test_oracle_pins.py::test_nested_statements_from_a_trapdoor).  Any point of order r would serve below.
+BLS_G1_GEN = (
+    0x008848defe740a67c8fc6225bf87ff5485951e2caa9d41bb188282c8bd37cb5cd5481512ffcd394eeab9b16eb21be9ef,
+    0x01914a69c5102eff1f674f5d30afeec4bd7fb348ca3e52d96d182ad44fb82305c2fe3d3634a9591afd82de55559c8ea6,
+)
+
+
+def fq2_add(a, b, p=BLS_Q):
+    return ((a[0] + b[0]) % p, (a[1] + b[1]) % p)
+
+
+def fq2_sub(a, b, p=BLS_Q):
+    return ((a[0] - b[0]) % p, (a[1] - b[1]) % p)
+
+
+def bls_g2_add(P, Q):
+    """Affine addition on the twist y^2 = x^3 + 1/u over Fq2 (a = 0)."""
+    if P is INF:
+        return Q
+    if Q is INF:
+        return P
+    (x1, y1), (x2, y2) = P, Q
+    if x1 == x2:
+        if fq2_add(y1, y2) == (0, 0):
+            return INF
+        xx = fq2_mul(x1, x1)
+        lam = fq2_mul(fq2_add(fq2_add(xx, xx), xx), fq2_inv(fq2_add(y1, y1)))
+    else:
+        lam = fq2_mul(fq2_sub(y2, y1), fq2_inv(fq2_sub(x2, x1)))
+    x3 = fq2_sub(fq2_sub(fq2_mul(lam, lam), x1), x2)
+    return (x3, fq2_sub(fq2_mul(lam, fq2_sub(x1, x3)), y1))
+
+
+def bls_g2_mul(k, P):
+    acc, k = INF, k % BLS_R
+    while k:
+        if k & 1:
+            acc = bls_g2_add(acc, P)
+        P = bls_g2_add(P, P)
+        k >>= 1
+    return acc
+
+
+def bls12_377_groth16_statement_from_trapdoor(rng, n_inputs, n_proofs):
+    """A VALID nested Groth16 statement with n_inputs public inputs, made from known toxic waste - no circuit and no prover is
+    needed to exercise a verifier's ACCEPT branch (the reference's slow test gets its valid nine-input proofs from a Zeth
+    fixture that is not in the tree: libzecale/tests/aggregator/aggregator_test.cpp:222-254,293-314).
+    Key: alpha = a G1, beta = b G2, delta = d G2, ABC_i = c_i G1, gamma = the fixed G2 generator (the Clearmatics variant,
+    bls12_377_groth16_verify below).  Proof for inputs x and random (rho, sigma): A = rho G1, B = sigma G2,
+    C = ((rho sigma - a b - c_0 - sum x_i c_i) / d) G1, which makes e(A,B) = e(alpha,beta) e(acc,gamma) e(C,delta) hold.
+    Returns (vk, [(proof, inputs)]) in the dict form the verifier takes; inputs are full-size elements of the nested scalar
+    field (253 bits), as a Zeth proof's hashes are."""
+    mul1 = lambda k: ec_mul(k % BLS_R, BLS_G1_GEN, BLS_Q)
+    a, b, d = (rng.randrange(1, BLS_R) for _ in range(3))
+    cs = [rng.randrange(1, BLS_R) for _ in range(n_inputs + 1)]
+    vk = dict(alpha=mul1(a), beta=bls_g2_mul(b, BLS_G2_GEN), delta=bls_g2_mul(d, BLS_G2_GEN), ABC=[mul1(c) for c in cs])
+    dinv = inv_mod(d, BLS_R)
+    proofs = []
+    for _ in range(n_proofs):
+        xs = [rng.randrange(BLS_R) for _ in range(n_inputs)]
+        rho, sigma = rng.randrange(1, BLS_R), rng.randrange(1, BLS_R)
+        c = (rho * sigma - a * b - cs[0] - sum(x * ci for x, ci in zip(xs, cs[1:]))) * dinv % BLS_R
+        proofs.append((dict(a=mul1(rho), b=bls_g2_mul(sigma, BLS_G2_GEN), c=mul1(c)), xs))
+    return vk, proofs
+
+
 def bls12_377_groth16_verify(vk, proof, inputs):
     """Nested (BLS12-377) Groth16 verification, Clearmatics variant without gamma:
     e(A,B) = e(alpha,beta) e(ABC_0 + sum x_i ABC_i, G2_one) e(C,delta).

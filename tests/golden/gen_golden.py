@@ -171,7 +171,35 @@ def gen_step_domain(rng):
     return dict(domain_sizes=sizes, forced_domain_sizes={m: R.forced_domain_size(int(m)) for m in sizes}, fft_vectors=vecs, groth16=g)
 
 
+def gen_nested(seed, n_inputs, n_proofs=3):
+    """Round 6: VALID nested BLS12-377 Groth16 statements with more than one public input, from a known trapdoor
+    (pyref.bls12_377_groth16_statement_from_trapdoor) - the reference's slow test aggregates valid nine-input Zeth proofs
+    (libzecale/tests/aggregator/aggregator_test.cpp:222-254,293-314) and no such proof is in the tree.  Same JSON shapes as
+    the reference's testdata/dummy_app/vk.json and extproof*.json (G2 coordinates as [c1, c0]).  Checked here: every point on
+    its curve and of order r, every proof accepted by the pinned verifier, and REJECTED with any one input bumped."""
+    vk, proofs = R.bls12_377_groth16_statement_from_trapdoor(random.Random(seed), n_inputs, n_proofs)
+    g1ok = lambda P: R.on_curve(P, R.BLS_G1_B, R.BLS_Q) and R.ec_mul(R.BLS_R, P, R.BLS_Q) is None
+    g2ok = lambda Q: R.bls_g2_on_curve(Q) and R.bls_g2_mul(R.BLS_R - 1, Q) == R.bls_g2_neg(Q)
+    assert g1ok(vk["alpha"]) and g2ok(vk["beta"]) and g2ok(vk["delta"]) and all(g1ok(P) for P in vk["ABC"])
+    g2 = lambda Q: [[hx(Q[0][1]), hx(Q[0][0])], [hx(Q[1][1]), hx(Q[1][0])]]
+    out = dict(vk=dict(alpha=pt(vk["alpha"]), beta=g2(vk["beta"]), delta=g2(vk["delta"]), ABC=[pt(P) for P in vk["ABC"]]), proofs=[])
+    for pr, xs in proofs:
+        assert g1ok(pr["a"]) and g2ok(pr["b"]) and g1ok(pr["c"])
+        assert R.bls12_377_groth16_verify(vk, pr, xs)
+        for j in range(n_inputs):
+            bad = list(xs); bad[j] = (bad[j] + 1) % R.BLS_R
+            assert not R.bls12_377_groth16_verify(vk, pr, bad), j
+        out["proofs"].append(dict(proof=dict(a=pt(pr["a"]), b=g2(pr["b"]), c=pt(pr["c"])), inputs=[hx(x) for x in xs]))
+    return out
+
+
 def main():
+    if "--nested-only" in sys.argv:
+        for k, seed in ((9, 0x9E57ED), (3, 0x3E57ED)):
+            with open(os.path.join(HERE, f"nested_k{k}.json"), "w") as f:
+                json.dump(gen_nested(seed, k), f, indent=0)
+            print("wrote nested_k%d" % k)
+        return
     if "--step-only" in sys.argv:          # (the other files are unchanged by rounds 4-5: their domains are powers of two under both rules)
         with open(os.path.join(HERE, "step_domain.json"), "w") as f:
             json.dump(gen_step_domain(random.Random(0x57E9)), f, indent=0)
@@ -181,6 +209,8 @@ def main():
     files = dict(field_vectors=gen_fields(rng), curve_vectors=gen_curve(rng), msm_vectors=gen_msm(rng),
                  ntt_vectors=gen_ntt(rng), groth16_small=gen_groth16(rng))
     files["step_domain"] = gen_step_domain(random.Random(0x57E9))
+    files["nested_k9"] = gen_nested(0x9E57ED, 9)
+    files["nested_k3"] = gen_nested(0x3E57ED, 3)
     for name, data in files.items():
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(data, f, indent=0)

@@ -9,7 +9,7 @@ import pytest
 from oracle import pyref as R
 from tests.helpers import fr_int, fr_limbs
 from tests.test_aggregator_host import nested_proof_limbs, nested_vk_limbs
-from tests.test_oracle_pins import load_nested_fixtures
+from tests.test_oracle_pins import load_nested_fixtures, load_nested_statement
 
 pytestmark = pytest.mark.gpu
 
@@ -253,10 +253,11 @@ def test_sixteen_batches_of_a_32_proof_round(zk):
 @pytest.mark.parametrize("domain", [None, "step"], ids=["forced-pow2-domain", "step-domain"])
 def test_nine_inputs_per_nested_proof_on_the_gpu(zk, domain):
     """(Both evaluation domains: the reference's forced 131,072 points - the default - and the optional 98,304-point step domain.)
-    The Zeth-shaped workload of libzecale/tests/aggregator/aggregator_test.cpp:222-254 (9 primary inputs per nested proof):
-    circuit, trusted setup on the GPU, witness, wrapping proof, wsnark::verify.  No Zeth proofs are in the tree: the nested key is
-    padded with further G1 points of the fixtures, so the nested proofs are INVALID for it and the wrapping proof must carry result
-    bits 0 (aggregator_circuit.hpp:51-54) together with the 18 nested inputs."""
+    The reference's slow test, libzecale/tests/aggregator/aggregator_test.cpp:222-254,293-314: two VALID nine-input nested proofs
+    -> circuit, trusted setup on the GPU, witness, wrapping proof, wsnark::verify == true with result bits {1,1}.  No Zeth proof is
+    in the tree: the nested statements are built from a known trapdoor (tests/golden/nested_k9.json, pinned by the oracle's verifier
+    in tests/test_oracle_pins.py).  Round 6: until then the nested key was padded with unrelated points and the only result bits any
+    nine-input run had ever produced were 0 - that all-reject case is kept at the end."""
     k = 9
     agg = zk.AggregatorCircuit(2, k)
     assert agg.num_primary_inputs() == 2 + 2 * k
@@ -266,25 +267,40 @@ def test_nine_inputs_per_nested_proof_on_the_gpu(zk, domain):
     vk = kp.vk()
     assert vk["ABC"].shape[0] == 2 + 2 * k + 1
     crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)          # (the handle starts on the default domain and follows the key)
-    nvk, proofs = load_nested_fixtures()
-    nvk9 = dict(nvk)
-    nvk9["ABC"] = list(nvk["ABC"]) + [proofs[i][0]["a"] for i in range(6)] + [proofs[0][0]["c"], proofs[1][0]["c"]]
+    nvk9, valid = load_nested_statement(k)
     nvk_l = nested_vk_limbs(nvk9)
-    xs = [[1000 * p + j for j in range(k)] for p in range(2)]
-    z = agg.witness(nvk_l, np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])]),
-                    np.array([fr_limbs(x) for row in xs for x in row]))
-    assert r1.is_satisfied(z)
-    proof = zk.groth16_prove(crs, r1, z, fr_limbs(0xabcdef), fr_limbs(0xfedcba))
-    prim = z[1:1 + agg.num_primary_inputs()]
-    assert zk.groth16_verify(vk, prim, proof)
-    assert fr_int(prim[0]) == R.nested_vk_hash(nvk9) and fr_int(prim[1]) == 0
-    assert [fr_int(x) for x in prim[2:]] == xs[0] + xs[1]
-    # the same batch through the streaming prover
+    npr = np.concatenate([nested_proof_limbs(valid[0][0]), nested_proof_limbs(valid[1][0])])
     pipe = zk.AggregatorPipeline(agg, crs, gpu_slots=2, witness_workers=2)
-    t = pipe.submit(nvk_l, np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])]),
-                    np.array([fr_limbs(x) for row in xs for x in row]), fr_limbs(0xabcdef), fr_limbs(0xfedcba))
-    prim2, proof2 = pipe.wait(t)
-    assert (prim2 == prim).all() and (proof2 == proof).all()
+    # valid batch: bits 3; input j of proof 0 / proof 1 / both bumped: 2 / 1 / 0 (j = first, middle, last of the accumulator)
+    cases = [((), 3)] + [c for j in (0, 4, 8) for c in ((((0, j),), 2), (((1, j),), 1), (((0, j), (1, j)), 0))]
+    for i, (bumps, bits) in enumerate(cases):
+        xs = [list(valid[0][1]), list(valid[1][1])]
+        for p, j in bumps:
+            xs[p][j] = (xs[p][j] + 1) % R.BLS_R
+        nin = np.array([fr_limbs(x) for row in xs for x in row])
+        r, s = fr_limbs(0xabcdef + i), fr_limbs(0xfedcba + 3 * i)
+        ticket = pipe.submit(nvk_l, npr, nin, r, s)               # the streaming prover ...
+        z = agg.witness(nvk_l, npr, nin)                          # ... and the serial path
+        assert r1.is_satisfied(z)
+        proof = zk.groth16_prove(crs, r1, z, r, s)
+        prim = z[1:1 + agg.num_primary_inputs()]
+        assert zk.groth16_verify(vk, prim, proof)
+        assert fr_int(prim[0]) == R.nested_vk_hash(nvk9) and fr_int(prim[1]) == bits, (bumps, fr_int(prim[1]))
+        assert [fr_int(x) for x in prim[2:]] == xs[0] + xs[1]
+        prim2, proof2 = pipe.wait(ticket)
+        assert (prim2 == prim).all() and (proof2 == proof).all()
+        # the proof is a proof of THESE bits: with a result bit flipped in the primary input it does not verify
+        forged = prim.copy(); forged[1] = fr_limbs(bits ^ 1)
+        assert not zk.groth16_verify(vk, forged, proof)
+    # the all-reject case of rounds 3-5: a nested key padded with unrelated points of the reference's fixtures
+    nvk, proofs = load_nested_fixtures()
+    nvkp = dict(nvk)
+    nvkp["ABC"] = list(nvk["ABC"]) + [proofs[i][0]["a"] for i in range(6)] + [proofs[0][0]["c"], proofs[1][0]["c"]]
+    xs = [[1000 * p + j for j in range(k)] for p in range(2)]
+    z = agg.witness(nested_vk_limbs(nvkp), np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])]),
+                    np.array([fr_limbs(x) for row in xs for x in row]))
+    assert r1.is_satisfied(z) and fr_int(z[1]) == R.nested_vk_hash(nvkp) and fr_int(z[2]) == 0
+    assert zk.groth16_verify(vk, z[1:1 + agg.num_primary_inputs()], zk.groth16_prove(crs, r1, z, fr_limbs(1), fr_limbs(2)))
     pipe.free()
     crs.free(); r1.free(); kp.free(); agg.free()
 

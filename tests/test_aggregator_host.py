@@ -9,7 +9,7 @@ import pytest
 
 from oracle import pyref as R
 from tests.helpers import fr_int, fr_limbs
-from tests.test_oracle_pins import load_nested_fixtures
+from tests.test_oracle_pins import load_nested_fixtures, load_nested_statement
 
 
 def _fl(x):
@@ -47,6 +47,23 @@ def test_native_nested_verifier_on_reference_fixtures():
         assert zkhip.bls12_377_groth16_verify(vk, np.array([fr_limbs(inputs[0])]), nested_proof_limbs(pr))
     pr, inputs = proofs[2]
     assert not zkhip.bls12_377_groth16_verify(vk, np.array([fr_limbs(inputs[0] + 1)]), nested_proof_limbs(pr))
+
+
+@pytest.mark.parametrize("k", [3, 9])
+def test_native_nested_verifier_with_several_inputs(k):
+    """zkhip_bls12_377_groth16_verify on VALID statements with more than one input (tests/golden/nested_k{3,9}.json, pinned by
+    tests/test_oracle_pins.py::test_nested_statements_from_a_trapdoor): all three proofs accepted, every single bumped input and
+    a foreign proof's inputs rejected - the same decisions as the oracle's verifier, position by position."""
+    from zecale_amd import zkhip
+    nvk, proofs = load_nested_statement(k)
+    vk = nested_vk_limbs(nvk)
+    ins = lambda xs: np.array([fr_limbs(x) for x in xs])
+    for pr, xs in proofs:
+        assert zkhip.bls12_377_groth16_verify(vk, ins(xs), nested_proof_limbs(pr))
+        for j in range(k):
+            bad = list(xs); bad[j] = (bad[j] + 1) % R.BLS_R
+            assert not zkhip.bls12_377_groth16_verify(vk, ins(bad), nested_proof_limbs(pr)), j
+    assert not zkhip.bls12_377_groth16_verify(vk, ins(proofs[1][1]), nested_proof_limbs(proofs[0][0]))
 
 
 def test_circuit_shape(circuit):
@@ -108,8 +125,49 @@ def test_other_batch_sizes(oracle_lib, num_proofs):
     c.free()
 
 
-def test_nine_inputs_per_nested_proof(oracle_lib):
-    """A Zeth joinsplit proof has 9 primary inputs (BASELINE configs[4]).  No such nested proofs are in the tree, so the nested
+def _bumps(k):
+    """(proof, input position) pairs to bump, and the result bits each leaves: the accept branch and all three reject patterns,
+    at the first, a middle and the last input of the accumulator acc = ABC_0 + sum x_j ABC_j."""
+    out = [((), 3)]
+    for j in sorted({0, k // 2, k - 1}):
+        out += [(((0, j),), 2), (((1, j),), 1), (((0, j), (1, j)), 0)]
+    return out
+
+
+@pytest.mark.parametrize("k", [3, 9])
+def test_valid_nested_proofs_with_several_inputs(oracle_lib, k):
+    """The reference's slow test (libzecale/tests/aggregator/aggregator_test.cpp:222-254,293-314): a batch of two VALID nine-input
+    nested proofs gives result bits {1,1}; here with the trapdoor-built statements of tests/golden/nested_k{3,9}.json (no Zeth
+    proof is in the tree).  The in-circuit verifier's ACCEPT branch for inputs 2..k: bits 3 for the valid batch, 2 / 1 / 0 when
+    input j of proof 0 / 1 / both is bumped (j = first, middle, last) - and every assignment satisfies every constraint under
+    the oracle, so the bit is what the constraints force, not what the generator chose."""
+    from zecale_amd import zkhip
+    c = zkhip.AggregatorCircuit(2, k)
+    nvk, proofs = load_nested_statement(k)
+    vk = nested_vk_limbs(nvk)
+    npr = np.concatenate([nested_proof_limbs(proofs[0][0]), nested_proof_limbs(proofs[1][0])])
+    A, B, C = c.get_constraint_system()
+    for bumps, bits in _bumps(k):
+        xs = [list(proofs[0][1]), list(proofs[1][1])]
+        for p, j in bumps:
+            xs[p][j] = (xs[p][j] + 1) % R.BLS_R
+        z = c.witness(vk, npr, np.array([fr_limbs(x) for row in xs for x in row]))
+        assert fr_int(z[2]) == bits, (bumps, fr_int(z[2]))
+        assert (z[1] == zkhip.aggregator_vk_hash(vk, k)).all() and fr_int(z[1]) == R.nested_vk_hash(nvk)
+        assert [fr_int(z[3 + i]) for i in range(2 * k)] == xs[0] + xs[1]
+        if len(bumps) != 1 or bumps[0][1] == k // 2:                 # (the oracle's pass over 92 k constraints: ~1 s each)
+            assert oracle_lib.r1cs_first_unsatisfied(A, B, C, z) == -1
+            zb = z.copy(); zb[2] = fr_limbs(bits ^ 1)               # ... and the OTHER value of a result bit violates one
+            assert oracle_lib.r1cs_first_unsatisfied(A, B, C, zb) >= 0
+    # the second and third proof in the other order: bits follow the proofs, not the positions
+    z = c.witness(vk, np.concatenate([nested_proof_limbs(proofs[2][0]), nested_proof_limbs(proofs[1][0])]),
+                  np.array([fr_limbs(x) for x in proofs[2][1] + proofs[0][1]]))
+    assert fr_int(z[2]) == 1                                         # proof 1 with proof 0's inputs: rejected
+    c.free()
+
+
+def test_nine_inputs_under_an_unrelated_key(oracle_lib):
+    """(Rounds 3-5's nine-input case, kept as the all-reject case.)  The nested
     key is padded with further G1 points from the fixtures and the inputs are arbitrary: the nested proofs are then INVALID, which
     the circuit must accept with result bits 0 (aggregator_circuit.hpp:51-54) - the witness satisfies every constraint."""
     from zecale_amd import zkhip

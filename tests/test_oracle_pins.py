@@ -109,6 +109,44 @@ def test_reference_nested_bls12_377_groth16_kats():
     assert not R.bls12_377_groth16_verify(nvk, pr, [inputs[0] + 1])
 
 
+def load_nested_statement(k):
+    """tests/golden/nested_k{k}.json: a nested BLS12-377 key with k public inputs and three VALID proofs for it, built from a known
+    trapdoor by tests/golden/gen_golden.py (round 6) - the same JSON shapes as the reference's vk.json / extproof*.json."""
+    j = golden(f"nested_k{k}.json")
+    g2 = lambda p: ((h2i(p[0][1]), h2i(p[0][0])), (h2i(p[1][1]), h2i(p[1][0])))   # JSON order is [c1, c0]
+    vk = j["vk"]
+    nvk = dict(alpha=pt_from_json(vk["alpha"]), beta=g2(vk["beta"]), delta=g2(vk["delta"]), ABC=[pt_from_json(p) for p in vk["ABC"]])
+    proofs = [(dict(a=pt_from_json(e["proof"]["a"]), b=g2(e["proof"]["b"]), c=pt_from_json(e["proof"]["c"])), [h2i(x) for x in e["inputs"]])
+              for e in j["proofs"]]
+    return nvk, proofs
+
+
+@pytest.mark.parametrize("k", [3, 9])
+def test_nested_statements_from_a_trapdoor(k):
+    """The valid k-input nested statements (the reference's slow test aggregates valid NINE-input Zeth proofs and expects
+    verify == true: libzecale/tests/aggregator/aggregator_test.cpp:222-254,293-314; none is in the tree, so these are built from
+    known toxic waste).  The verifier that the reference's own six proofs pin (test above) accepts all three, rejects the first
+    with ANY one input bumped, and rejects a proof paired with another proof's inputs; the generator reproduces the committed
+    file from its seed (the fixture is what the script makes)."""
+    nvk, proofs = load_nested_statement(k)
+    assert len(nvk["ABC"]) == k + 1 and len(proofs) == 3
+    assert R.on_curve(R.BLS_G1_GEN, R.BLS_G1_B, R.BLS_Q) and R.ec_mul(R.BLS_R, R.BLS_G1_GEN, R.BLS_Q) is None
+    for P in [nvk["alpha"]] + nvk["ABC"] + [pr["a"] for pr, _ in proofs] + [pr["c"] for pr, _ in proofs]:
+        assert R.on_curve(P, R.BLS_G1_B, R.BLS_Q)
+    for Q in [nvk["beta"], nvk["delta"]] + [pr["b"] for pr, _ in proofs]:
+        assert R.bls_g2_on_curve(Q)
+    for pr, xs in proofs:
+        assert len(xs) == k and len(set(xs)) == k and all(x.bit_length() > 200 for x in xs)     # full-size inputs, as a Zeth proof's
+        assert R.bls12_377_groth16_verify(nvk, pr, xs)
+    pr, xs = proofs[0]
+    for j in range(k):
+        bad = list(xs); bad[j] = (bad[j] + 1) % R.BLS_R
+        assert not R.bls12_377_groth16_verify(nvk, pr, bad), j
+    assert not R.bls12_377_groth16_verify(nvk, pr, proofs[1][1])
+    vk2, proofs2 = R.bls12_377_groth16_statement_from_trapdoor(__import__("random").Random({9: 0x9E57ED, 3: 0x3E57ED}[k]), k, 3)
+    assert vk2 == nvk and proofs2 == proofs
+
+
 # ---------------------------------------------------------------- 2. C oracle vs golden vectors
 def test_c_oracle_fields(oracle_lib):
     O = oracle_lib

@@ -8,13 +8,14 @@ W=${TMPDIR:-/tmp}/zkhip_asan
 CL=/opt/rocm/lib/llvm/bin/clang++
 RT=$(find /opt/rocm/lib/llvm -name 'libclang_rt.asan-x86_64.so' | head -1)
 rm -rf $W && mkdir -p $W/repo/zecale_amd && cd $W
-for f in msm ntt qap zkhip_api; do
+for f in msm ntt qap zkhip_api witness; do
   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -DZK_MUL_INLINE=1 -fPIC -fsanitize=address -shared-libsan -Wno-option-ignored -c $ROOT/zecale_amd/csrc/$f.hip -o $f.o &
 done
-$CL -O1 -g -std=c++17 -fPIC -pthread -fsanitize=address -shared-libsan -c $ROOT/zecale_amd/csrc/aggregator.cpp -o aggregator.o &
-$CL -O1 -g -std=c++17 -fPIC -pthread -fsanitize=address -shared-libsan -c $ROOT/zecale_amd/csrc/pipeline.cpp -o pipeline.o &
+for f in aggregator pipeline witness_tape multi_device; do
+  $CL -O1 -g -std=c++17 -fPIC -pthread -fsanitize=address -shared-libsan -c $ROOT/zecale_amd/csrc/$f.cpp -o $f.o &
+done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -pthread -fsanitize=address -shared-libsan -o repo/zecale_amd/libzkhip.so msm.o ntt.o qap.o zkhip_api.o aggregator.o pipeline.o
+hipcc --offload-arch=gfx950 -shared -fPIC -pthread -fsanitize=address -shared-libsan -o repo/zecale_amd/libzkhip.so msm.o ntt.o qap.o zkhip_api.o witness.o aggregator.o pipeline.o witness_tape.o multi_device.o
 cp $ROOT/zecale_amd/*.py repo/zecale_amd/
 for d in tests oracle include bench.py; do ln -s $ROOT/$d repo/$d; done
 cd repo

@@ -249,8 +249,10 @@ struct FixedBase8 {
   static constexpr int W = 48;                 // ceil(377 / 8)
   std::vector<HFq> xy;                         // [w][d - 1] -> x, y
   bool base_inf = true;
+  bool ok = true;                              // false: a multiple was the point at infinity (see build) - the table must not be used
   void build(const HJac& P) {
     base_inf = P.is_inf();
+    ok = true;
     xy.assign((size_t)W * 255 * 2, HFq::zero());
     if (base_inf) return;
     std::vector<HJac> pts((size_t)W * 255);
@@ -260,7 +262,12 @@ struct FixedBase8 {
       for (int d = 1; d <= 255; d++) { pts[(size_t)w * 255 + d - 1] = acc; acc = acc.add(step); }
       step = acc;                              // 256 step
     }
-    // batch normalisation (a multiple of a point of prime order r by d 2^(8w) < r is never the point at infinity)
+    // batch normalisation: one inversion for all 48 x 255 multiples.  A multiple d 2^(8w) P (< r) of a point of prime order r is
+    // never the point at infinity; a key read from a FILE is only checked to lie on the curve, and a delta with a small-order
+    // component would put a zero Z into the running product and turn every entry into garbage: such a table is
+    // marked unusable and the tail falls back to variable-base multiplications, which are correct for any point.
+    for (const HJac& q : pts)
+      if (q.is_inf()) { ok = false; xy.clear(); return; }
     std::vector<HFq> pre(pts.size());
     HFq run = HFq::one();
     for (size_t i = 0; i < pts.size(); i++) { pre[i] = run; run = run * pts[i].Z; }

@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -35,6 +36,15 @@ namespace {
 struct AppEntry {
   zkhip_aggregator_app* app = nullptr;
   int state = 0;                  // 0: being built, 1: ready, 2: could not be built (its batches take the plain path and report their own errors)
+  uint64_t last_used = 0;         // the pipeline's application clock at the last batch (the table evicts its least recently used entry)
+  // An entry leaves the table when it is evicted or when the pipeline is freed; batches in flight keep it alive through their
+  // shared_ptr, so the handle is freed by whoever drops the last reference - on whatever thread, whose library device is restored.
+  ~AppEntry() {
+    if (!app) return;
+    const int saved = zkhip_get_device();
+    zkhip_aggregator_app_free(app);
+    if (saved >= 0) (void)zkhip_set_device(saved);
+  }
 };
 struct Job {
   std::shared_ptr<AppEntry> app;  // set: the assignment is MASKED and the proof goes through zkhip_prover_prove_app[_dev]
@@ -54,7 +64,10 @@ struct zkhip_pipeline {
   const zkhip_crs* crs = nullptr;
   bool app_cache = true;                         // per-application constants (off: ZKHIP_PIPELINE_NO_APP_CACHE)
   std::mutex mu_apps;
-  std::map<std::vector<uint64_t>, std::shared_ptr<AppEntry>> apps;      // by nested key
+  std::map<std::vector<uint64_t>, std::shared_ptr<AppEntry>> apps;      // by nested key: being built or ready
+  std::set<std::vector<uint64_t>> bad_apps;      // keys that could not be given a handle (off-curve, degenerate): remembered, NOT counted against the table
+  uint64_t app_clock = 0;
+  bool app_evict_logged = false;
   std::atomic<uint64_t> st_app_hits{0};
   // assignment buffers (n_vars x 48 bytes: 2-4 MB) are reused from job to job: allocated per job they are mmap'ed and munmap'ed by the
   // allocator, and ten generator threads doing that held the process in the kernel (aggregator.cpp: SectionPool)
@@ -112,26 +125,42 @@ void lower_priority() {
 }
 
 constexpr size_t MAX_APPS = 32;          // per pipeline: each holds ~15 MB on the host and ~13 MB on the device
+constexpr size_t MAX_BAD_APPS = 256;     // negative cache (keys only: a few hundred bytes each)
 
-// The application of a batch's nested key, built on first sight.  Null: no cache, the table is full, the handle is still being
-// built by another thread, or it could not be built - the batch then takes the plain path.
+// The application of a batch's nested key, built on first sight.  Null: no cache, the handle is still being built by another
+// thread, every entry of a full table is still being built, or the key cannot have a handle - the batch then takes the plain path.
+// A full table evicts its least recently used READY entry (round 6, ADVICE r5: until then the 33rd key of a pipeline's life - valid
+// or not - and every key after it silently took the plain path for good, and failed builds held their places for ever).
 std::shared_ptr<AppEntry> find_app(zkhip_pipeline* p, const std::vector<uint64_t>& vk, bool wait_for_build = false) {
   if (!p->app_cache) return nullptr;
-  std::shared_ptr<AppEntry> e;
+  std::shared_ptr<AppEntry> e, evicted;
   {
     std::lock_guard<std::mutex> lk(p->mu_apps);
     auto it = p->apps.find(vk);
     if (it != p->apps.end()) {
-      if (it->second->state == 1) return it->second;
-      if (!wait_for_build || it->second->state == 2) return nullptr;
+      if (it->second->state == 1) { it->second->last_used = ++p->app_clock; return it->second; }
+      if (!wait_for_build) return nullptr;
       e = it->second;
     } else {
-      if (p->apps.size() >= MAX_APPS) return nullptr;
+      if (p->bad_apps.count(vk)) return nullptr;
+      if (p->apps.size() >= MAX_APPS) {
+        auto lru = p->apps.end();
+        for (auto jt = p->apps.begin(); jt != p->apps.end(); ++jt)
+          if (jt->second->state == 1 && (lru == p->apps.end() || jt->second->last_used < lru->second->last_used)) lru = jt;
+        if (lru == p->apps.end()) return nullptr;             // (all being built)
+        if (!p->app_evict_logged) {
+          p->app_evict_logged = true;
+          fprintf(stderr, "zkhip pipeline: more than %zu applications in use - evicting the least recently used handle (logged once)\n", MAX_APPS);
+        }
+        evicted = lru->second;                                  // (freed below, outside the lock, unless batches in flight still hold it)
+        p->apps.erase(lru);
+      }
       e = std::make_shared<AppEntry>();
       p->apps[vk] = e;
       wait_for_build = false;
     }
   }
+  evicted.reset();
   if (wait_for_build) {                         // (registration of a key a worker is already building: poll, it takes ~0.2 s)
     for (int i = 0; i < 2000; i++) {
       { std::lock_guard<std::mutex> lk(p->mu_apps); if (e->state) break; }
@@ -140,12 +169,24 @@ std::shared_ptr<AppEntry> find_app(zkhip_pipeline* p, const std::vector<uint64_t
     std::lock_guard<std::mutex> lk(p->mu_apps);
     return e->state == 1 ? e : nullptr;
   }
+  // (a registration comes from the caller's thread - a gRPC handler: its library device is put back)
+  const int saved = zkhip_get_device();
   zkhip_aggregator_app* app = nullptr;
   const int rc = (zkhip_set_device(p->device) == ZKHIP_OK) ? zkhip_aggregator_app_new(p->agg, p->crs, vk.data(), &app) : ZKHIP_ERR_STATE;
+  if (saved >= 0 && saved != p->device) (void)zkhip_set_device(saved);
   std::lock_guard<std::mutex> lk(p->mu_apps);
-  e->app = app;
-  e->state = rc == ZKHIP_OK ? 1 : 2;
-  return rc == ZKHIP_OK ? e : nullptr;
+  if (rc == ZKHIP_OK) {
+    e->app = app;
+    e->state = 1;
+    e->last_used = ++p->app_clock;
+    return e;
+  }
+  e->state = 2;                                 // (a registration polling this entry sees the failure)
+  auto it = p->apps.find(vk);
+  if (it != p->apps.end() && it->second == e) p->apps.erase(it);
+  if (p->bad_apps.size() >= MAX_BAD_APPS) p->bad_apps.clear();
+  p->bad_apps.insert(vk);
+  return nullptr;
 }
 
 // overflow_only (a HYBRID pipeline's host generators): take a batch only while MORE than one full witness launch is queued - what
@@ -222,7 +263,6 @@ void gpu_witness_loop(zkhip_pipeline* p) {
       if (jobs.empty()) continue;                     // another batcher took them while this one waited for a slab
       slab = p->slab_free.back(); p->slab_free.pop_back();
     }
-    std::shared_ptr<AppEntry> app = find_app(p, jobs[0]->vk);
     for (auto& j : jobs) {
       int wf = 0;
       int rc = zkhip_aggregator_check_inputs(p->agg, j->vk.data(), j->proofs.data(), &wf);
@@ -230,6 +270,8 @@ void gpu_witness_loop(zkhip_pipeline* p) {
       if (rc == ZKHIP_OK) good.push_back(j);
       else { std::lock_guard<std::mutex> lk(p->mu); finish_failed(p, j, rc); }
     }
+    // (after the input check: a key with a point off its curve never reaches the handle builder from here)
+    std::shared_ptr<AppEntry> app = good.empty() ? nullptr : find_app(p, good[0]->vk);
     int rc = ZKHIP_OK;
     if (!good.empty()) {
       vks.clear(); prs.clear(); ins.clear();
@@ -407,7 +449,7 @@ void zkhip_aggregator_pipeline_free(zkhip_pipeline* p) {
             (unsigned long long)p->st_prove_n.load(), p->st_prove_ns / 1e6 / p->st_prove_n, p->st_slot_wait_ns / 1e6 / p->st_prove_n,
             (unsigned long long)p->st_wit_n.load(), p->st_wit_n ? p->st_wit_ns / 1e6 / p->st_wit_n : 0.0, (unsigned long long)p->st_app_hits.load(), p->apps.size());
   for (zkhip_prover* q : p->provers) zkhip_prover_free(q);
-  for (auto& kv : p->apps) zkhip_aggregator_app_free(kv.second->app);
+  p->apps.clear();                               // (~AppEntry frees the handles)
   for (auto& q : p->slabs) zkhip_device_free(q.base);
   delete p;
 }
@@ -421,8 +463,7 @@ int zkhip_aggregator_pipeline_register_app(zkhip_pipeline* p, const uint64_t* ne
   // no handle: the key could not be given one (a point off its curve, a degenerate key: ZKHIP_ERR_ARG - its batches will be proved by
   // the plain path and report their own errors), or the pipeline's table of applications is full (the cache is best effort: OK)
   std::lock_guard<std::mutex> lk(p->mu_apps);
-  auto it = p->apps.find(vk);
-  return (it != p->apps.end() && it->second->state == 2) ? ZKHIP_ERR_ARG : ZKHIP_OK;
+  return p->bad_apps.count(vk) ? ZKHIP_ERR_ARG : ZKHIP_OK;
 }
 size_t zkhip_aggregator_pipeline_app_hits(const zkhip_pipeline* p) { return p ? (size_t)p->st_app_hits.load() : 0; }
 

@@ -288,8 +288,8 @@ static void free_domain_buffers(R1csDev* r) {
 // Everything of a constraint system that depends on its evaluation domain: the three work vectors, 1 / Z on the coset and, for a
 // step domain, the powers of its element-wise halves.  The matrices do not.  A handle can be moved to another domain (the proving
 // key decides: zkhip_groth16_prove with a key of another valid domain size); the caller makes sure nothing is in flight on it.
+static int r1cs_build_domain(R1csDev* r, size_t want, char* err, size_t errlen);
 int r1cs_set_domain(R1csDev* r, size_t domain_size, char* err, size_t errlen) {
-  using host::HFr;
   const size_t points = r->n_constraints + r->n_primary + 1;
   const size_t want = host::resolve_domain(points, domain_size);
   if (!want) {
@@ -297,8 +297,21 @@ int r1cs_set_domain(R1csDev* r, size_t domain_size, char* err, size_t errlen) {
     return ZKHIP_ERR_ARG;
   }
   if (want > ((size_t)1 << 22)) { snprintf(err, errlen, "r1cs: domain larger than 2^22"); return ZKHIP_ERR_ARG; }
-  if (want == r->d && r->bufA) return ZKHIP_OK;
+  if (want == r->d && r->bufA) return ZKHIP_OK;           // (r->d != 0 only after EVERY buffer of that domain was built: below)
   free_domain_buffers(r);
+  const int rc = r1cs_build_domain(r, want, err, errlen);
+  if (rc != ZKHIP_OK) {
+    // A failure half-way (an allocation refused while a 32-instance pipeline holds the HBM) must not leave the handle NAMING the new
+    // domain over freed / null buffers - the next prove through it would launch the QAP kernels on null pointers.  The
+    // handle is left on NO domain: r->d = 0 matches no key, so follow_key_domain and this function rebuild on the next call.
+    free_domain_buffers(r);
+    r->d = r->big = r->small = 0;
+    r->log_d = r->log_big = r->log_small = 0;
+  }
+  return rc;
+}
+static int r1cs_build_domain(R1csDev* r, size_t want, char* err, size_t errlen) {
+  using host::HFr;
   const host::EvalDomain dom(want);
   r->d = dom.m; r->big = dom.big; r->small = dom.small;
   r->log_d = host::ceil_log2(dom.m); r->log_big = dom.log_big; r->log_small = dom.log_small;
@@ -419,6 +432,10 @@ static int step_ntts(R1csDev* r, uint32_t* const* bufs, int nbuf, int inverse, i
 }
 
 int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, size_t errlen, const uint64_t* d_z_app) {
+  if (!r->d || !r->bufA || !r->bufB || !r->bufC || !r->zinv) {           // (a domain switch that failed: r1cs_set_domain)
+    snprintf(err, errlen, "constraint system handle has no evaluation domain (an earlier domain switch failed)");
+    return ZKHIP_ERR_ARG;
+  }
   const int lg = r->log_d;
   const uint32_t d = (uint32_t)r->d;
   if (d_z_app) fr_abi_to_dev_merge(d_z_abi, d_z_app, r->z, r->n_vars, st);       // masked assignment | the application's constants
@@ -455,6 +472,10 @@ int qap_h_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, char* err, si
 }
 
 int r1cs_is_satisfied_dev(R1csDev* r, const uint64_t* d_z_abi, hipStream_t st, int* ok, char* err, size_t errlen) {
+  if (!r->d || !r->bufA || !r->bufB || !r->bufC) {
+    snprintf(err, errlen, "constraint system handle has no evaluation domain (an earlier domain switch failed)");
+    return ZKHIP_ERR_ARG;
+  }
   fr_abi_to_dev(d_z_abi, r->z, r->n_vars, st);
   spmv3(r, st);
   uint32_t* flag = r->tmp;   // first word of the scratch buffer

@@ -921,6 +921,13 @@ struct TailPre {
   bool started = false;
   uint64_t rc_[6], sc_[6], rsc_[6];
   std::future<host::HJac> rd1, sd2, sd1, rsd1;
+  // A packaged_task's future does not block in its destructor (std::async's did): a proof that fails between tail_begin and
+  // finish_impl must not return while a zk-tail worker still holds the key's tables.  The tasks themselves capture
+  // their scalars BY VALUE, so nothing in the pool points into this object either.
+  ~TailPre() {
+    for (std::future<host::HJac>* f : {&rd1, &sd2, &sd1, &rsd1})
+      if (f->valid()) f->wait();
+  }
 };
 // The tail's scalar multiplications run on a small pool of host threads ("zk-tail"; round 5: rounds 2-4 started a std::async thread
 // per multiplication - six thread creations per proof, 2,400 a second in a stream).  Tasks are ~0.15 ms (fixed-base, with the key's
@@ -967,8 +974,11 @@ class TailPool {
   std::deque<std::function<void()>> q_;
 };
 }  // namespace
+struct TailScalar { uint64_t v[6]; };
+static TailScalar tail_scalar(const uint64_t* k) { TailScalar t; memcpy(t.v, k, sizeof t.v); return t; }
 static std::future<host::HJac> tail_smul(host::HJac p, const uint64_t* k) {
-  return TailPool::get().run([p, k]() { return p.mul_canonical(k, 6); });
+  const TailScalar kv = tail_scalar(k);
+  return TailPool::get().run([p, kv]() { return p.mul_canonical(kv.v, 6); });
 }
 // tab: the key's fixed-base tables (null: the plain zkhip_groth16_finish, which is handed raw points: variable-base products)
 static void tail_begin(TailPre& tp, const uint64_t delta_g1[24], const uint64_t delta_g2[24], const uint64_t r_m[6], const uint64_t s_m[6],
@@ -977,11 +987,11 @@ static void tail_begin(TailPre& tp, const uint64_t delta_g1[24], const uint64_t 
   HFr r = HFr::from_limbs(r_m), s = HFr::from_limbs(s_m), rs = r * s;
   r.to_canonical(tp.rc_); s.to_canonical(tp.sc_); rs.to_canonical(tp.rsc_);
   if (tab) {
-    const uint64_t *rc = tp.rc_, *sc = tp.sc_, *rsc = tp.rsc_;
-    tp.rd1 = TailPool::get().run([tab, rc] { return tab->d1.mul(rc); });
-    tp.sd2 = TailPool::get().run([tab, sc] { return tab->d2.mul(sc); });
-    tp.sd1 = TailPool::get().run([tab, sc] { return tab->d1.mul(sc); });
-    tp.rsd1 = TailPool::get().run([tab, rsc] { return tab->d1.mul(rsc); });
+    const TailScalar rc = tail_scalar(tp.rc_), sc = tail_scalar(tp.sc_), rsc = tail_scalar(tp.rsc_);
+    tp.rd1 = TailPool::get().run([tab, rc] { return tab->d1.mul(rc.v); });
+    tp.sd2 = TailPool::get().run([tab, sc] { return tab->d2.mul(sc.v); });
+    tp.sd1 = TailPool::get().run([tab, sc] { return tab->d1.mul(sc.v); });
+    tp.rsd1 = TailPool::get().run([tab, rsc] { return tab->d1.mul(rsc.v); });
   } else {
     auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
     const HJac d1 = aff(delta_g1), d2 = aff(delta_g2);
@@ -999,7 +1009,7 @@ static const TailTables* crs_tail_tables(const zkhip_crs* c) {
     t->d2.build(aff(c->delta_g2));
     c->tail = std::move(t);
   });
-  return c->tail.get();
+  return (c->tail->d1.ok && c->tail->d2.ok) ? c->tail.get() : nullptr;       // (not ok: variable-base products in tail_begin)
 }
 
 static int finish_impl(const uint64_t alpha_g1[24], const uint64_t beta_g1[24], const uint64_t beta_g2[24], const uint64_t delta_g1[24],
@@ -1943,6 +1953,70 @@ int zkhip_internal_field_selftest(int field, const uint32_t* limbs_in, size_t n,
   if ((field != 0 && field != 1) || (n && (!limbs_in || !limbs_out)) || n > (1u << 20)) return fail(ZKHIP_ERR_ARG, "field 0 (Fq) or 1 (Fr), at most 2^20 cases");
   std::lock_guard<std::mutex> lk(g.dev[cur_dev()].mu);
   return msm_field_selftest(field, limbs_in, n, limbs_out, t_err, sizeof t_err);
+}
+
+// Host only (no device needed): the prover's tail on the paths a healthy proof never takes.
+//  (1) `rounds` proofs that FAIL between tail_begin and finish_impl: the TailPre goes out of scope with its four tasks queued and the
+//      key's tables are freed straight after - under the CPU AddressSanitizer build (tools/sanitize/asan_host_tests.sh) a task that
+//      outlives either is a use-after-scope / use-after-free report (packaged_task futures do not wait in ~future);
+//  (2) a delta with a small-order component: FixedBase8 must refuse the table (ok == false) and the tail must fall back to
+//      variable-base products that equal k P computed directly; a healthy table must equal the variable-base product too.
+// g1 / g2: points of order r (the curve generators); small: a point of small order on G1's curve ((1, 0) has order 2).
+int zkhip_internal_tail_selftest(const uint64_t g1[24], const uint64_t g2[24], const uint64_t small[24], int rounds) {
+  using namespace host;
+  if (!g1 || !g2 || !small || rounds < 0 || rounds > 100000) return fail(ZKHIP_ERR_ARG, "tail selftest: arguments");
+  auto aff = [](const uint64_t* p) { return HJac::from_affine(HFq::from_limbs(p), HFq::from_limbs(p + 12)); };
+  auto same = [](const HJac& a, const HJac& b) {
+    if (a.is_inf() || b.is_inf()) return a.is_inf() && b.is_inf();
+    HFq ax, ay, bx, by;
+    a.to_affine(ax, ay); b.to_affine(bx, by);
+    uint64_t l[4][12];
+    ax.to_limbs(l[0]); ay.to_limbs(l[1]); bx.to_limbs(l[2]); by.to_limbs(l[3]);
+    return !memcmp(l[0], l[2], 96) && !memcmp(l[1], l[3], 96);
+  };
+  uint64_t r_m[6], s_m[6];
+  HFr::from_u64(0x1234567u).to_limbs(r_m);
+  (HFr::from_u64(0x89abcdefu) * HFr::from_u64(0xfedcba98u) * HFr::from_u64(0x76543211u)).to_limbs(s_m);
+  for (int i = 0; i < rounds; i++) {
+    std::unique_ptr<TailTables> tab(new TailTables());
+    tab->d1.build(aff(g1));
+    tab->d2.build(aff(g2));
+    if (!tab->d1.ok || !tab->d2.ok) return fail(ZKHIP_ERR_STATE, "tail selftest: a prime-order table was refused");
+    {
+      TailPre pre;
+      tail_begin(pre, g1, g2, r_m, s_m, tab.get());
+    }                                            // "prove_partial failed": nobody collects the futures
+    tab.reset();                                 // "the caller frees the key"
+    {
+      TailPre pre;
+      tail_begin(pre, g1, g2, r_m, s_m);         // the variable-base form (zkhip_groth16_finish), abandoned the same way
+    }
+  }
+  // healthy table = variable base, on a full-size scalar
+  uint64_t k[6];
+  HFr::from_limbs(s_m).to_canonical(k);
+  FixedBase8 t1;
+  t1.build(aff(g1));
+  if (!t1.ok || !same(t1.mul(k), aff(g1).mul_canonical(k, 6))) return fail(ZKHIP_ERR_STATE, "tail selftest: fixed-base table differs from k P");
+  // a small-order point: table refused ...
+  FixedBase8 t2;
+  t2.build(aff(small));
+  if (t2.ok) return fail(ZKHIP_ERR_STATE, "tail selftest: the table of a small-order point was accepted");
+  // ... and the tail, handed such a delta_1 through a KEY's tables (null: refused), equals the direct computation: with zero sums
+  // and alpha = g1 the proof's A is g1 + r delta_1
+  TailTables bad;
+  bad.d1.build(aff(small)); bad.d2.build(aff(g2));
+  const TailTables* usable = (bad.d1.ok && bad.d2.ok) ? &bad : nullptr;           // (what crs_tail_tables returns)
+  if (usable) return fail(ZKHIP_ERR_STATE, "tail selftest: unusable tables were offered to the tail");
+  uint64_t sums[180] = {0}, proof[72];
+  TailPre pre;
+  tail_begin(pre, small, g2, r_m, s_m, usable);
+  const int rc = finish_impl(g1, g1, g2, small, g2, sums, r_m, s_m, proof, nullptr, &pre);
+  if (rc != ZKHIP_OK) return rc;
+  uint64_t rc_k[6];
+  HFr::from_limbs(r_m).to_canonical(rc_k);
+  if (!same(aff(proof), aff(g1).add(aff(small).mul_canonical(rc_k, 6)))) return fail(ZKHIP_ERR_STATE, "tail selftest: g1 + r delta_1 of a small-order delta_1 is wrong");
+  return ZKHIP_OK;
 }
 
 // pinned host memory for callers without a HIP runtime of their own (source of zkhip_msm_stream_submit_host's asynchronous copies)

@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkhip.so")
+# ZKHIP_LIB: another build of the same library (A/B builds, the mutation run of tools/mutation_abc5.sh); default: the in-tree one
+LIB_PATH = os.environ.get("ZKHIP_LIB") or os.path.join(_HERE, "libzkhip.so")
 
 EXPORTS = [
     "zkhip_init", "zkhip_set_device", "zkhip_get_device", "zkhip_device_count", "zkhip_fr_random", "zkhip_shutdown", "zkhip_strerror", "zkhip_last_error", "zkhip_set_msm_window", "zkhip_set_affine_levels",
@@ -30,7 +31,7 @@ EXPORTS = [
     "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
     "zkhip_last_accumulate_interval", "zkhip_crs_upload_ex", "zkhip_crs_upload_slice_ex", "zkhip_bases_precompute_ex", "zkhip_crs_table_kind", "zkhip_crs_finite_terms",
-    "zkhip_bases_set_window", "zkhip_reset_time_base", "zkhip_measure_fq_mul_rate", "zkhip_internal_field_selftest", "zkhip_host_alloc", "zkhip_host_free",
+    "zkhip_bases_set_window", "zkhip_reset_time_base", "zkhip_measure_fq_mul_rate", "zkhip_internal_field_selftest", "zkhip_internal_tail_selftest", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_msm_stream_new", "zkhip_msm_stream_submit", "zkhip_msm_stream_submit_host", "zkhip_msm_stream_collect", "zkhip_msm_stream_last_accumulate_ms",
     "zkhip_msm_stream_last_accumulate_interval", "zkhip_msm_stream_free", "zkhip_prover_new_slice", "zkhip_prover_prove_partial",
     "zkhip_dispatcher_new", "zkhip_dispatcher_size", "zkhip_dispatcher_submit", "zkhip_dispatcher_wait", "zkhip_dispatcher_stats", "zkhip_dispatcher_free",
