@@ -284,6 +284,15 @@ int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]);   /* as zkhip_last_
 /* 1 if p's last proof was chained (streaming mode, see zkhip_prover_set_streaming): slots [0] and [1] above are then the time it took
  * to ENQUEUE the upload and the QAP map, and the five MSM slots hold the whole device time of the proof */
 int zkhip_prover_timings_chained(zkhip_prover* p);
+/* (2: p's last proof was SPLIT - with ZKHIP_PROVE_SPLIT=1, an option that is OFF by default because it measured slower, a prover
+ * that is not streaming runs the four MSMs over the assignment beside the QAP map and the H MSM behind it, two launch sequences:
+ * slot [1] is then the time to enqueue the map and both sequences, the MSM slots the device time of all of it.)  The same question
+ * for the plain entry points
+ * (zkhip_groth16_prove[_partial|_app]) on the calling thread's device: */
+int zkhip_last_prove_split(void);
+/* the option itself, process-wide (provers that are NOT streaming): 0 one launch sequence (default), 1 two sequences with the H
+ * accumulation gated behind the first, 2 not gated.  Proofs are bit-identical in every mode. */
+int zkhip_set_prove_split(int mode);
 float zkhip_prover_last_accumulate_ms(zkhip_prover* p);          /* as zkhip_last_accumulate_ms, for p's last proof */
 int zkhip_prover_last_accumulate_entries(zkhip_prover* p, uint64_t* out);   /* as zkhip_last_accumulate_entries, for p's last proof */
 void zkhip_prover_free(zkhip_prover* p);
@@ -399,6 +408,10 @@ int zkhip_groth16_prove_app(const zkhip_crs* crs, zkhip_r1cs* r1cs, const zkhip_
                             const uint64_t s[6], uint64_t proof_affine[72]);
 int zkhip_prover_prove_app(zkhip_prover* p, const zkhip_aggregator_app* app, const uint64_t* z_masked, const uint64_t r[6], const uint64_t s[6],
                            uint64_t proof_affine[72]);
+/* PRECONDITION of the device form (not checked - a check would cost a pass over the assignment per proof): d_z_masked is an assignment
+ * of THIS application with zero at every constant position (zkhip_aggregator_app_constants' `positions`) - what
+ * zkhip_gpu_witness_run_batched_app writes.  The QAP map ORs the constants into it limb-wise, so a full or foreign assignment gives a
+ * wrong H and a proof that does not verify, with ZKHIP_OK.  The host forms above refuse such an assignment. */
 int zkhip_prover_prove_app_dev(zkhip_prover* p, const zkhip_aggregator_app* app, const void* d_z_masked, const uint64_t r[6], const uint64_t s[6],
                                uint64_t proof_affine[72]);
 /* zkhip_gpu_witness_run_batched for n batches of ONE application, by the application's own device program (the key folded in: no
@@ -454,6 +467,16 @@ int zkhip_groth16_setup(const zkhip_r1cs_desc* cs, const uint64_t tau[6], const 
  * libzeth's generate_setup uses (what zkhip_groth16_setup does), ZKHIP_DOMAIN_STEP = libfqfft's unforced choice, else a valid size */
 int zkhip_groth16_setup_ex(const zkhip_r1cs_desc* cs, const uint64_t tau[6], const uint64_t alpha[6], const uint64_t beta[6],
                            const uint64_t delta[6], size_t domain_size, zkhip_keypair** out);
+/* ONE RANK'S SHARE of the same setup, for a key partitioned over the GPUs of a node (BASELINE configs[3]): the exponents are
+ * evaluated on the host as above, the three index ranges are cut into `parts` contiguous slices of equal FINITE terms - the cuts
+ * zkhip_key_partition makes on a finished key: an exponent of zero is a base at infinity - and only slice `part` is multiplied out,
+ * on the device, straight into the base sets and window tables of *slice_out (a handle like zkhip_crs_upload_slice_ex's; the points
+ * never visit the host).  ranges: a_lo, a_hi, h_lo, h_hi, l_lo, l_hi of the slice.  *vk_out (optional): a keypair WITHOUT query
+ * vectors - its verification half (zkhip_keypair_vk) and the five constants zkhip_groth16_finish needs (zkhip_keypair_crs_desc).
+ * replaces: the same generate_setup call, run by N processes that each keep an N-th of pk. */
+int zkhip_groth16_setup_slice(const zkhip_r1cs_desc* cs, const uint64_t tau[6], const uint64_t alpha[6], const uint64_t beta[6],
+                              const uint64_t delta[6], size_t domain_size, int parts, int part, const zkhip_key_opts* opts,
+                              zkhip_crs** slice_out, size_t ranges[6], zkhip_keypair** vk_out);
 /* proving half: pointers into the keypair (valid while it lives) */
 int zkhip_keypair_crs_desc(const zkhip_keypair* kp, zkhip_crs_desc* out);
 /* verification half: alpha (G1), beta, delta (G2), abc = (n_primary + 1) x 24 limbs; returns n_primary + 1 */

@@ -196,6 +196,92 @@ def test_key_partitioned_prover_matches_whole_key(zk):
     whole.free(); r1.free()
 
 
+@pytest.mark.parametrize("domain", [None, "step"], ids=["forced-pow2-domain", "step-domain"])
+def test_setup_slice_is_the_slice_of_the_whole_setup(zk, domain):
+    """zkhip_groth16_setup_slice (round 6): every rank of a partitioned key evaluates the exponents, cuts by FINITE terms from the
+    exponents (zero exponent = base at infinity: the cuts zkhip_key_partition makes on the finished key) and multiplies only its own
+    slice on the device.  Against the whole setup (zkhip_groth16_setup_ex) with the same toxic waste: the ranges equal
+    zkhip_key_partition's on the whole key, the partial sums equal those of the same slice uploaded from the whole key, the
+    verification half and the tail's constants are the whole key's, and the three ranks' sums finish to the whole-key proof.
+    A boolean-heavy system with unused variables: a third of its B query is the point at infinity, so the cuts are uneven."""
+    n, n_primary = 3000, 3
+    A, B, C, z = make_r1cs(4242, n, n_primary, n + 700, 0.4)          # (700 more variables than constraints: some occur in no B row)
+    m = len(z)
+    csr = (csr_from_rows(A), csr_from_rows(B), csr_from_rows(C))
+    desc, keep = zk.make_r1cs_desc(*csr, m, n_primary)
+    td = [fr_limbs(x) for x in (0x1111111, 0x2222223, 0x3333335, 0x4444447)]
+    kp = zk.Keypair(desc, *td, domain=domain)
+    pk, m_pk, l_pk, dom = kp.pk_arrays()
+    finite = lambda a: int(np.count_nonzero(a.reshape(-1, 24).any(axis=1)))
+    assert finite(pk["B2"]) < m and finite(pk["B2"]) == finite(pk["B1"])          # (there ARE bases at infinity to cut around)
+    r1 = zk.R1cs(*csr, m, n_primary, domain=domain)
+    zl = fr_array(z)
+    rr, ss = fr_limbs(0xabcdef1), fr_limbs(0x1fedcba)
+    whole = kp.upload_crs()
+    expect = zk.groth16_prove(whole, r1, zl, rr, ss)
+    world = 3
+    cuts = zk.key_partition(pk, m, n_primary, dom, world)
+    total = None
+    for rank in range(world):
+        vk_only, sl = zk.Keypair.setup_slice(desc, *td, world, rank, domain=domain)
+        want = tuple((int(c[rank]), int(c[rank + 1])) for c in cuts)
+        assert sl.ranges == want, (sl.ranges, want)
+        ref = zk.Crs.upload_slice(pk, m, n_primary, dom, *want)
+        assert sl.finite_terms() == ref.finite_terms() and sl.table_window == ref.table_window
+        part, part_ref = zk.groth16_prove_partial(sl, r1, zl), zk.groth16_prove_partial(ref, r1, zl)
+        for k in range(5):          # (the SAME group elements: a sum's Jacobian representation depends on the order its pieces were stitched in)
+            assert (zk.jac_to_affine(part[k]) == zk.jac_to_affine(part_ref[k])).all(), (rank, k)
+        total = part if total is None else np.array([zk.jac_add(total[k], part[k]) for k in range(5)])
+        v1, v0 = vk_only.vk(), kp.vk()
+        assert all((v1[k] == v0[k]).all() for k in ("alpha", "beta", "delta", "ABC")) and vk_only.domain_size == dom
+        c1, c0 = vk_only.consts(), kp.consts()
+        assert all((c1[k] == c0[k]).all() for k in c0)
+        sl.free(); ref.free(); vk_only.free()
+    got = zk.groth16_finish(kp.consts(), total, rr, ss)
+    assert (got == expect).all() and zk.groth16_verify(kp.vk(), zl[1:1 + n_primary], got)
+    with pytest.raises(zk.ZkhipError):
+        zk.Keypair.setup_slice(desc, *td, 3, 3)
+    whole.free(); r1.free(); kp.free()
+
+
+def test_split_proof_option_gives_the_same_proof(zk):
+    """zkhip_set_prove_split (round 6; measured slower and OFF by default, profiles/r06_split_proof_ab.txt): the four MSMs that need
+    only the assignment on one plan beside the QAP map, the H MSM on a second plan behind it - the proof and the partial sums of a
+    key slice are the same group elements as with one launch sequence, for a whole key, a slice, and a prover instance."""
+    n, n_primary = 6000, 2
+    A, B, C, z = make_r1cs(99, n, n_primary, n, 0.3)
+    m = len(z)
+    csr = (csr_from_rows(A), csr_from_rows(B), csr_from_rows(C))
+    desc, keep = zk.make_r1cs_desc(*csr, m, n_primary)
+    kp = zk.Keypair(desc, *(fr_limbs(x) for x in (0x1111111, 0x2222223, 0x3333335, 0x4444447)))
+    r1, zl = zk.R1cs(*csr, m, n_primary), fr_array(z)
+    crs = kp.upload_crs()
+    rr, ss = fr_limbs(0x5151), fr_limbs(0x7171)
+    pk, _, _, dom = kp.pk_arrays()
+    cuts = zk.key_partition(pk, m, n_primary, dom, 2)
+    sl = zk.Crs.upload_slice(pk, m, n_primary, dom, *((int(c[1]), int(c[2])) for c in cuts))
+    try:
+        zk.set_prove_split(0)
+        expect = zk.groth16_prove(crs, r1, zl, rr, ss)
+        assert not zk.last_prove_split()
+        part0 = zk.groth16_prove_partial(sl, r1, zl)
+        for mode in (1, 2):
+            zk.set_prove_split(mode)
+            for _ in range(2):
+                assert (zk.groth16_prove(crs, r1, zl, rr, ss) == expect).all() and zk.last_prove_split()
+            part = zk.groth16_prove_partial(sl, r1, zl)
+            assert all((zk.jac_to_affine(part[k]) == zk.jac_to_affine(part0[k])).all() for k in range(5))
+            pr = zk.Prover(crs, desc)
+            assert (pr.prove(zl, rr, ss) == expect).all()
+            pr.free()
+        with pytest.raises(zk.ZkhipError):
+            zk.set_prove_split(3)
+    finally:
+        zk.set_prove_split(0)
+    assert zk.groth16_verify(kp.vk(), zl[1:1 + n_primary], expect)
+    sl.free(); crs.free(); r1.free(); kp.free()
+
+
 def test_full_size_2_20_key_modes_agree(zk):
     """BASELINE configs[2] size.  No oracle finishes a 2^20-constraint proof in seconds, so the full-size check is a consistency
     property: the three key modes (window tables + one launch sequence for the five MSMs, window tables + one launch sequence per

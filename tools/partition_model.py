@@ -22,7 +22,7 @@ fs = bench.FullSizeProver(zkhip, log_n)
 print("2^%d - 8 constraints; setup %.1f s; finite terms of the whole key: %s" % (log_n, time.time() - t, fs.crs.finite_terms()), flush=True)
 pk, m, l, dom = fs.kp.pk_arrays()
 fs.crs.free()
-for world in (1, 2, 4, 8):
+for world in [int(x) for x in os.environ.get("ZKHIP_MODEL_WORLDS", "1,2,4,8").split(",")]:
     for rank in sorted({0, world - 1}):
         ranges = zdist.key_slices_by_finite_terms(pk, m, l, dom, world, rank)
         by_index = zdist.key_slices(m, l, dom, world, rank)
@@ -34,7 +34,7 @@ for world in (1, 2, 4, 8):
             zkhip.groth16_prove_partial(crs, fs.r1, fs.z)
             ts.append((time.time() - t) * 1e3)
         ph = bench.phase_dict(zkhip.last_prove_timings())
-        print("N = %d rank %d: slice %s (by index it would be %s), finite terms %s, window %d: prove_partial %.1f ms (min of 3: %.1f); phases %s; k_accumulate<5> %.1f ms"
-              % (world, rank, ranges, by_index, crs.finite_terms(), crs.table_window, sum(ts) / 3, min(ts), {k: v for k, v in ph.items() if k != "host_tail"},
+        print("N = %d rank %d: slice %s (by index it would be %s), finite terms %s, window %d: prove_partial %.1f ms (min of 3: %.1f); phases %s; split %s; accumulation launches %.1f ms"
+              % (world, rank, ranges, by_index, crs.finite_terms(), crs.table_window, sum(ts) / 3, min(ts), {k: v for k, v in ph.items() if k != "host_tail"}, zkhip.last_prove_split(),
                  zkhip.last_accumulate_ms()), flush=True)
         crs.free()

@@ -434,6 +434,27 @@ __device__ __forceinline__ uint32_t slice_weight(uint32_t G, uint32_t T, uint32_
   return a < a_host ? a : a_host;
 }
 
+// Closing a run: the four coordinates go to the run's slot of the limb-major array (105 words, one 4-byte store each, 4 * stride
+// bytes apart).  -DZK_EXP_AOS_CLOSE (tools/aos_close_experiment.sh, round 6): a MEASUREMENT build that sends the same
+// 105 words to 432 contiguous bytes per slot instead - the WRITE side of an array-of-structures slot layout, readers unchanged, so
+// its results are WRONG; it exists to price the layout (WRITE_SIZE and the kernel's duration) before anybody rewrites the readers.
+#ifdef ZK_EXP_AOS_CLOSE
+#define ZK_CLOSE_RUN(acc, xs, zz, zzz, ty)                                                                          \
+  do {                                                                                                               \
+    XyzzRef aos_ = acc;                                                                                              \
+    aos_.voff = (acc.voff >> 2) * 432u;                                                                              \
+    aos_.stride_b = 4u;                                                                                              \
+    mem_st(aos_, CX, lds_ld_packed(xs)); mem_st(aos_, CZZ, lds_ld(zz)); mem_st(aos_, CZZZ, lds_ld(zzz));          \
+    mem_st(aos_, CY, ty);                                                                                            \
+  } while (0)
+#else
+#define ZK_CLOSE_RUN(acc, xs, zz, zzz, ty)                                                                          \
+  do {                                                                                                               \
+    mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));             \
+    mem_st(acc, CY, ty);                                                                                             \
+  } while (0)
+#endif
+
 // entries == nullptr: the sorted list IS the dense point array bp.p[0] (the output of the batched-affine levels, k_affine_level):
 // entry k is point k, never negated; a point may be the level encoding of infinity (skipped).
 template <int NJ>
@@ -539,8 +560,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
       if (k == bend) {
         if (!first) {
           if (!inf) {   // close the finished run
-            mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));
-            mem_st(acc, CY, ty);
+            ZK_CLOSE_RUN(acc, xs, zz, zzz, ty);
           }
           b++;
           while (offsets[b] + counts[b] <= k) b++;     // next non-empty bucket
@@ -580,8 +600,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   }
   if (board_mine && (threadIdx.x & 63u) == 0) __hip_atomic_store(board_mine, (prio_tag << 16) | 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!inf) {
-    mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));
-    mem_st(acc, CY, ty);
+    ZK_CLOSE_RUN(acc, xs, zz, zzz, ty);
   }
   // a run that cancelled to infinity leaves ZZ = 0 in its slot: madd_same_x wrote the zeros, or the slot
   // was never written (zero-filled array)

@@ -60,6 +60,12 @@ void cuts_by_weight(const std::vector<uint32_t>& w, size_t parts, size_t* cuts) 
 }
 }  // namespace
 
+// (zkhip_groth16_setup_slice cuts by the same rule from the key's exponents, before any point exists)
+extern "C" void zkhip_internal_cuts_by_weight(const uint32_t* w, size_t n, size_t parts, size_t* cuts) {
+  std::vector<uint32_t> v(w, w + n);
+  cuts_by_weight(v, parts, cuts);
+}
+
 extern "C" int zkhip_key_partition(const zkhip_crs_desc* key, int parts, size_t* a_cuts, size_t* h_cuts, size_t* l_cuts) {
   if (!key || !a_cuts || !h_cuts || !l_cuts || parts < 1 || parts > 64) return fail(ZKHIP_ERR_ARG, "zkhip_key_partition: bad argument");
   if (key->n_vars < key->n_primary + 1 || key->domain_size < 1 || !key->a_query || !key->b_g2_query || !key->b_g1_query || (key->domain_size > 1 && !key->h_query))

@@ -64,13 +64,18 @@ namespace {
 // (the prover keeps 2 (large) or 5 (small circuits) MSMs in flight).  The library owns one (the plain entry points,
 // serialised by g.mu); every zkhip_prover owns another, so several host threads can keep several proofs in flight.
 constexpr int ZK_MSM_SLOTS = 8;
+constexpr int ZK_CTX_Z = ZK_MSM_SLOTS + 1, ZK_CTX_H = ZK_MSM_SLOTS + 2, ZK_CTX_TOTAL = ZK_MSM_SLOTS + 3;
 struct ProveState {
   // MSM contexts: [0, ZK_MSM_SLOTS) the slots of zkhip_msm_submit / collect (the first five also serve a proof whose five MSMs run as
-  // separate launch sequences), [ZK_MSM_SLOTS] the context of a proof's five MSMs in ONE launch sequence
-  MsmCtx ctx[ZK_MSM_SLOTS + 1];
-  bool ready[ZK_MSM_SLOTS + 1] = {};
+  // separate launch sequences), [ZK_MSM_SLOTS] the context of a proof's five MSMs in ONE launch sequence, [ZK_CTX_Z] / [ZK_CTX_H] the
+  // two sequences of a proof ALONE (round 6): the four MSMs over the assignment, and the H MSM behind the QAP map
+  MsmCtx ctx[ZK_CTX_TOTAL];
+  bool ready[ZK_CTX_TOTAL] = {};
   hipStream_t st = nullptr;
   hipEvent_t ev_st = nullptr;      // blocking-sync event for waits on st (the waiting host thread sleeps)
+  hipEvent_t ev_up = nullptr, ev_qap = nullptr;   // split proofs: the assignment is on the device / the QAP map has finished (stream-to-stream)
+  bool split_last = false;         // the last proof ran as two launch sequences (A, B-G2, B-G1, L beside the QAP map; then H)
+  MsmCtx* last_acc_ctx2 = nullptr; // ... whose second accumulation launch ran on this plan
   uint64_t* dz = nullptr;
   size_t dz_cap = 0;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -83,9 +88,12 @@ struct ProveState {
   hipStream_t pre[2] = {nullptr, nullptr};   // streams made ahead of the first proof (zkhip_prover_create_streams): the launch sequence's plan adopts them
   void release() {
     for (int k = 0; k < 2; k++) if (pre[k]) { (void)hipStreamDestroy(pre[k]); pre[k] = nullptr; }
-    for (int k = 0; k <= ZK_MSM_SLOTS; k++) if (ready[k]) { msm_plan_free(&ctx[k]); ready[k] = false; }
+    for (int k = 0; k < ZK_CTX_TOTAL; k++) if (ready[k]) { msm_plan_free(&ctx[k]); ready[k] = false; }
     if (st) { (void)hipStreamDestroy(st); st = nullptr; }
     if (ev_st) { (void)hipEventDestroy(ev_st); ev_st = nullptr; }
+    if (ev_up) { (void)hipEventDestroy(ev_up); ev_up = nullptr; }
+    if (ev_qap) { (void)hipEventDestroy(ev_qap); ev_qap = nullptr; }
+    last_acc_ctx = last_acc_ctx2 = nullptr;
     if (dz) { (void)hipFree(dz); dz = nullptr; dz_cap = 0; }
   }
 };
@@ -757,6 +765,13 @@ static int follow_key_domain(const zkhip_crs* crs, R1csDev* rd) {
   return r1cs_set_domain(rd, crs->domain_size, t_err, sizeof t_err);
 }
 
+// 0 (default): a proof's five MSMs are one launch sequence; 1 / 2: the split form (see prove_partial).  ZKHIP_PROVE_SPLIT / zkhip_set_prove_split.
+static std::atomic<int> g_prove_split{[] { const char* e = getenv("ZKHIP_PROVE_SPLIT"); const int v = e ? atoi(e) : 0; return v < 0 || v > 2 ? 0 : v; }()};
+extern "C" int zkhip_set_prove_split(int mode) {
+  if (mode < 0 || mode > 2) return fail(ZKHIP_ERR_ARG, "prove split: 0 (one launch sequence), 1 (two, gated) or 2 (two, not gated)");
+  g_prove_split.store(mode);
+  return ZKHIP_OK;
+}
 static int prove_check(const zkhip_crs* crs, const R1csDev* rd, size_t a_lo, size_t h_lo, size_t l_lo) {
   const size_t m = rd->n_vars, l = rd->n_primary, d = rd->d;
   const size_t a_len = crs->A->len, h_len = crs->H->len, l_len = crs->L->len;
@@ -782,7 +797,13 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
   { int rc_ = prove_check(crs, rd, a_lo, h_lo, l_lo); if (rc_ != ZKHIP_OK) return rc_; }
   const int tc = crs->A->table_c;
   auto t0 = clk::now();
-  if (!ps.st) API_HIP(hipStreamCreateWithFlags(&ps.st, hipStreamNonBlocking));
+  if (!ps.st) {
+    // (ZKHIP_QAP_STREAM_PRIO=1: the QAP map's stream at the highest priority - an experiment of the split proof, see below)
+    static const int qprio = getenv("ZKHIP_QAP_STREAM_PRIO") ? atoi(getenv("ZKHIP_QAP_STREAM_PRIO")) : 0;
+    int lo = 0, hi = 0;
+    if (qprio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) API_HIP(hipStreamCreateWithPriority(&ps.st, hipStreamNonBlocking, hi));
+    else API_HIP(hipStreamCreateWithFlags(&ps.st, hipStreamNonBlocking));
+  }
   if (!ps.ev_st) API_HIP(hipEventCreateWithFlags(&ps.ev_st, hipEventBlockingSync | hipEventDisableTiming));
   if (ps.dz_cap < m) {
     if (ps.dz) { (void)hipFree(ps.dz); ps.dz = nullptr; ps.dz_cap = 0; }
@@ -812,6 +833,72 @@ static int prove_partial(ProveState& ps, const zkhip_crs* crs, R1csDev* rd, cons
                      ctx_reusable(&ps.ctx[ZK_MSM_SLOTS], ps.ready[ZK_MSM_SLOTS], maxlen, tc, 5, crs->A->table_naf, total_finite ? total_finite : 1);
   hipStream_t qst = chain ? ps.ctx[ZK_MSM_SLOTS].stream : ps.st;
   ps.chained_last = chain;
+  ps.split_last = false;
+  ps.last_acc_ctx2 = nullptr;
+  // OPTION, off by default (ZKHIP_PROVE_SPLIT=1; =2: without the gate between the two accumulations) - a proof that is alone on the
+  // chip as TWO launch sequences (round 6): four of the five MSMs - A, B-G2, B-G1, L - need only the assignment, so
+  // their sort and accumulation start as soon as z is on the device, on their own plan, while the QAP map runs beside them on the
+  // prover's stream; the H MSM follows on a second plan behind an event on h, and the bucket reduction of the first sequence runs
+  // under its accumulation.  Same group elements, bit-identical proofs (the partitioned and serial tests pass with it on).
+  // MEASURED AND NOT ADOPTED (profiles/r06_split_proof_ab.txt, one box, tools/partition_model.py): one 2^20 proof alone 50.0 ms as one
+  // sequence, 52.0 split (49.8-50.5 without the gate); one rank of an eight-way 2^22 key 38.6 -> 39.8 ms; an eighth of a 2^20 key
+  // 12.4 -> 13.5-14.8 ms.  The map is not idle time to hide: at 2^22 its seven FFTs and three SpMVs fill the chip (9.4 ms of
+  // multiplier and HBM work) and share the accumulation's issue slots when run beside it - the two accumulation launches together
+  // take 44 ms where the single one takes 37 - and every launch sequence brings its own one-fill tail, stitching and reduction chain.
+  const int split_env = g_prove_split.load();
+  if (split_env && !chain && !ps.quad_below && tc > 0 && crs->batch_msms && h_len > 0 && a_len > 0) {
+    const zkhip_bases* qz[4] = {crs->A, crs->B2, crs->B1, crs->L};
+    const size_t lz[4] = {a_len, a_len, a_len, l_len};
+    size_t tot_z = 0, max_z = a_len > l_len ? a_len : l_len;
+    for (int j = 0; j < 4; j++) { const size_t nf = lz[j] == qz[j]->len ? qz[j]->n_finite : 0; tot_z += (nf && nf < lz[j]) ? nf : lz[j]; }
+    const size_t nf_h = h_len == crs->H->len ? crs->H->n_finite : 0, tot_h = (nf_h && nf_h < h_len) ? nf_h : h_len;
+    MsmCtx *cz = &ps.ctx[ZK_CTX_Z], *ch = &ps.ctx[ZK_CTX_H];
+    int rc = ensure_ctx(cz, &ps.ready[ZK_CTX_Z], max_z ? max_z : 1, tc, 4, crs->A->table_naf, tot_z ? tot_z : 1, 0, ps.pre);
+    if (rc == ZKHIP_OK) rc = ensure_ctx(ch, &ps.ready[ZK_CTX_H], h_len, tc, 1, crs->A->table_naf, tot_h ? tot_h : 1);
+    if (rc == ZKHIP_OK) {
+      if (!ps.ev_up) API_HIP(hipEventCreateWithFlags(&ps.ev_up, hipEventDisableTiming));
+      if (!ps.ev_qap) API_HIP(hipEventCreateWithFlags(&ps.ev_qap, hipEventDisableTiming));
+      if (!d_z_ready) API_HIP(hipMemcpyAsync(ps.dz, z, m * 48, hipMemcpyHostToDevice, ps.st));
+      API_HIP(hipEventRecord(ps.ev_up, ps.st));
+      API_HIP(hipStreamWaitEvent(cz->stream, ps.ev_up, 0));
+      ps.ms[0] = ms_since(t0);
+      t0 = clk::now();
+      MsmJob mz[4];
+      const uint64_t* scz[4] = {dz + a_lo * 6, dz + a_lo * 6, dz + a_lo * 6, dz + (l + 1 + l_lo) * 6};
+      for (int j = 0; j < 4; j++)
+        mz[j] = MsmJob{qz[j]->d_pts, qz[j]->d_inf, scz[j], lz[j], 1, qz[j]->len, lz[j] == qz[j]->len ? qz[j]->n_finite : 0};
+      const MsmJob mh{crs->H->d_pts, crs->H->d_inf, (const uint64_t*)rd->bufA + h_lo * 6, h_len, 2, crs->H->len, nf_h};
+      auto tl0 = clk::now();
+      rc = msm_launch_multi(cz, 4, mz);
+      if (rc != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", cz->errbuf); return rc; }
+      rc = qap_h_dev(rd, dz, ps.st, t_err, sizeof t_err, d_z_app);
+      if (rc == ZKHIP_OK) {
+        hipError_t e = hipEventRecord(ps.ev_qap, ps.st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ch->stream, ps.ev_qap, 0);
+        if (e != hipSuccess) { snprintf(t_err, sizeof t_err, "split proof: %s", hipGetErrorString(e)); rc = ZKHIP_ERR_HIP; }
+      }
+      if (rc == ZKHIP_OK) {
+        ch->acc_gate = split_env == 2 ? nullptr : cz->ev_acc1;       // H's accumulation starts when the first one has ended (2: no gate)
+        rc = msm_launch_multi(ch, 1, &mh);
+        ch->acc_gate = nullptr;
+        if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", ch->errbuf);
+      }
+      ps.ms[1] = ms_since(t0);                      // (enqueueing the QAP map and both sequences: the phases overlap on the device)
+      uint64_t sz[4 * 36];
+      const int rc_z = msm_finish_multi(cz, 4, sz);           // (always collected: a pending plan would refuse the next proof)
+      if (rc_z != ZKHIP_OK && rc == ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", cz->errbuf); rc = rc_z; }
+      if (rc != ZKHIP_OK) { (void)hipStreamSynchronize(ps.st); return rc; }
+      if ((rc = msm_finish_multi(ch, 1, sums + 108)) != ZKHIP_OK) { snprintf(t_err, sizeof t_err, "%s", ch->errbuf); return rc; }
+      memcpy(sums, sz, 3 * 36 * 8);
+      memcpy(sums + 144, sz + 108, 36 * 8);
+      for (int j = 0; j < 5; j++) ps.ms[2 + j] = ms_since(tl0);
+      ps.last_accumulate_ms = cz->last_accumulate_ms + ch->last_accumulate_ms;
+      ps.last_acc_ctx = cz; ps.last_acc_ctx2 = ch;
+      ps.split_last = true;
+      return ZKHIP_OK;
+    }
+    if (rc != ZKHIP_ERR_ARG) return rc;             // (a plan that does not fit 32-bit entry positions: the single-sequence path below decides)
+  }
   if (!d_z_ready) {
     API_HIP(hipMemcpyAsync(ps.dz, z, m * 48, hipMemcpyHostToDevice, qst));
     if (!chain) {
@@ -1212,6 +1299,15 @@ int zkhip_aggregator_app_new(zkhip_aggregator* a, const zkhip_crs* crs, const ui
     memcpy(&z_app[i * 6], c, 48);
     T.out_ref[i] = zero_ref;                         // the application's generator writes the MASKED assignment
   }
+  // The masked HOST generator (witness_proofs_only) leaves the whole hash and key sections [sec_hash, sec_proofs) at zero and relies on
+  // every one of those positions being a constant of the handle: checked here rather than assumed - a recorder that stopped
+  // folding one of them would otherwise give an assignment with a hole, a wrong H and an unverifiable proof with rc OK.
+  {
+    size_t covered = 0;
+    for (uint32_t i : app->s_idx) covered += (i >= a->sec_hash && i < a->sec_proofs) ? 1 : 0;
+    if (covered != a->sec_proofs - a->sec_hash)
+      return fail(ZKHIP_ERR_STATE, "zkhip_aggregator_app_new: the key's hash and line sections did not fold into constants completely");
+  }
   // Self-check: the constants came out of the RECORDING build of the circuit (the route the device takes); the host generator is the
   // reference for parity.  One full host assignment under this key (the key's own points stand in for the proofs: the constant
   // positions do not depend on them) must hold exactly these values there - a degenerate key, where the two routes part, gets no handle.
@@ -1343,7 +1439,7 @@ int zkhip_prover_set_streaming(zkhip_prover* p, int on) {
   // measured on the wrapping circuit: 212 -> 228 proofs/s with six provers in flight, 107 -> 98 one at a time
   p->ps.quad_below = on ? 1024u : 0u;
   p->rd->spmv_log_lanes = on ? (p->rd->spmv_log_lanes_alone < 2 ? p->rd->spmv_log_lanes_alone : 2) : p->rd->spmv_log_lanes_alone;
-  for (int k = 0; k <= ZK_MSM_SLOTS; k++) if (p->ps.ready[k]) { p->ps.ctx[k].quad_below = on ? 1024u : 65536u; p->ps.ctx[k].one_stream = on ? 1 : 0; }
+  for (int k = 0; k < ZK_CTX_TOTAL; k++) if (p->ps.ready[k]) { p->ps.ctx[k].quad_below = on ? 1024u : 65536u; p->ps.ctx[k].one_stream = on ? 1 : 0; }
   return ZKHIP_OK;
 }
 
@@ -1352,6 +1448,12 @@ static int last_entries_of(ProveState& ps, uint64_t* out) {
   if (!ps.last_acc_ctx) return ZKHIP_OK;
   int rc = msm_last_entries(ps.last_acc_ctx, out);
   if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", ps.last_acc_ctx->errbuf);
+  if (rc == ZKHIP_OK && ps.last_acc_ctx2) {          // a split proof: two accumulation launches
+    uint64_t more = 0;
+    rc = msm_last_entries(ps.last_acc_ctx2, &more);
+    if (rc != ZKHIP_OK) snprintf(t_err, sizeof t_err, "%s", ps.last_acc_ctx2->errbuf);
+    *out += more;
+  }
   return rc;
 }
 int zkhip_prover_last_accumulate_entries(zkhip_prover* p, uint64_t* out) {
@@ -1378,7 +1480,15 @@ int zkhip_prover_timings(zkhip_prover* p, double out_ms[8]) {
 int zkhip_prover_timings_chained(zkhip_prover* p) {
   if (!p) return 0;
   std::lock_guard<std::mutex> lk(p->mu);
-  return p->ps.chained_last ? 1 : 0;
+  return p->ps.chained_last ? 1 : (p->ps.split_last ? 2 : 0);
+}
+// 1: the last proof of the plain entry points on this thread's device ran as two launch sequences (see prove_partial): slot [1] of
+// zkhip_last_prove_timings is then the time to ENQUEUE the QAP map and both sequences, the MSM slots hold the device time of all of it
+int zkhip_last_prove_split(void) {
+  const int dev = t_prove_dev >= 0 ? t_prove_dev : cur_dev();
+  if (dev < 0) return 0;
+  std::lock_guard<std::mutex> lk(g.dev[dev].mu);
+  return g.dev[dev].ps.split_last ? 1 : 0;
 }
 
 int zkhip_groth16_verify(const uint64_t vk_alpha_g1[24], const uint64_t vk_beta_g2[24], const uint64_t vk_delta_g2[24],
@@ -1431,11 +1541,18 @@ int zkhip_groth16_setup(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], cons
   return zkhip_groth16_setup_ex(cs, tau_m, alpha_m, beta_m, delta_m, 0, out);     // the reference's forced power-of-two domain
 }
 
-int zkhip_groth16_setup_ex(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], const uint64_t alpha_m[6], const uint64_t beta_m[6],
-                           const uint64_t delta_m[6], size_t domain_size, zkhip_keypair** out) {
+extern "C" void zkhip_internal_cuts_by_weight(const uint32_t* w, size_t n, size_t parts, size_t* cuts);      // multi_device.cpp: zkhip_key_partition's rule
+// The exponents of a key (host): QAP polynomials at tau through the Lagrange basis of the key's domain (one batch inversion), then
+// the five query vectors' scalars.  Shared by the whole-key setup and the slice setup below.
+extern "C++" {
+namespace {
+struct SetupScalars {
+  size_t n = 0, m = 0, l = 0, d = 0;
+  std::vector<host::HFr> At, Bt, hs, ls, abc, single;      // single: alpha, beta, delta
+};
+int setup_scalars(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], const uint64_t alpha_m[6], const uint64_t beta_m[6],
+                  const uint64_t delta_m[6], size_t domain_size, SetupScalars& o) {
   using namespace host;
-  BIND_CUR();
-  if (!cs || !tau_m || !alpha_m || !beta_m || !delta_m || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
   const size_t n = cs->n_constraints, m = cs->n_vars, l = cs->n_primary;
   if (m < l + 1) return fail(ZKHIP_ERR_ARG, "bad sizes");
   // the evaluation domain (domain.hpp): 0 = the power of two libzeth's groth16_snark forces (the reference's keys), ZKHIP_DOMAIN_STEP =
@@ -1450,40 +1567,60 @@ int zkhip_groth16_setup_ex(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], c
   const HFr Zt = dom.vanishing(tau);
   std::vector<HFr> Lg;
   if (!dom.lagrange_at(tau, Lg)) return fail(ZKHIP_ERR_ARG, "tau lies in the evaluation domain");
-  std::vector<HFr> At(m, HFr::zero()), Bt(m, HFr::zero()), Ct(m, HFr::zero());
+  o.n = n; o.m = m; o.l = l; o.d = d;
+  o.At.assign(m, HFr::zero()); o.Bt.assign(m, HFr::zero());
+  std::vector<HFr> Ct(m, HFr::zero());
   auto accumulate = [&](const uint32_t* rp, const uint32_t* col, const uint64_t* val, std::vector<HFr>& out_) {
     for (size_t j = 0; j < n; j++)
       for (uint32_t k = rp[j]; k < rp[j + 1]; k++) out_[col[k]] = out_[col[k]] + HFr::from_limbs(val + (size_t)k * 6) * Lg[j];
   };
-  accumulate(cs->a_row_ptr, cs->a_col, cs->a_val, At);
-  accumulate(cs->b_row_ptr, cs->b_col, cs->b_val, Bt);
+  accumulate(cs->a_row_ptr, cs->a_col, cs->a_val, o.At);
+  accumulate(cs->b_row_ptr, cs->b_col, cs->b_val, o.Bt);
   accumulate(cs->c_row_ptr, cs->c_col, cs->c_val, Ct);
-  for (size_t k = 0; k <= l; k++) At[k] = At[k] + Lg[n + k];          // input-consistency rows
-  HFr delta_inv = delta.inv();
-  // scalar vectors -> limbs
-  auto pack = [](const std::vector<HFr>& v) { std::vector<uint64_t> o(v.size() * 6); for (size_t i = 0; i < v.size(); i++) v[i].to_limbs(&o[i * 6]); return o; };
-  std::vector<HFr> hs(d - 1), ls(m - l - 1), abc(l + 1), single(3);
+  for (size_t k = 0; k <= l; k++) o.At[k] = o.At[k] + Lg[n + k];          // input-consistency rows
+  const HFr delta_inv = delta.inv();
+  o.hs.resize(d - 1); o.ls.resize(m - l - 1); o.abc.resize(l + 1); o.single.resize(3);
   HFr t = Zt * delta_inv;
-  for (size_t j = 0; j + 1 < d; j++) { hs[j] = t; t = t * tau; }
-  for (size_t i = l + 1; i < m; i++) ls[i - l - 1] = (beta * At[i] + alpha * Bt[i] + Ct[i]) * delta_inv;
-  for (size_t i = 0; i <= l; i++) abc[i] = beta * At[i] + alpha * Bt[i] + Ct[i];
-  single[0] = alpha; single[1] = beta; single[2] = delta;
-  uint64_t g1[24], g2[24];
+  for (size_t j = 0; j + 1 < d; j++) { o.hs[j] = t; t = t * tau; }
+  for (size_t i = l + 1; i < m; i++) o.ls[i - l - 1] = (beta * o.At[i] + alpha * o.Bt[i] + Ct[i]) * delta_inv;
+  for (size_t i = 0; i <= l; i++) o.abc[i] = beta * o.At[i] + alpha * o.Bt[i] + Ct[i];
+  o.single[0] = alpha; o.single[1] = beta; o.single[2] = delta;
+  return ZKHIP_OK;
+}
+std::vector<uint64_t> pack_scalars(const host::HFr* v, size_t count) {
+  std::vector<uint64_t> o(count * 6);
+  for (size_t i = 0; i < count; i++) v[i].to_limbs(&o[i * 6]);
+  return o;
+}
+void generators(uint64_t g1[24], uint64_t g2[24]) {
   memcpy(g1, FqParams::G1_GEN_X64, 96); memcpy(g1 + 12, FqParams::G1_GEN_Y64, 96);
   memcpy(g2, FqParams::G2_GEN_X64, 96); memcpy(g2 + 12, FqParams::G2_GEN_Y64, 96);
+}
+}  // namespace
+}  // extern "C++"
+
+int zkhip_groth16_setup_ex(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], const uint64_t alpha_m[6], const uint64_t beta_m[6],
+                           const uint64_t delta_m[6], size_t domain_size, zkhip_keypair** out) {
+  using namespace host;
+  BIND_CUR();
+  if (!cs || !tau_m || !alpha_m || !beta_m || !delta_m || !out) return fail(ZKHIP_ERR_ARG, "null pointer");
+  SetupScalars sc;
+  int rc = setup_scalars(cs, tau_m, alpha_m, beta_m, delta_m, domain_size, sc);
+  if (rc != ZKHIP_OK) return rc;
+  uint64_t g1[24], g2[24];
+  generators(g1, g2);
   zkhip_keypair* kp = new zkhip_keypair();
-  kp->n_vars = m; kp->n_primary = l; kp->domain_size = d;
-  auto fb = [&](const uint64_t* base, const std::vector<HFr>& sc, std::vector<uint64_t>& dst) -> int {
-    dst.assign(sc.size() * 24, 0);
-    if (sc.empty()) return ZKHIP_OK;
-    std::vector<uint64_t> s = pack(sc);
-    return zkhip_fixed_base_mul(base, s.data(), sc.size(), 1, dst.data());
+  kp->n_vars = sc.m; kp->n_primary = sc.l; kp->domain_size = sc.d;
+  auto fb = [&](const uint64_t* base, const std::vector<HFr>& v, std::vector<uint64_t>& dst) -> int {
+    dst.assign(v.size() * 24, 0);
+    if (v.empty()) return ZKHIP_OK;
+    std::vector<uint64_t> s = pack_scalars(v.data(), v.size());
+    return zkhip_fixed_base_mul(base, s.data(), v.size(), 1, dst.data());
   };
-  int rc;
   std::vector<uint64_t> s1, s2;
-  if ((rc = fb(g1, single, s1)) != ZKHIP_OK || (rc = fb(g2, single, s2)) != ZKHIP_OK || (rc = fb(g1, At, kp->A)) != ZKHIP_OK ||
-      (rc = fb(g2, Bt, kp->B2)) != ZKHIP_OK || (rc = fb(g1, Bt, kp->B1)) != ZKHIP_OK || (rc = fb(g1, hs, kp->H)) != ZKHIP_OK ||
-      (rc = fb(g1, ls, kp->L)) != ZKHIP_OK || (rc = fb(g1, abc, kp->ABC)) != ZKHIP_OK) {
+  if ((rc = fb(g1, sc.single, s1)) != ZKHIP_OK || (rc = fb(g2, sc.single, s2)) != ZKHIP_OK || (rc = fb(g1, sc.At, kp->A)) != ZKHIP_OK ||
+      (rc = fb(g2, sc.Bt, kp->B2)) != ZKHIP_OK || (rc = fb(g1, sc.Bt, kp->B1)) != ZKHIP_OK || (rc = fb(g1, sc.hs, kp->H)) != ZKHIP_OK ||
+      (rc = fb(g1, sc.ls, kp->L)) != ZKHIP_OK || (rc = fb(g1, sc.abc, kp->ABC)) != ZKHIP_OK) {
     delete kp;
     return rc;
   }
@@ -1491,6 +1628,85 @@ int zkhip_groth16_setup_ex(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], c
   kp->delta_g1.assign(s1.begin() + 48, s1.begin() + 72);
   kp->beta_g2.assign(s2.begin() + 24, s2.begin() + 48); kp->delta_g2.assign(s2.begin() + 48, s2.begin() + 72);
   *out = kp;
+  return ZKHIP_OK;
+}
+
+// One rank's share of a trusted setup (BASELINE configs[3]: the key pre-partitioned over the GPUs of a node).  Every rank evaluates
+// the exponents (host: seconds at 2^22), cuts the three index ranges by FINITE terms exactly as zkhip_key_partition would cut the
+// finished key - an exponent of zero IS a base at infinity - and then multiplies ONLY its own slice: an N-th of the fixed-base work,
+// the points go from k_fixed_base_mul's output straight into the slice's base sets and window tables without leaving the device
+// (round 6, VERDICT r5 item 4: until then every rank generated the whole key, copied its 4 GB to the host twice and uploaded an
+// N-th).  *vk_out: a keypair WITHOUT queries (verification half and the five constants a prover's tail needs).
+int zkhip_groth16_setup_slice(const zkhip_r1cs_desc* cs, const uint64_t tau_m[6], const uint64_t alpha_m[6], const uint64_t beta_m[6],
+                              const uint64_t delta_m[6], size_t domain_size, int parts, int part, const zkhip_key_opts* opts,
+                              zkhip_crs** slice_out, size_t ranges[6], zkhip_keypair** vk_out) {
+  using namespace host;
+  BIND_CUR();
+  if (!cs || !tau_m || !alpha_m || !beta_m || !delta_m || !slice_out || !ranges) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (parts < 1 || parts > 64 || part < 0 || part >= parts) return fail(ZKHIP_ERR_ARG, "setup_slice: part must be in [0, parts), parts in [1, 64]");
+  if (opts && (opts->window < 0 || (opts->window > 0 && (opts->window < 4 || opts->window > 22))))
+    return fail(ZKHIP_ERR_ARG, "zkhip_key_opts.window must be 0 (automatic) or in [4, 22]");
+  SetupScalars sc;
+  int rc = setup_scalars(cs, tau_m, alpha_m, beta_m, delta_m, domain_size, sc);
+  if (rc != ZKHIP_OK) return rc;
+  // the cuts of zkhip_key_partition, from the exponents: weight of index i = its finite bases among A, B-G2, B-G1
+  std::vector<size_t> ca(parts + 1), chh(parts + 1), cl(parts + 1);
+  {
+    std::vector<uint32_t> w(sc.m);
+    for (size_t i = 0; i < sc.m; i++) w[i] = (sc.At[i].is_zero() ? 0u : 1u) + (sc.Bt[i].is_zero() ? 0u : 2u);
+    zkhip_internal_cuts_by_weight(w.data(), w.size(), (size_t)parts, ca.data());
+    w.assign(sc.hs.size(), 0);
+    for (size_t i = 0; i < sc.hs.size(); i++) w[i] = sc.hs[i].is_zero() ? 0u : 1u;
+    zkhip_internal_cuts_by_weight(w.data(), w.size(), (size_t)parts, chh.data());
+    w.assign(sc.ls.size(), 0);
+    for (size_t i = 0; i < sc.ls.size(); i++) w[i] = sc.ls[i].is_zero() ? 0u : 1u;
+    zkhip_internal_cuts_by_weight(w.data(), w.size(), (size_t)parts, cl.data());
+  }
+  const size_t a_lo = ca[part], a_len = ca[part + 1] - ca[part], h_lo = chh[part], h_len = chh[part + 1] - chh[part],
+               l_lo = cl[part], l_len = cl[part + 1] - cl[part];
+  ranges[0] = a_lo; ranges[1] = a_lo + a_len; ranges[2] = h_lo; ranges[3] = h_lo + h_len; ranges[4] = l_lo; ranges[5] = l_lo + l_len;
+  uint64_t g1[24], g2[24];
+  generators(g1, g2);
+  // the constants and the verification half (l + 1 + 6 products): through the host, they are needed there
+  std::unique_ptr<zkhip_keypair> kp(new zkhip_keypair());
+  kp->n_vars = sc.m; kp->n_primary = sc.l; kp->domain_size = sc.d;
+  {
+    std::vector<uint64_t> s1(72), s2(72), ps = pack_scalars(sc.single.data(), 3), pa = pack_scalars(sc.abc.data(), sc.abc.size());
+    kp->ABC.assign(sc.abc.size() * 24, 0);
+    if ((rc = zkhip_fixed_base_mul(g1, ps.data(), 3, 1, s1.data())) != ZKHIP_OK || (rc = zkhip_fixed_base_mul(g2, ps.data(), 3, 1, s2.data())) != ZKHIP_OK ||
+        (rc = zkhip_fixed_base_mul(g1, pa.data(), sc.abc.size(), 1, kp->ABC.data())) != ZKHIP_OK)
+      return rc;
+    kp->alpha_g1.assign(s1.begin(), s1.begin() + 24); kp->beta_g1.assign(s1.begin() + 24, s1.begin() + 48);
+    kp->delta_g1.assign(s1.begin() + 48, s1.begin() + 72);
+    kp->beta_g2.assign(s2.begin() + 24, s2.begin() + 48); kp->delta_g2.assign(s2.begin() + 48, s2.begin() + 72);
+  }
+  // the slice's five query vectors: exponents up, products on the device, straight into base sets
+  zkhip_crs* c = new zkhip_crs();
+  c->device = cur_dev();
+  c->n_vars = sc.m; c->n_primary = sc.l; c->domain_size = sc.d;
+  memcpy(c->alpha_g1, kp->alpha_g1.data(), 192); memcpy(c->beta_g1, kp->beta_g1.data(), 192); memcpy(c->beta_g2, kp->beta_g2.data(), 192);
+  memcpy(c->delta_g1, kp->delta_g1.data(), 192); memcpy(c->delta_g2, kp->delta_g2.data(), 192);
+  auto query = [&](const uint64_t* base, const HFr* v, size_t count, zkhip_bases** dst) -> int {
+    if (!count) return zkhip_bases_upload_dev(nullptr, 0, dst);
+    Scratch scr;
+    void *ds = nullptr, *dp = nullptr;
+    API_HIP(scr.alloc(&ds, count * 48));
+    API_HIP(scr.alloc(&dp, count * 192));
+    {
+      const std::vector<uint64_t> s = pack_scalars(v, count);
+      API_HIP(hipMemcpy(ds, s.data(), count * 48, hipMemcpyHostToDevice));
+    }
+    int r = zkhip_fixed_base_mul_dev(base, ds, count, 1, dp);
+    if (r == ZKHIP_OK) r = zkhip_bases_upload_dev(dp, count, dst);
+    return r;
+  };
+  if ((rc = query(g1, sc.At.data() + a_lo, a_len, &c->A)) == ZKHIP_OK && (rc = query(g2, sc.Bt.data() + a_lo, a_len, &c->B2)) == ZKHIP_OK &&
+      (rc = query(g1, sc.Bt.data() + a_lo, a_len, &c->B1)) == ZKHIP_OK && (rc = query(g1, sc.hs.data() + h_lo, h_len, &c->H)) == ZKHIP_OK &&
+      (rc = query(g1, sc.ls.data() + l_lo, l_len, &c->L)) == ZKHIP_OK)
+    rc = crs_build_tables(c, resolve_opts(opts));
+  if (rc != ZKHIP_OK) { zkhip_crs_free(c); return rc; }
+  *slice_out = c;
+  if (vk_out) *vk_out = kp.release();
   return ZKHIP_OK;
 }
 

@@ -28,10 +28,10 @@ EXPORTS = [
     "zkhip_gpu_witness_stats", "zkhip_prover_prove_dev", "zkhip_aggregator_check_inputs", "zkhip_aggregator_vk_hash", "zkhip_aggregator_num_proofs", "zkhip_aggregator_inputs_per_proof",
     "zkhip_prover_new", "zkhip_prover_create_streams", "zkhip_prover_prove", "zkhip_prover_timings", "zkhip_prover_free", "zkhip_prover_last_accumulate_ms",
     "zkhip_aggregator_pipeline_new", "zkhip_aggregator_pipeline_new_ex", "zkhip_crs_device", "zkhip_aggregator_pipeline_submit", "zkhip_aggregator_pipeline_wait", "zkhip_aggregator_pipeline_free",
-    "zkhip_groth16_setup", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
+    "zkhip_groth16_setup", "zkhip_groth16_setup_slice", "zkhip_keypair_crs_desc", "zkhip_keypair_vk", "zkhip_keypair_free", "zkhip_keypair_write", "zkhip_keypair_read",
     "zkhip_jac_to_affine", "zkhip_jac_add", "zkhip_to_canonical",
     "zkhip_last_accumulate_interval", "zkhip_crs_upload_ex", "zkhip_crs_upload_slice_ex", "zkhip_bases_precompute_ex", "zkhip_crs_table_kind", "zkhip_crs_finite_terms",
-    "zkhip_bases_set_window", "zkhip_reset_time_base", "zkhip_measure_fq_mul_rate", "zkhip_internal_field_selftest", "zkhip_internal_tail_selftest", "zkhip_host_alloc", "zkhip_host_free",
+    "zkhip_bases_set_window", "zkhip_reset_time_base", "zkhip_measure_fq_mul_rate", "zkhip_internal_field_selftest", "zkhip_internal_tail_selftest", "zkhip_last_prove_split", "zkhip_set_prove_split", "zkhip_host_alloc", "zkhip_host_free",
     "zkhip_msm_stream_new", "zkhip_msm_stream_submit", "zkhip_msm_stream_submit_host", "zkhip_msm_stream_collect", "zkhip_msm_stream_last_accumulate_ms",
     "zkhip_msm_stream_last_accumulate_interval", "zkhip_msm_stream_free", "zkhip_prover_new_slice", "zkhip_prover_prove_partial",
     "zkhip_dispatcher_new", "zkhip_dispatcher_size", "zkhip_dispatcher_submit", "zkhip_dispatcher_wait", "zkhip_dispatcher_stats", "zkhip_dispatcher_free",
@@ -1025,6 +1025,25 @@ class Keypair:
         _check(lib.zkhip_groth16_setup_ex(ctypes.byref(r1cs_desc), c(tau), c(alpha), c(beta), c(delta), _domain_arg(domain), ctypes.byref(h)))
         self.handle = h
 
+    @classmethod
+    def setup_slice(cls, r1cs_desc, tau, alpha, beta, delta, parts, part, opts=None, domain=None):
+        """zkhip_groth16_setup_slice: this rank's share of a trusted setup -> (keypair WITHOUT queries: vk() and consts() work, Crs slice
+        with .ranges).  Only the slice is multiplied out, on the device; nothing of the proving half visits the host."""
+        lib = load()
+        c = lambda a: _p(np.ascontiguousarray(a, dtype=np.uint64))
+        lib.zkhip_groth16_setup_slice.argtypes = [ctypes.POINTER(R1csDesc), c_u64p_t, c_u64p_t, c_u64p_t, c_u64p_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p)]
+        hc, hk = ctypes.c_void_p(), ctypes.c_void_p()
+        rng = (ctypes.c_size_t * 6)()
+        _check(lib.zkhip_groth16_setup_slice(ctypes.byref(r1cs_desc), c(tau), c(alpha), c(beta), c(delta), _domain_arg(domain), int(parts), int(part),
+                                             ctypes.byref(opts) if opts is not None else None, ctypes.byref(hc), rng, ctypes.byref(hk)))
+        kp = cls.__new__(cls)
+        kp.handle = hk
+        crs = Crs.__new__(Crs)
+        crs.handle = hc
+        crs.ranges = ((int(rng[0]), int(rng[1])), (int(rng[2]), int(rng[3])), (int(rng[4]), int(rng[5])))
+        return kp, crs
+
     @property
     def domain_size(self):
         d = CrsDesc()
@@ -1124,6 +1143,16 @@ def last_prove_timings():
     t = (ctypes.c_double * 8)()
     _check(load().zkhip_last_prove_timings(t))
     return dict(zip(["upload_z", "qap", "msm_A", "msm_B2", "msm_B1", "msm_H", "msm_L", "host_tail"], list(t)))
+
+
+def set_prove_split(mode):
+    """0: a proof's five MSMs in one launch sequence (default); 1 / 2: the four MSMs over z beside the QAP map, H behind it (gated / not)"""
+    _check(load().zkhip_set_prove_split(int(mode)))
+
+
+def last_prove_split():
+    """True: this thread's last plain proof ran as two launch sequences (the four MSMs over z beside the QAP map, H behind it)"""
+    return bool(load().zkhip_last_prove_split())
 
 
 def jac_to_affine(jac):
