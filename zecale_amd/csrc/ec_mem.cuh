@@ -22,18 +22,55 @@ namespace zkhip {
 typedef __amdgpu_buffer_rsrc_t zk_rsrc_t;
 struct XyzzRef {
   zk_rsrc_t rs;        // wave-uniform: base pointer, 108 * stride words
-  uint32_t stride_b;   // wave-uniform: row stride in bytes
-  uint32_t voff;       // per lane: 4 * index
+  uint32_t stride_b;   // wave-uniform: distance between two limbs of a coordinate, in bytes (limb-major: the row stride; slot array: 4)
+  uint32_t coord_b;    // wave-uniform: distance between two coordinates, in bytes (limb-major: 27 rows; slot array: 112)
+  uint32_t voff;       // per lane: byte offset of the item (limb-major: 4 * index; slot array: 448 * index)
 };
 // base / stride must be wave-uniform (kernel arguments); 108 * stride * 4 must stay below 4 GiB.
 __device__ __forceinline__ XyzzRef make_ref(uint32_t* base, uint32_t stride, uint32_t idx) {
   XyzzRef r;
   r.rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(108u * stride * 4u), 0x00020000);
   r.stride_b = stride * 4u;
+  r.coord_b = 27u * stride * 4u;
   r.voff = idx * 4u;
   return r;
 }
 enum { CX = 0, CY = 1, CZZ = 2, CZZZ = 3 };
+
+// THE SLOT ARRAY of a launch sequence - where k_accumulate leaves its runs: one slot per bucket, two per slice for the pieces of the
+// buckets a slice boundary cuts - is an array of STRUCTURES since round 6: slot s = X | Y | ZZ | ZZZ, each coordinate 27 limbs padded
+// to 28 words (112 bytes, 16-byte aligned), 448 bytes a slot.  A run is closed by ONE lane at a moment of its own (the lanes of a wave
+// close their runs at different iterations), so in the limb-major layout every one of its 105 stores was a 4-byte write into a line of
+// its own: 2.04 GB of WRITE_SIZE per 2^20-term launch for 0.33 GB of slots, partial lines the L2 also has to fetch.  In the
+// structure a lane's stores fall into four lines back to back and a slot is read and written with 16-byte accesses (seven per
+// coordinate: mem_ld / mem_st below) - WRITE_SIZE 0.59 GB, FETCH_SIZE 3.98 -> 3.68 GB, and, interleaved on one box
+// (profiles/r06_slots_layout_ab.txt): k_accumulate<1> alone 11.10 -> 10.66 ms, MSM stream 83.1 -> 86.9 Mscalar/s, 2^20 prover
+// 21.0 -> 22.2 proofs/s, wrapping stream 430.6 -> 450.0 proofs/s (4-byte accesses to 432-byte slots gave a quarter of that).
+// Every other XYZZ array (the reduction's levels: one lane per item, read and written by whole waves) stays limb-major.
+// -DZK_SLOTS_AOS=0 restores the limb-major slot array.
+#ifndef ZK_SLOTS_AOS
+#define ZK_SLOTS_AOS 1
+#endif
+#if ZK_SLOTS_AOS
+#define ZK_SLOT_WORDS 112u
+#define ZK_SLOT_PITCH 448u
+__device__ __forceinline__ XyzzRef make_slot_ref(uint32_t* base, uint32_t n_slots, uint32_t idx) {
+  XyzzRef r;
+  r.rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(ZK_SLOT_WORDS * n_slots * 4u), 0x00020000);
+  r.stride_b = 4u;
+  r.coord_b = 112u;
+  r.voff = idx * ZK_SLOT_PITCH;
+  return r;
+}
+#else
+#define ZK_SLOT_WORDS 108u
+#define ZK_SLOT_PITCH 4u
+__device__ __forceinline__ XyzzRef make_slot_ref(uint32_t* base, uint32_t n_slots, uint32_t idx) { return make_ref(base, n_slots, idx); }
+#endif
+// `in` of the first level of the bucket reduction is the slot array, of the later levels a limb-major array
+__device__ __forceinline__ XyzzRef make_in_ref(uint32_t* base, uint32_t stride, uint32_t idx, int is_slots) {
+  return is_slots ? make_slot_ref(base, stride, idx) : make_ref(base, stride, idx);
+}
 
 // a == 0 (mod p) for a in [0, 2p), for a value that is almost never zero (PP of an addition: zero only when the two points share
 // their x coordinate).  The full test reads all 27 limbs twice (~100 instructions in every addition); zero and p both show in the
@@ -44,17 +81,48 @@ __device__ __forceinline__ bool fp_is_zero_2p_rare(const Fq& a) {
   return maybe && fp_is_zero_2p(a);
 }
 
+// a coordinate of a SLOT (27 consecutive words, 16-byte aligned): six 16-byte accesses and one of 12
+typedef uint32_t zk_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t zk_u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ Fq slot_ld_wide(const zk_rsrc_t& rs, uint32_t vo, uint32_t so) {
+  Fq v;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const zk_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so + 16u * (uint32_t)j, 0);
+    v.l[4 * j] = w.x; v.l[4 * j + 1] = w.y; v.l[4 * j + 2] = w.z; v.l[4 * j + 3] = w.w;
+  }
+  const zk_u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, vo, so + 96u, 0);
+  v.l[24] = t.x; v.l[25] = t.y; v.l[26] = t.z;
+  return v;
+}
+__device__ __forceinline__ void slot_st_wide(const zk_rsrc_t& rs, uint32_t vo, uint32_t so, const Fq& v) {
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    zk_u32x4 w;
+    w.x = v.l[4 * j]; w.y = v.l[4 * j + 1]; w.z = v.l[4 * j + 2]; w.w = v.l[4 * j + 3];
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, vo, so + 16u * (uint32_t)j, 0);
+  }
+  zk_u32x3 t;
+  t.x = v.l[24]; t.y = v.l[25]; t.z = v.l[26];
+  __builtin_amdgcn_raw_buffer_store_b96(t, rs, vo, so + 96u, 0);
+}
 __device__ __forceinline__ Fq mem_ld(const XyzzRef& r, int c) {
+#if ZK_SLOTS_AOS
+  if (r.coord_b == 112u) return slot_ld_wide(r.rs, r.voff, (uint32_t)c * 112u);      // (wave-uniform: the reference of a SLOT - a limb-major array has coord_b = 108 x its stride, never 112)
+#endif
   Fq v;
 #pragma unroll
   for (int i = 0; i < 27; i++)
-    v.l[i] = __builtin_amdgcn_raw_buffer_load_b32(r.rs, r.voff, (uint32_t)(c * 27 + i) * r.stride_b, 0);
+    v.l[i] = __builtin_amdgcn_raw_buffer_load_b32(r.rs, r.voff, (uint32_t)c * r.coord_b + (uint32_t)i * r.stride_b, 0);
   return v;
 }
 __device__ __forceinline__ void mem_st(const XyzzRef& r, int c, const Fq& v) {
+#if ZK_SLOTS_AOS
+  if (r.coord_b == 112u) { slot_st_wide(r.rs, r.voff, (uint32_t)c * 112u, v); return; }
+#endif
 #pragma unroll
   for (int i = 0; i < 27; i++)
-    __builtin_amdgcn_raw_buffer_store_b32(v.l[i], r.rs, r.voff, (uint32_t)(c * 27 + i) * r.stride_b, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(v.l[i], r.rs, r.voff, (uint32_t)c * r.coord_b + (uint32_t)i * r.stride_b, 0);
 }
 __device__ __forceinline__ void mem_set_inf(const XyzzRef& r) {
   Fq z = fp_zero<FqParams>();
@@ -424,14 +492,20 @@ __device__ __forceinline__ Fq fq_sel(bool c, const Fq& a, const Fq& b) {
 // coordinate chosen per lane (the row base goes into the lane offset instead of the scalar offset)
 __device__ __forceinline__ Fq mem_ld_lane(const XyzzRef& r, uint32_t c) {
   Fq v;
-  uint32_t vo = r.voff + c * 27u * r.stride_b;
+  uint32_t vo = r.voff + c * r.coord_b;
+#if ZK_SLOTS_AOS
+  if (r.coord_b == 112u) return slot_ld_wide(r.rs, vo, 0u);
+#endif
 #pragma unroll
   for (int i = 0; i < 27; i++) v.l[i] = __builtin_amdgcn_raw_buffer_load_b32(r.rs, vo, (uint32_t)i * r.stride_b, 0);
   return v;
 }
 
 __device__ __forceinline__ void mem_st_lane(const XyzzRef& r, uint32_t c, const Fq& v) {
-  uint32_t vo = r.voff + c * 27u * r.stride_b;
+  uint32_t vo = r.voff + c * r.coord_b;
+#if ZK_SLOTS_AOS
+  if (r.coord_b == 112u) { slot_st_wide(r.rs, vo, 0u, v); return; }
+#endif
 #pragma unroll
   for (int i = 0; i < 27; i++) __builtin_amdgcn_raw_buffer_store_b32(v.l[i], r.rs, vo, (uint32_t)i * r.stride_b, 0);
 }

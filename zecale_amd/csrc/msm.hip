@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ out, co
 // Bucket accumulation, load-balanced: lane t owns a SLICE of the bucket-sorted entry list, whatever buckets it crosses.  A run of
 // entries that covers a whole bucket is accumulated straight into that bucket's slot; a run cut by a slice boundary goes to a
 // per-slice boundary slot (F = the slice starts inside the bucket, L = the slice ends inside it) and k_fixup stitches the pieces.
-// All slots live in ONE limb-major array (one buffer descriptor): [0, nb) buckets, [nb, nb+T) F slots, [nb+T, nb+2T) L slots.
+// All slots live in ONE array (one buffer descriptor; an array of structures, ec_mem.cuh): [0, nb) buckets, [nb, nb+T) F slots, [nb+T, nb+2T) L slots.
 // Slices have equal WEIGHT, not equal length (round 4): the first entry of a bucket only OPENS a run - loads, no field arithmetic -
 // so it weighs ZK_W_FIRST = 1 where an entry that is ADDED to a running sum weighs ZK_W_NEXT = 8.  Every lane then performs the same
 // number of additions (to within one) and the openings ride along inside the iteration of the addition that follows them; with
@@ -409,6 +409,16 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offse
   return lo;
 }
 
+// ZZ = 0 marks an empty slot (the point at infinity): the 27 ZZ words of every slot of the array of structures are cleared before a
+// launch - a quarter of the array's bytes, as the limb-major layout's memset of its 27 ZZ rows was.  One word per lane, 27
+// consecutive lanes per slot.
+__global__ void __launch_bounds__(256) k_slots_clear_zz(uint32_t* __restrict__ slots, uint32_t n_slots) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_slots * 27) return;
+  const size_t s_ = i / 27, w = i % 27;
+  slots[s_ * ZK_SLOT_WORDS + (size_t)CZZ * (ZK_SLOT_WORDS / 4) + w] = 0u;
+}
+
 // Several MSMs may share one launch (merged plans: bucket window k belongs to job k): the base set of a run is chosen
 // by its bucket, b >> bshift (plain plans: one base set, bshift = 31).
 // NJ = 1: a plan for single MSMs (the selection folds away); NJ = MSM_MAX_JOBS: the five MSMs of a proof in one launch.  Two
@@ -434,26 +444,12 @@ __device__ __forceinline__ uint32_t slice_weight(uint32_t G, uint32_t T, uint32_
   return a < a_host ? a : a_host;
 }
 
-// Closing a run: the four coordinates go to the run's slot of the limb-major array (105 words, one 4-byte store each, 4 * stride
-// bytes apart).  -DZK_EXP_AOS_CLOSE (tools/aos_close_experiment.sh, round 6): a MEASUREMENT build that sends the same
-// 105 words to 432 contiguous bytes per slot instead - the WRITE side of an array-of-structures slot layout, readers unchanged, so
-// its results are WRONG; it exists to price the layout (WRITE_SIZE and the kernel's duration) before anybody rewrites the readers.
-#ifdef ZK_EXP_AOS_CLOSE
-#define ZK_CLOSE_RUN(acc, xs, zz, zzz, ty)                                                                          \
-  do {                                                                                                               \
-    XyzzRef aos_ = acc;                                                                                              \
-    aos_.voff = (acc.voff >> 2) * 432u;                                                                              \
-    aos_.stride_b = 4u;                                                                                              \
-    mem_st(aos_, CX, lds_ld_packed(xs)); mem_st(aos_, CZZ, lds_ld(zz)); mem_st(aos_, CZZZ, lds_ld(zzz));          \
-    mem_st(aos_, CY, ty);                                                                                            \
-  } while (0)
-#else
+// Closing a run: the four coordinates go to the run's slot (ec_mem.cuh: the slot array is an array of structures)
 #define ZK_CLOSE_RUN(acc, xs, zz, zzz, ty)                                                                          \
   do {                                                                                                               \
     mem_st(acc, CX, lds_ld_packed(xs)); mem_st(acc, CZZ, lds_ld(zz)); mem_st(acc, CZZZ, lds_ld(zzz));             \
     mem_st(acc, CY, ty);                                                                                             \
   } while (0)
-#endif
 
 // entries == nullptr: the sorted list IS the dense point array bp.p[0] (the output of the batched-affine levels, k_affine_level):
 // entry k is point k, never negated; a point may be the level encoding of infinity (skipped).
@@ -511,7 +507,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
   uint32_t* zz = lds_zz + threadIdx.x;
   uint32_t* zzz = lds_zzz + threadIdx.x;
   uint32_t* xs = lds_x + threadIdx.x;
-  XyzzRef acc = make_ref(slots, stride, 0);
+  XyzzRef acc = make_slot_ref(slots, stride, 0);
   bool inf = true;
   Fq ty = fp_zero<FqParams>();     // Y of the running accumulator, carried in registers across the additions of a run
   const bool dense = entries == nullptr;
@@ -569,7 +565,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(BasePtrs bp, int bshift, 
         bend = offsets[b] + counts[b];
         const bool starts = (k == offsets[b]), ends = (bend <= pos1);
         const uint32_t slot = (starts && ends) ? b : (!starts ? nb + t : nb + T + t);
-        acc.voff = slot * 4u;
+        acc.voff = slot * ZK_SLOT_PITCH;
         inf = true;
       }
       if (!inf) break;
@@ -848,8 +844,8 @@ __global__ void __launch_bounds__(256, 2) k_fixup_fold(const uint32_t* __restric
     const uint32_t n = cnt[0], per = QUAD ? 64u : 256u;
     for (uint32_t i = blockIdx.x * per + (QUAD ? threadIdx.x >> 2 : threadIdx.x); i < n; i += short_blocks * per) {
       const uint2 w = list_short[i];                    // first F slot, number of F pieces
-      const XyzzRef dst = make_ref(slots, stride, nb + w.x);
-      for (uint32_t j = 1; j < w.y; j++) pt_add<QUAD>(dst, make_ref(slots, stride, nb + w.x + j), q, sc);
+      const XyzzRef dst = make_slot_ref(slots, stride, nb + w.x);
+      for (uint32_t j = 1; j < w.y; j++) pt_add<QUAD>(dst, make_slot_ref(slots, stride, nb + w.x + j), q, sc);
     }
     return;
   }
@@ -859,7 +855,7 @@ __global__ void __launch_bounds__(256, 2) k_fixup_fold(const uint32_t* __restric
 #pragma unroll 1
     for (uint32_t d = 1; d <= w.y - w.x; d <<= 1) {
       for (uint64_t t = (uint64_t)w.x + (uint64_t)quad * 2 * d; t + d <= w.y; t += (uint64_t)64 * 2 * d)
-        add_mem_quad(make_ref(slots, stride, nb + (uint32_t)t), make_ref(slots, stride, nb + (uint32_t)t + d), q);
+        add_mem_quad(make_slot_ref(slots, stride, nb + (uint32_t)t), make_slot_ref(slots, stride, nb + (uint32_t)t + d), q);
       __threadfence_block();
       __syncthreads();
     }
@@ -884,7 +880,7 @@ __global__ void __launch_bounds__(256, 2) k_fixup(const uint32_t* __restrict__ o
   uint32_t b = bucket_of(offsets, nb, pos1 - 1);
   uint32_t bend = offsets[b] + counts[b];
   if (bend <= pos1 || offsets[b] < pos0) return;      // not cut at this slice's end, or started earlier
-  const XyzzRef dst = make_ref(slots, stride, b), pl = make_ref(slots, stride, nb + T + t), pf = make_ref(slots, stride, nb + t + 1);
+  const XyzzRef dst = make_slot_ref(slots, stride, b), pl = make_slot_ref(slots, stride, nb + T + t), pf = make_slot_ref(slots, stride, nb + t + 1);
   const bool l_inf = mem_is_inf(pl), f_inf = mem_is_inf(pf);
   if (l_inf || f_inf) {                                 // (a piece whose points cancelled: rare)
     if (l_inf && f_inf) mem_set_inf(dst);
@@ -928,7 +924,7 @@ __global__ void __launch_bounds__(256, 2) k_seg(uint32_t* __restrict__ in, size_
 // consecutive h for every (g, h / L, lo) (column sums).  in: n_in items with row stride in_stride words.
 template <bool QUAD>
 __global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_t n_in, uint32_t in_stride, int L, uint32_t row_len,
-                                                 uint32_t* __restrict__ out) {
+                                                 uint32_t* __restrict__ out, int in_slots /* `in` is the slot array (ec_mem.cuh) */) {
   ADD_SCRATCH_DECL(QUAD);
   size_t n_out = n_in / L;
   size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? gt >> 2 : gt;    // one lane / quad per output
@@ -936,14 +932,14 @@ __global__ void __launch_bounds__(256, 2) k_sum(uint32_t* __restrict__ in, size_
   if (t >= n_out) return;
   const size_t i0 = (t / row_len) * ((size_t)L * row_len) + (t % row_len);
   XyzzRef acc = make_ref(out, (uint32_t)n_out, (uint32_t)t);
-  pt_copy<QUAD>(acc, make_ref(in, in_stride, (uint32_t)i0), q);
-  for (int u = 1; u < L; u++) pt_add<QUAD>(acc, make_ref(in, in_stride, (uint32_t)(i0 + (size_t)u * row_len)), q, sc);
+  pt_copy<QUAD>(acc, make_in_ref(in, in_stride, (uint32_t)i0, in_slots), q);
+  for (int u = 1; u < L; u++) pt_add<QUAD>(acc, make_in_ref(in, in_stride, (uint32_t)(i0 + (size_t)u * row_len), in_slots), q, sc);
 }
 
 // k_sum with one lane per output and the running sum held on the CU (add_lds_regy): the throughput-bound plain sums of the bucket
 // reduction.  Same indexing as k_sum.
 __global__ void __launch_bounds__(256, 2) k_sum_lds(uint32_t* __restrict__ in, size_t n_in, uint32_t in_stride, int L, uint32_t row_len,
-                                                     uint32_t* __restrict__ out) {
+                                                     uint32_t* __restrict__ out, int in_slots /* `in` is the slot array (ec_mem.cuh) */) {
   __shared__ uint32_t lds_zz[27 * ZK_LDS_STRIDE], lds_zzz[27 * ZK_LDS_STRIDE], lds_x[24 * ZK_LDS_STRIDE];
   const size_t n_out = n_in / L;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -956,7 +952,7 @@ __global__ void __launch_bounds__(256, 2) k_sum_lds(uint32_t* __restrict__ in, s
   bool inf = true;
   Fq ty = fp_zero<FqParams>();
   for (int u = 0; u < L; u++) {
-    const XyzzRef B = make_ref(in, in_stride, (uint32_t)(i0 + (size_t)u * row_len));
+    const XyzzRef B = make_in_ref(in, in_stride, (uint32_t)(i0 + (size_t)u * row_len), in_slots);
     if (mem_is_inf(B)) continue;
     if (inf) {
       lds_st_packed(xs, mem_ld(B, CX));             // X of a stored point is an X3 [10]: below 2^768, packs into 24 words
@@ -1127,6 +1123,7 @@ __device__ __forceinline__ XyzzRef make_ref5(uint32_t* base, uint32_t stride, ui
   XyzzRef r;
   r.rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(135u * stride * 4u), 0x00020000);
   r.stride_b = stride * 4u;
+  r.coord_b = 27u * stride * 4u;
   r.voff = idx * 4u;
   return r;
 }
@@ -1540,9 +1537,9 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t to
     ctx->S = (uint32_t)S;
     ctx->T = (uint32_t)((m_max + S - 1) / S);
     ctx->slot_stride = (uint32_t)(nb + 2 * (size_t)ctx->T);
-    if ((size_t)ctx->slot_stride * 108 * 4 >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;
+    if ((size_t)ctx->slot_stride * ZK_SLOT_WORDS * 4 >= ((size_t)1 << 32)) return ZKHIP_ERR_ARG;
   }
-  HIP_TRY(hipMalloc(&ctx->buckets, (size_t)ctx->slot_stride * 108 * 4));
+  HIP_TRY(hipMalloc(&ctx->buckets, (size_t)ctx->slot_stride * ZK_SLOT_WORDS * 4));
   if (getenv("ZKHIP_DEBUG_DUMP")) HIP_TRY(hipMalloc(&ctx->dbg_times, ((size_t)ctx->T / 64 + 8) * 32));
   HIP_TRY(hipMalloc(&ctx->prio_board, (size_t)ZK_PRIO_BOARD_WORDS * 4));          // 8 XCC x 8 SE x 2 SH x 16 CU x 4 SIMD x 16 wave slots
   HIP_TRY(hipMemset(ctx->prio_board, 0, (size_t)ZK_PRIO_BOARD_WORDS * 4));
@@ -1737,7 +1734,15 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   const int tight = (ctx->one_stream || dense) ? 0 : env_int("ZKHIP_TIGHT_SLICES", 1, 0, 1);      // (a streaming prover shares the chip: see slice_len)
   // all-zero ZZ = infinity is what every reader of a slot tests first (mem_is_inf; X, Y, ZZZ of an infinite slot are copied along at
   // most, never used): only the 27 ZZ rows of the limb-major array need the zero fill - a quarter of the bytes
+#if ZK_SLOTS_AOS
+  {
+    static const int clear_mode = env_int("ZKHIP_SLOTS_CLEAR", 0, 0, 1);      // 0: the ZZ words only (a kernel); 1: the whole array (one memset, four times the bytes, whole lines)
+    if (clear_mode == 1) HIP_TRY(hipMemsetAsync(ctx->buckets, 0, (size_t)ctx->slot_stride * ZK_SLOT_WORDS * 4, st));
+    else hipLaunchKernelGGL(k_slots_clear_zz, dim3(nblk((size_t)ctx->slot_stride * 27, 256)), dim3(256), 0, st, ctx->buckets, ctx->slot_stride);
+  }
+#else
   HIP_TRY(hipMemsetAsync(ctx->buckets + (size_t)CZZ * 27 * ctx->slot_stride, 0, (size_t)ctx->slot_stride * 27 * 4, st));
+#endif
   if (ctx->dbg_times) HIP_TRY(hipMemsetAsync(ctx->dbg_times, 0, ((size_t)ctx->T / 64 + 8) * 32, st));
   if (ctx->acc_gate) HIP_TRY(hipStreamWaitEvent(st, ctx->acc_gate, 0));
   if (ctx->aff_levels == 0) HIP_TRY(hipEventRecord(ctx->ev_acc0, st));
@@ -1785,8 +1790,9 @@ int msm_launch_multi(MsmCtx* ctx, int K, const MsmJob* jobs) {
   const uint32_t Rr = 1u << lo_bits, Hh = 1u << hi_bits, Nn = Rr > Hh ? Rr : Hh;
   auto launch_sum = [&](hipStream_t s_, uint32_t* in, size_t n_in, uint32_t in_stride, int L, uint32_t row_len, uint32_t* out) {
     size_t n_out = n_in / L;
-    if (n_out >= QUAD_BELOW) hipLaunchKernelGGL(k_sum_lds, dim3(nblk(n_out, 256)), dim3(256), 0, s_, in, n_in, in_stride, L, row_len, out);
-    else hipLaunchKernelGGL(k_sum<true>, dim3(nblk(n_out * 4, 256)), dim3(256), 0, s_, in, n_in, in_stride, L, row_len, out);
+    const int in_slots = (in == ctx->buckets) ? 1 : 0;          // the first level reads the slot array (an array of structures: ec_mem.cuh)
+    if (n_out >= QUAD_BELOW) hipLaunchKernelGGL(k_sum_lds, dim3(nblk(n_out, 256)), dim3(256), 0, s_, in, n_in, in_stride, L, row_len, out, in_slots);
+    else hipLaunchKernelGGL(k_sum<true>, dim3(nblk(n_out * 4, 256)), dim3(256), 0, s_, in, n_in, in_stride, L, row_len, out, in_slots);
   };
   HIP_TRY(hipEventRecord(ctx->ev, st));
   HIP_TRY(hipStreamWaitEvent(st2, ctx->ev, 0));
