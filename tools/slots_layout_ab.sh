@@ -13,28 +13,32 @@ if [ "$1" = build ]; then
   ls -la $ROOT/build/libzkhip_limb.so
   exit 0
 fi
-OUT=$ROOT/gpurun_out/r06f
+OUT=$ROOT/gpurun_out/${OUTDIR:-r06f}
+VARIANTS=${VARIANTS:-"aos limb"}      # aos: the tree; limb: build/libzkhip_limb.so
+setlib() { if [ $1 = aos ]; then unset ZKHIP_LIB; else export ZKHIP_LIB=$ROOT/build/libzkhip_$1.so; fi; }
 mkdir -p $OUT
 cd $ROOT
 msm_line() { python3 -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d['roofline']; print('$1', '%.3f Mscalar/s' % d['value'], 'k_accumulate<1> alone %.3f ms' % r['kernel_ms'], 'mad peak this run %.2f G/s' % r['fq_mul_peak_this_run_g_per_s'])"; }
 val_line() { python3 -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$1', d['value'], d['unit'], 'ms_per_step', d['ms_per_step'], 'verifies', d.get('last_proof_verifies'))"; }
 for rep in 1 2 3; do
-  for v in aos limb; do
-    if [ $v = limb ]; then export ZKHIP_LIB=$ROOT/build/libzkhip_limb.so; else unset ZKHIP_LIB; fi
+  for v in $VARIANTS; do
+    setlib $v
     python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | msm_line "msm stream  $v" >> $OUT/ab.txt
   done
 done
 for rep in 1 2; do
-  for v in aos limb; do
-    if [ $v = limb ]; then export ZKHIP_LIB=$ROOT/build/libzkhip_limb.so; else unset ZKHIP_LIB; fi
+  for v in $VARIANTS; do
+    setlib $v
     python3 bench.py --workload prover --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | val_line "prover 2^20  $v" >> $OUT/ab.txt
     python3 bench.py --workload aggregator --steps 800 --warmup 80 --no-cpu-baseline 2>/dev/null | val_line "wrapping    $v" >> $OUT/ab.txt
+    python3 bench.py --workload aggregator --serial --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | val_line "wrapping one proof at a time $v" >> $OUT/ab.txt
+    python3 bench.py --serial --steps 6 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | msm_line "msm one at a time $v" >> $OUT/ab.txt
   done
 done
 cat $OUT/ab.txt
 cd /tmp && export TMPDIR=/tmp
-for v in aos limb; do
-  if [ $v = limb ]; then export ZKHIP_LIB=$ROOT/build/libzkhip_limb.so; else unset ZKHIP_LIB; fi
+for v in $VARIANTS; do
+  setlib $v
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$v -o t -- python3 $ROOT/bench.py --serial --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/trace_$v.log 2>&1
   find $OUT/trace_$v -name "*kernel_trace.csv" -delete; find $OUT/trace_$v -name "*.db" -delete
   for c in WRITE_SIZE FETCH_SIZE; do

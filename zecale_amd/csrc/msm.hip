@@ -1528,10 +1528,10 @@ int msm_plan_init(MsmCtx* ctx, size_t max_n, int c, int merged, int K, size_t to
     if (fills < 1) fills = 1;
     size_t S = (m_max + lanes * fills - 1) / (lanes * fills);
     if (S < 16) S = 16;
-    // the slot array (nb buckets + two boundary slots per slice) is addressed through ONE buffer descriptor: 108 rows x 4 bytes
-    // x slots < 4 GiB.  Large inputs (the five MSMs of a 2^22 key in one launch: 377 M entries) get longer slices instead of
+    // the slot array (nb buckets + two boundary slots per slice) is addressed through ONE buffer descriptor: 448 bytes (four
+    // coordinates of 28 words; ec_mem.cuh) x slots < 4 GiB.  Large inputs (the five MSMs of a 2^22 key in one launch: 377 M entries) get longer slices instead of
     // more of them.
-    const size_t max_slots = (((size_t)1 << 32) - 1) / (108 * 4);
+    const size_t max_slots = (((size_t)1 << 32) - 1) / (ZK_SLOT_WORDS * 4);
     if (nb + 64 >= max_slots) return ZKHIP_ERR_ARG;
     while (nb + 2 * ((m_max + S - 1) / S) >= max_slots) S += (S + 7) / 8;
     ctx->S = (uint32_t)S;
