@@ -257,3 +257,44 @@ def test_hybrid_witness_and_dispatcher_registration(zk):
         disp.register_app(bad)                     # off-curve key: refused on the first entry
     disp.free()
     crs.free(); r1.free(); kp.free(); agg.free()
+
+
+def test_application_table_evicts_and_failed_keys_hold_no_place(zk):
+    """a pipeline's table of application handles holds 32.  Until round 6 the 33rd key of a pipeline's life - and every
+    key after it, valid or not - took the plain path for good, and a key that could not be given a handle held a place for ever.  Now
+    the least recently used ready handle is evicted and failed keys go to a negative cache: 36 DISTINCT on-curve keys (the fixture's
+    key with ABC_0 / ABC_1 replaced by pairs of other G1 points of the fixtures), one batch each, are ALL proved from a handle -
+    after a degenerate key (ABC_1 = ABC_0: no handle) has been met several times - and the first key, evicted meanwhile, gets its
+    handle again.  Every proof equals the plain serial proof of the full assignment."""
+    agg, desc, kp, nvk_l, proofs = _setup(zk)
+    crs, r1 = kp.upload_crs(), zk.r1cs_from_desc(desc)
+    pts = [nvk_l[60:72].copy(), nvk_l[72:84].copy()]
+    for pr, _ in proofs:
+        l = nested_proof_limbs(pr)
+        pts += [l[:12].copy(), l[36:48].copy()]                              # A and C of the six fixture proofs: points of G1
+    keys = []
+    for i in range(len(pts)):
+        for j in range(len(pts)):
+            if i != j and len(keys) < 36 and not (pts[i] == pts[j]).all():
+                k = nvk_l.copy(); k[60:72] = pts[i]; k[72:84] = pts[j]
+                keys.append(k)
+    assert len(keys) == 36 and len({bytes(k) for k in keys}) == 36
+    pipe = zk.AggregatorPipeline(agg, crs, gpu_slots=2, witness_workers=2)
+    npr, nin = _batch(proofs, 0, 1)
+    deg = nvk_l.copy(); deg[72:84] = deg[60:72]
+    for _ in range(3):                                                        # no handle, no place taken, proved all the same
+        prim, proof = pipe.wait(pipe.submit(deg, npr, nin, fr_limbs(5), fr_limbs(6)))
+        assert zk.groth16_verify(kp.vk(), prim, proof)
+    assert pipe.app_hits() == 0
+    with pytest.raises(zk.ZkhipError):
+        pipe.register_app(deg)
+    for n, k in enumerate(keys):
+        prim, proof = pipe.wait(pipe.submit(k, npr, nin, fr_limbs(0x100 + n), fr_limbs(0x200 + n)))
+        assert pipe.app_hits() == n + 1, (n, pipe.app_hits())                # (before round 6: stuck at 32)
+        if n in (0, 31, 32, 35):
+            z = agg.witness(k, npr, nin)
+            assert (prim == z[1:1 + agg.num_primary_inputs()]).all()
+            assert (proof == zk.groth16_prove(crs, r1, z, fr_limbs(0x100 + n), fr_limbs(0x200 + n))).all()
+    prim, proof = pipe.wait(pipe.submit(keys[0], npr, nin, fr_limbs(7), fr_limbs(8)))      # evicted by now: built again, used at once
+    assert pipe.app_hits() == 37 and zk.groth16_verify(kp.vk(), prim, proof)
+    pipe.free(); crs.free(); r1.free(); kp.free(); agg.free()
