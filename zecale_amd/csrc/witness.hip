@@ -124,7 +124,7 @@ __device__ __forceinline__ bool w_exec(uint32_t c, int32_t rb, const FrD& x, con
 // barrier and no waiting for stores between levels.  What a level costs is then the latency of its operands, and the
 // program being static, almost all of it is taken off the critical path:
 //   * the instruction words are fetched three chunks ahead;
-//   * the last 1,024 results wait in an LDS ring (slot = position mod 1,024: the last 16 chunks) - nine operands in ten;
+//   * the last RING results wait in an LDS ring (slot = position mod RING; 1,024 = the last 16 chunks held nine operands in ten);
 //   * an older operand is loaded from the value array one chunk ahead (its store is many chunks old).
 // (A witness is cut into several launches of a few milliseconds so that the kernels of the provers that share a hardware queue
 // with it are not held up for its whole duration.)
@@ -152,15 +152,26 @@ __device__ __forceinline__ void w_prefetch(const WitnessProg& P, const uint32_t*
   py = w_ld(reinterpret_cast<const uint4*>(pb));
 }
 
-constexpr uint32_t WIT_RING = 1024;      // 64 KiB of the CU's 160
-__global__ void __launch_bounds__(64) k_witness(WitnessProg P, uint32_t c0, uint32_t c1, const uint64_t* __restrict__ inputs /* batches x n_inputs x 6, ABI */,
-                                                 uint32_t* __restrict__ values /* batches x n_pos x 16 */, uint32_t* __restrict__ flags) {
-  __shared__ uint4 ring[WIT_RING * 4];
+// WPG witnesses per WORKGROUP, one wave each, RING results per wave in LDS: WPG x RING x 64 B = 64 KiB of the CU's 160 whatever the
+// split.  Why the split matters (round 6): a witness wave cannot share a CU with TWO workgroups of k_accumulate (78 KiB of LDS and
+// all 512 VGPRs of every SIMD each pair), so every CU that hosts a witness workgroup runs ONE accumulation workgroup instead of two -
+// one wave per SIMD, 78 % of the multiplier's rate - for as long as the witness launch lasts.  With one witness per workgroup and
+// its 64 KiB ring (rounds 3-5) a launch of sixteen witnesses took a slot on SIXTEEN CUs and eight launches in flight on half the
+// chip: the 10 % by which the GPU generator trailed the device's own limit.  Four witnesses per workgroup - one wave per SIMD, a
+// quarter of the ring each - take the same slot on FOUR CUs.  The shorter ring (the last 4 chunks instead of 16) turns some ring hits
+// into prefetches from the value array, which the chunk-ahead prefetch already covers (it always issues its two loads per lane).
+template <uint32_t WPG, uint32_t WIT_RING>
+__global__ void __launch_bounds__(64 * WPG) k_witness(WitnessProg P, uint32_t c0, uint32_t c1, const uint64_t* __restrict__ inputs /* batches x n_inputs x 6, ABI */,
+                                                       uint32_t* __restrict__ values /* batches x n_pos x 16 */, uint32_t* __restrict__ flags, uint32_t n_batches) {
+  __shared__ uint4 ring_all[WPG * WIT_RING * 4];
   __shared__ uint4 subk[WT_SUBK_LEVELS * 4];
-  const uint32_t batch = blockIdx.x, lane = threadIdx.x;
-  if (lane < WT_SUBK_LEVELS * 4) subk[lane] = reinterpret_cast<const uint4*>(P.subk)[lane];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t batch = blockIdx.x * WPG + wave;
+  uint4* ring = ring_all + (size_t)wave * WIT_RING * 4;
+  if (lane < WT_SUBK_LEVELS * 4) subk[lane] = reinterpret_cast<const uint4*>(P.subk)[lane];      // (every wave writes the same words, and reads what IT wrote)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  if (batch >= n_batches) return;                                   // (whole waves: nothing below synchronises across waves)
   const uint64_t* in = inputs + (size_t)batch * P.n_inputs * 6;
   uint32_t* vals = values + (size_t)batch * P.n_pos * WSLOT;
   uint32_t bad = 0;
@@ -374,8 +385,14 @@ void witness_launch(const WitnessProg& P, const uint64_t* d_inputs, uint32_t* d_
   (void)hipEventRecord(ev_join, st_chain);
   static const uint32_t seg_env = [] { const char* e = getenv("ZKHIP_WITNESS_SEGMENT"); int v = e ? atoi(e) : 0; return (uint32_t)(v >= 64 && v <= (1 << 20) ? v : 2048); }();
   const uint32_t n_chunks = P.chain_start / 64, seg = seg_env;       // chunks per launch: a few milliseconds (tuning knob: ZKHIP_WITNESS_SEGMENT)
-  for (uint32_t c0 = 0; c0 < n_chunks; c0 += seg)
-    hipLaunchKernelGGL(k_witness, dim3(batches), dim3(64), 0, st, P, c0, (c0 + seg < n_chunks ? c0 + seg : n_chunks), d_inputs, d_values, d_flags);
+  // witnesses per workgroup (see k_witness): 4 by default; ZKHIP_WITNESS_WPG = 1 | 2 | 4 (1: rounds 3-5's form, a 64 KiB ring per witness)
+  static const int wpg = [] { const char* e = getenv("ZKHIP_WITNESS_WPG"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
+  for (uint32_t c0 = 0; c0 < n_chunks; c0 += seg) {
+    const uint32_t c1 = c0 + seg < n_chunks ? c0 + seg : n_chunks;
+    if (wpg == 4) hipLaunchKernelGGL((k_witness<4, 256>), dim3((batches + 3) / 4), dim3(256), 0, st, P, c0, c1, d_inputs, d_values, d_flags, batches);
+    else if (wpg == 2) hipLaunchKernelGGL((k_witness<2, 512>), dim3((batches + 1) / 2), dim3(128), 0, st, P, c0, c1, d_inputs, d_values, d_flags, batches);
+    else hipLaunchKernelGGL((k_witness<1, 1024>), dim3(batches), dim3(64), 0, st, P, c0, c1, d_inputs, d_values, d_flags, batches);
+  }
   (void)hipStreamWaitEvent(st, ev_join, 0);
   hipLaunchKernelGGL(k_witness_out, dim3((P.n_vars + 255) / 256, batches), dim3(256), 0, st, P, d_values, d_z);
 }

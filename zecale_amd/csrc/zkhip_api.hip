@@ -1862,6 +1862,10 @@ int zkhip_gpu_witness_new_batched(zkhip_aggregator* a, size_t max_batches, zkhip
   if (e == hipSuccess) e = hipMalloc(&w->d_vals, max_batches * (size_t)w->prog.n_pos * witness_value_bytes);
   if (e == hipSuccess) e = hipMalloc(&w->d_flag, max_batches * 4 + 64);
   if (e == hipSuccess) e = hipHostMalloc(&w->h_in, max_batches * (w->in_words + 1 + a->n_primary * 6) * 8);
+  // (High-priority streams for the witness launches - hardware queues of their own instead of a place behind some prover's 2 ms
+  //  accumulation launch - were measured in round 6 and LOSE 10 %: 256-265 -> 221-234 proofs/s with nine inputs, 444-449 -> 395-407 with
+  //  one, profiles/r06_witness_wpg_and_priority.txt.  A witness wave that is dispatched at once takes its CU slot at once, on whatever
+  //  CU frees one first; what the provers need is that those slots are FEW, which is what k_witness's four waves a workgroup do.)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->st2, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev, hipEventBlockingSync | hipEventDisableTiming);
