@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--stream", type=int, default=0, help="also push this many proofs through the streaming prover")
     ap.add_argument("--prove-stream", type=int, default=0, help="GPU side only: this many proofs of ONE precomputed assignment through --gpu-slots "
                     "prover instances on a host thread each (no witness generation: the device's capacity, with less host noise)")
+    ap.add_argument("--app", action="store_true", help="--prove-stream: the MASKED assignment of the registered application through zkhip_prover_prove_app "
+                    "(the streaming pipeline's steady state with the per-application constants on) instead of the full one")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the --stream / --prove-stream measurement this many times")
     ap.add_argument("--gpu-slots", type=int, default=24)
     ap.add_argument("--depth", type=int, default=0, help="--stream: batches the caller keeps outstanding (0 = gpu slots + witness workers + 2)")
@@ -149,6 +151,8 @@ def main():
             for p_ in provers:
                 p_.set_streaming(True)
                 p_.prove(z, rr, ss)                      # work space
+            app = zkhip.AggregatorApp(agg, crs, nvk_l) if args.app else None
+            zm = app.witness(npr, nin) if args.app else None
             rates = []
             for _ in range(args.repeat):
                 counter, lock, outs = [args.prove_stream], threading.Lock(), []
@@ -159,13 +163,15 @@ def main():
                             if counter[0] <= 0:
                                 return
                             counter[0] -= 1
-                        outs.append(p_.prove(z, rr, ss))
+                        outs.append(p_.prove_app(app, zm, rr, ss) if args.app else p_.prove(z, rr, ss))
                 ths = [threading.Thread(target=worker, args=(p_,)) for p_ in provers]
                 t = time.time()
                 [x.start() for x in ths]; [x.join() for x in ths]
                 rates.append(round(args.prove_stream / (time.time() - t), 1))
                 assert all((o == ref_proof).all() for o in outs[-4:])
-            line.update(prove_stream_proofs_per_s=rates)
+            line.update(prove_stream_proofs_per_s=rates, masked_assignment=bool(args.app))
+            if app is not None:
+                app.free()
             for p_ in provers:
                 p_.free()
             if saved is not None:
