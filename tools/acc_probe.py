@@ -72,6 +72,8 @@ def main():
                     "prover instances on a host thread each (no witness generation: the device's capacity, with less host noise)")
     ap.add_argument("--app", action="store_true", help="--prove-stream: the MASKED assignment of the registered application through zkhip_prover_prove_app "
                     "(the streaming pipeline's steady state with the per-application constants on) instead of the full one")
+    ap.add_argument("--pinned", action="store_true", help="--prove-stream: the assignment lives in PINNED host memory (zkhip_host_alloc) - the per-proof upload "
+                    "is then a DMA the stream waits for, not a staged copy the host thread drives")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the --stream / --prove-stream measurement this many times")
     ap.add_argument("--gpu-slots", type=int, default=24)
     ap.add_argument("--depth", type=int, default=0, help="--stream: batches the caller keeps outstanding (0 = gpu slots + witness workers + 2)")
@@ -153,6 +155,16 @@ def main():
                 p_.prove(z, rr, ss)                      # work space
             app = zkhip.AggregatorApp(agg, crs, nvk_l) if args.app else None
             zm = app.witness(npr, nin) if args.app else None
+            pin = None
+            if args.pinned:
+                import ctypes
+                src = zm if args.app else z
+                pin = zkhip.PinnedBuffer(src)
+                view = np.ctypeslib.as_array(ctypes.cast(pin.ptr, ctypes.POINTER(ctypes.c_uint64)), (src.size,)).reshape(src.shape)
+                if args.app:
+                    zm = view
+                else:
+                    z = view
             rates = []
             for _ in range(args.repeat):
                 counter, lock, outs = [args.prove_stream], threading.Lock(), []
@@ -169,7 +181,9 @@ def main():
                 [x.start() for x in ths]; [x.join() for x in ths]
                 rates.append(round(args.prove_stream / (time.time() - t), 1))
                 assert all((o == ref_proof).all() for o in outs[-4:])
-            line.update(prove_stream_proofs_per_s=rates, masked_assignment=bool(args.app))
+            line.update(prove_stream_proofs_per_s=rates, masked_assignment=bool(args.app), pinned_assignment=bool(args.pinned))
+            if pin is not None:
+                pin.free()
             if app is not None:
                 app.free()
             for p_ in provers:
