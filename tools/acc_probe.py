@@ -72,6 +72,7 @@ def main():
                     "prover instances on a host thread each (no witness generation: the device's capacity, with less host noise)")
     ap.add_argument("--app", action="store_true", help="--prove-stream: the MASKED assignment of the registered application through zkhip_prover_prove_app "
                     "(the streaming pipeline's steady state with the per-application constants on) instead of the full one")
+    ap.add_argument("--dev", action="store_true", help="--prove-stream --app: the masked assignment already in DEVICE memory (zkhip_prover_prove_app_dev): no upload per proof")
     ap.add_argument("--pinned", action="store_true", help="--prove-stream: the assignment lives in PINNED host memory (zkhip_host_alloc) - the per-proof upload "
                     "is then a DMA the stream waits for, not a staged copy the host thread drives")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the --stream / --prove-stream measurement this many times")
@@ -155,6 +156,7 @@ def main():
                 p_.prove(z, rr, ss)                      # work space
             app = zkhip.AggregatorApp(agg, crs, nvk_l) if args.app else None
             zm = app.witness(npr, nin) if args.app else None
+            dbuf = zkhip.DeviceBuffer(zm) if (args.app and args.dev) else None
             pin = None
             if args.pinned:
                 import ctypes
@@ -175,13 +177,15 @@ def main():
                             if counter[0] <= 0:
                                 return
                             counter[0] -= 1
-                        outs.append(p_.prove_app(app, zm, rr, ss) if args.app else p_.prove(z, rr, ss))
+                        outs.append(p_.prove_app_dev(app, dbuf.ptr, rr, ss) if (args.app and args.dev) else (p_.prove_app(app, zm, rr, ss) if args.app else p_.prove(z, rr, ss)))
                 ths = [threading.Thread(target=worker, args=(p_,)) for p_ in provers]
                 t = time.time()
                 [x.start() for x in ths]; [x.join() for x in ths]
                 rates.append(round(args.prove_stream / (time.time() - t), 1))
                 assert all((o == ref_proof).all() for o in outs[-4:])
-            line.update(prove_stream_proofs_per_s=rates, masked_assignment=bool(args.app), pinned_assignment=bool(args.pinned))
+            line.update(prove_stream_proofs_per_s=rates, masked_assignment=bool(args.app), pinned_assignment=bool(args.pinned), device_assignment=bool(args.app and args.dev))
+            if dbuf is not None:
+                dbuf.free()
             if pin is not None:
                 pin.free()
             if app is not None:

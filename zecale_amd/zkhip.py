@@ -842,6 +842,17 @@ class Prover:
         _check(lib.zkhip_prover_prove_app(self.handle, app.handle, _p(z), _p(r), _p(s), _p(out)))
         return out
 
+    def prove_app_dev(self, app, d_z_masked, r, s):
+        """zkhip_prover_prove_app_dev: the masked assignment already in DEVICE memory (an integer pointer; what the application's GPU
+        program writes).  Precondition: it is masked (see include/zkhip.h) - not checked."""
+        c = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        r, s = c(r), c(s)
+        out = np.zeros(72, dtype=np.uint64)
+        lib = load()
+        lib.zkhip_prover_prove_app_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_u64p_t, c_u64p_t, c_u64p_t]
+        _check(lib.zkhip_prover_prove_app_dev(self.handle, app.handle, ctypes.c_void_p(int(d_z_masked)), _p(r), _p(s), _p(out)))
+        return out
+
     def create_streams(self, which):
         """zkhip_prover_create_streams: for a caller with several instances - which = 0 for all of them, then which = 1 for all"""
         _check(load().zkhip_prover_create_streams(self.handle, int(which)))
