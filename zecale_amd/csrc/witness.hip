@@ -160,6 +160,10 @@ __device__ __forceinline__ void w_prefetch(const WitnessProg& P, const uint32_t*
 // chip: the 10 % by which the GPU generator trailed the device's own limit.  Four witnesses per workgroup - one wave per SIMD, a
 // quarter of the ring each - take the same slot on FOUR CUs.  The shorter ring (the last 4 chunks instead of 16) turns some ring hits
 // into prefetches from the value array, which the chunk-ahead prefetch already covers (it always issues its two loads per lane).
+#ifndef ZK_WITNESS_PRIO
+#define ZK_WITNESS_PRIO 1
+#endif
+constexpr int WIT_PRIO = ZK_WITNESS_PRIO;
 template <uint32_t WPG, uint32_t WIT_RING>
 __global__ void __launch_bounds__(64 * WPG) k_witness(WitnessProg P, uint32_t c0, uint32_t c1, const uint64_t* __restrict__ inputs /* batches x n_inputs x 6, ABI */,
                                                        uint32_t* __restrict__ values /* batches x n_pos x 16 */, uint32_t* __restrict__ flags, uint32_t n_batches) {
@@ -172,6 +176,11 @@ __global__ void __launch_bounds__(64 * WPG) k_witness(WitnessProg P, uint32_t c0
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (batch >= n_batches) return;                                   // (whole waves: nothing below synchronises across waves)
+  // A witness wave shares its SIMD with a wave of k_accumulate, which raises its own priority as it goes (s_setprio 1 .. 3): at the
+  // default priority the witness wave got the issue slots the other one left - a launch of sixteen witnesses lasted ~190 ms beside the
+  // provers against ~25 ms alone, holding its CUs' second workgroup slot all that time.  Its instruction stream is a trickle next to
+  // the accumulation's (a dependent chain that waits on LDS and memory most of the time), so it takes the SIMD whenever it can issue.
+  if (WIT_PRIO) __builtin_amdgcn_s_setprio(3);
   const uint64_t* in = inputs + (size_t)batch * P.n_inputs * 6;
   uint32_t* vals = values + (size_t)batch * P.n_pos * WSLOT;
   uint32_t bad = 0;
