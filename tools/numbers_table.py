@@ -18,7 +18,7 @@ def both(fmt, *keys):
 
 
 rows = [
-    ("G1 MSM, 2^20 terms, uniform scalars, table-backed resident bases, eight in flight (BASELINE configs[1])", "84.17", "`value`, `ms_per_step`",
+    ("G1 MSM, 2^20 terms, uniform scalars, table-backed resident bases, ten in flight (round 5: eight) (BASELINE configs[1])", "84.17", "`value`, `ms_per_step`",
      both("**{} Mscalar/s**, {} ms per MSM", "value", "ms_per_step")),
     ("`k_accumulate<1>` ALONE on the chip", "11.07 ms", "`roofline.kernel_ms`, `.fq_mul_frac_vs_this_run_peak`, `.fq_mul_peak_this_run_g_per_s`",
      both("{} ms; {} of this run's measured multiplier peak ({} G Fq-mul/s)", "roofline.kernel_ms", "roofline.fq_mul_frac_vs_this_run_peak", "roofline.fq_mul_peak_this_run_g_per_s")),
@@ -34,7 +34,7 @@ rows = [
      both("{} ms, {} of this run's peak", "prover_2_20.roofline.kernel_ms", "prover_2_20.roofline.fq_mul_frac_vs_this_run_peak")),
     ("... the C restatement proving the SAME system on 16 host cores, one whole proof timed, proof limb-identical", "-", "`prover_2_20.cpu_baseline`",
      both("{} proofs/s", "prover_2_20.cpu_baseline.value")),
-    ("Groth16 proof over 2^22 - 8 constraints (body of configs[3]) on one GPU, two in flight, verified", "5.917", "`prover_2_22`",
+    ("Groth16 proof over 2^22 - 8 constraints (body of configs[3]) on one GPU, four in flight (round 5: two), verified", "5.917", "`prover_2_22`",
      both("**{} proofs/s** ({} ms)", "prover_2_22.value", "prover_2_22.ms_per_proof")),
     ("the real batch-2 wrapping circuit (44,183 constraints, **65,536-point domain**), host witness, per-application constants, steady state", "(in the driver's record only as a key name)", "`wrapping_prover.value`, `.host_cores_busy`",
      both("**{} proofs/s** on {} host cores", "wrapping_prover.value", "wrapping_prover.host_cores_busy")),
