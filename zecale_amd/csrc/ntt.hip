@@ -127,10 +127,19 @@ __device__ __forceinline__ uint32_t lds_sw(uint32_t p) {
 }
 
 // Inputs < 8r (every producer here stores < 2r); values grow by at most 2r per stage (< 2^7 r = 2^384 at the end).
+// A workgroup of the QAP map's kernels that becomes resident beside the provers takes the place of one of a CU's two k_accumulate
+// workgroups (displacement), whose waves raise their own priority as they go: at the default priority a short
+// kernel's waves get the issue slots the accumulation leaves and hold their CU slot several times longer than their work takes.
+// They ask for the SIMD instead (-DZK_SHORT_KERNEL_PRIO=0: off).
+#ifndef ZK_SHORT_KERNEL_PRIO_LEVEL
+#define ZK_SHORT_KERNEL_PRIO_LEVEL 3
+#endif
+#define ZK_SHORT_KERNEL_PRIO() do { if (ZK_SHORT_KERNEL_PRIO_LEVEL) __builtin_amdgcn_s_setprio(ZK_SHORT_KERNEL_PRIO_LEVEL); } while (0)
 template <int LOGK, int LOGC>
 __global__ void __launch_bounds__(pass_threads(LOGK, LOGC)) k_ntt_pass(PassArgs a) {
   constexpr uint32_t K = 1u << LOGK, C = 1u << LOGC, E = K * C, T = pass_threads(LOGK, LOGC);
   __shared__ uint32_t lds[14 * E];
+  ZK_SHORT_KERNEL_PRIO();
   const uint32_t tid = threadIdx.x;
   const uint32_t q0 = blockIdx.x * C;
   uint32_t* const data = a.data[blockIdx.y];

@@ -74,6 +74,10 @@ __device__ __forceinline__ uint32_t part_index(const PartLayout& L, uint32_t loc
 
 template <int LG>
 __global__ void __launch_bounds__(256) k_spmv(Spmv3 m, const uint32_t* __restrict__ z, uint32_t n, uint32_t d, PartLayout lay) {
+#ifndef ZK_SHORT_KERNEL_PRIO_LEVEL
+#define ZK_SHORT_KERNEL_PRIO_LEVEL 3
+#endif
+  if (ZK_SHORT_KERNEL_PRIO_LEVEL) __builtin_amdgcn_s_setprio(ZK_SHORT_KERNEL_PRIO_LEVEL);      // (ntt.hip: a short kernel beside the provers asks for the SIMD)
   const uint32_t* __restrict__ row_ptr = m.row_ptr[blockIdx.y];
   const uint32_t* __restrict__ col = m.col[blockIdx.y];
   const uint32_t* __restrict__ val = m.val[blockIdx.y];
