@@ -236,6 +236,10 @@ def test_setup_slice_is_the_slice_of_the_whole_setup(zk, domain):
         assert all((v1[k] == v0[k]).all() for k in ("alpha", "beta", "delta", "ABC")) and vk_only.domain_size == dom
         c1, c0 = vk_only.consts(), kp.consts()
         assert all((c1[k] == c0[k]).all() for k in c0)
+        if rank == 0:                       # the keypair of a slice setup holds no queries: asking for them is an error, not a crash
+            for call in (vk_only.pk_arrays, vk_only.upload_crs, lambda: vk_only.write("/tmp/zkhip_no_queries.bin")):
+                with pytest.raises(zk.ZkhipError):
+                    call()
         sl.free(); ref.free(); vk_only.free()
     got = zk.groth16_finish(kp.consts(), total, rr, ss)
     assert (got == expect).all() and zk.groth16_verify(kp.vk(), zl[1:1 + n_primary], got)

@@ -1741,6 +1741,8 @@ uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
 
 int zkhip_keypair_write(const zkhip_keypair* kp, const char* path) {
   if (!kp || !path) return fail(ZKHIP_ERR_ARG, "null pointer");
+  if (kp->A.size() != kp->n_vars * 24 || kp->H.size() != (kp->domain_size - 1) * 24)
+    return fail(ZKHIP_ERR_ARG, "this keypair holds no query vectors (zkhip_groth16_setup_slice keeps the slice on the device): nothing to write");
   FILE* f = fopen(path, "wb");
   if (!f) return fail(ZKHIP_ERR_ARG, "cannot open the keypair file for writing");
   uint64_t hdr[8] = {0, (uint64_t)kp->n_vars, (uint64_t)kp->n_primary, (uint64_t)kp->domain_size, 0, 0, 0, 0};

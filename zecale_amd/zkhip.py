@@ -1078,6 +1078,8 @@ class Keypair:
         """opts: key_opts(...) - this key's own table / launch options (None: the process defaults)."""
         d = CrsDesc()
         _check(load().zkhip_keypair_crs_desc(self.handle, ctypes.byref(d)))
+        if d.n_vars and not d.a_query:
+            raise ZkhipError("this keypair holds no query vectors (Keypair.setup_slice): there is nothing to upload")
         crs = Crs.__new__(Crs)
         h = ctypes.c_void_p()
         _check(load().zkhip_crs_upload_ex(ctypes.byref(d), ctypes.byref(opts) if opts is not None else None, ctypes.byref(h)))
@@ -1096,6 +1098,8 @@ class Keypair:
         d = CrsDesc()
         _check(load().zkhip_keypair_crs_desc(self.handle, ctypes.byref(d)))
         m, l, dom = d.n_vars, d.n_primary, d.domain_size
+        if m and not d.a_query:
+            raise ZkhipError("this keypair holds no query vectors (Keypair.setup_slice: the slice lives on the device; vk() and consts() are what it keeps)")
         arr = lambda ptr, n: (np.ctypeslib.as_array(ctypes.cast(ptr, c_u64p_t), (n, 24)).copy() if n else np.zeros((0, 24), dtype=np.uint64))
         pk = {k: arr(getattr(d, k), 1).reshape(24) for k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2")}
         pk.update(A=arr(d.a_query, m), B2=arr(d.b_g2_query, m), B1=arr(d.b_g1_query, m), H=arr(d.h_query, dom - 1), L=arr(d.l_query, m - l - 1))
